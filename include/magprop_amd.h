@@ -1,0 +1,154 @@
+/*
+ * magprop_amd.h — C ABI of the MI355X-native magnetar log-posterior hot path.
+ *
+ * This is the drop-in boundary for the ONE data-parallel path of sgibson91/magprop
+ * that this project accelerates: for each of N walkers, lnprior + integrate the
+ * (Mdisc, omega) ODEs over the 10 001-point log grid + luminosity light curve +
+ * linear interpolation at the observed times + -0.5*chi^2.
+ *
+ * Reference interfaces replaced (paths relative to the reference checkout):
+ *   - lnprob(pars, x, y, yerr, fbad)            code/synthetic_datasets/mcmc_eqns.py:52-81
+ *   - lnlike(pars, x, y, yerr)                  code/synthetic_datasets/mcmc_eqns.py:5-25
+ *   - lnprior(pars)                             code/synthetic_datasets/mcmc_eqns.py:28-49
+ *   - model_lum(pars, xdata=None, n, alpha, cs7, k, dipeff, propeff, f_beam)
+ *                                               code/synthetic_datasets/funcs.py:146-236
+ *   - lnprob(pars, data, GRBtype, custom_lims)  magnetar/mcmc_eqns.py:87-119
+ *   - lnlike(pars, data, GRBtype)               magnetar/mcmc_eqns.py:6-37
+ *   - lnprior(pars, custom_lims)                magnetar/mcmc_eqns.py:40-84
+ *   - model_lc(pars, xdata, GRBtype, ...)       magnetar/funcs.py:105-220
+ *   - init_conds / odes / ODEs                  magnetar/funcs.py:17-101,
+ *                                               code/synthetic_datasets/funcs.py:51-142
+ * The reference is pure Python; its "FFI" for this path is the emcee log_prob_fn
+ * callable (code/synthetic_datasets/synth_mcmc.py:180-185).  The ctypes binding a
+ * maintainer would add is shown in INTEGRATION.md and shipped in
+ * magprop_amd/_capi.py.
+ *
+ * Conventions
+ *   - plain C, no torch / C++ types in any signature; caller owns every buffer.
+ *   - every function returning int returns MP_OK (0) or a negative MP_E* code and
+ *     records a message retrievable with mp_last_error() (thread-local).
+ *   - per-walker physics failures are NOT errors: lnprob = -inf and a status code
+ *     (reference: the string 'flag', magnetar/funcs.py:153-154).
+ *   - all floating point is IEEE fp64.
+ */
+#ifndef MAGPROP_AMD_H
+#define MAGPROP_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MP_ABI_VERSION 1
+
+/* return codes */
+#define MP_OK 0
+#define MP_EINVAL (-1)  /* bad argument (NULL, size, ds_id, ndim ...)            */
+#define MP_EHIP (-2)    /* a HIP runtime call failed; see mp_last_error()         */
+#define MP_ERANGE (-3)  /* observed time outside the model grid (interp1d raises  */
+                        /* ValueError there: magnetar/funcs.py:214-215)           */
+#define MP_ENODEV (-4)  /* no usable gfx950 device                                */
+#define MP_ESTATE (-5)  /* call order problem (dataset / prior not set)           */
+
+/* per-walker status (reference: success / 'flag' string / non-finite lnlike) */
+#define MP_STATUS_OK 0
+#define MP_STATUS_FLAG 1      /* break-up limit reached: the reference's LSODA 'flag'   */
+#define MP_STATUS_NONFINITE 2 /* state or chi^2 went non-finite                         */
+#define MP_STATUS_PRIOR 3     /* outside the prior box, model never evaluated           */
+
+/* limits */
+#define MP_MAX_NDIM 9        /* 6 physics parameters + up to dipeff, propeff, f_beam */
+#define MP_MAX_DATASETS 64
+
+/*
+ * The two physics variants of the reference are data, not code forks
+ * (SURVEY.md section 2.1).  mp_cfg_synth()/mp_cfg_lib() fill the two presets.
+ */
+typedef struct mp_model_cfg {
+    double inertia_factor;     /* I = f*M*R^2 : 0.8 (magnetar/funcs.py:12) | 0.35 (code/synthetic_datasets/funcs.py:17) */
+    double rm_massflow_factor; /* Rm ~ (f*Mdisc/tvisc)^(-2/7): 1 (magnetar/funcs.py:64) | 3 (synth funcs.py:105)        */
+    double n_ode;              /* propeller switch-on inside the ODE right-hand side                                    */
+    double n_lum;              /* propeller switch-on in the luminosity stage                                           */
+    double alpha;              /* sound-speed prescription                                                              */
+    double cs7;                /* sound speed, 1e7 cm/s                                                                 */
+    double k;                  /* light-cylinder capping fraction                                                       */
+    double dipeff;             /* default dipole efficiency   (overridden per walker when ndim is 8 or 9)               */
+    double propeff;            /* default propeller efficiency (overridden per walker when ndim is 8 or 9)              */
+    double f_beam;             /* default beaming fraction     (overridden per walker when ndim is 7 or 9)              */
+    double nacc_lum_threshold; /* luminosity-stage break-up test: 0.27 (synth funcs.py:206) | 0.0 (magnetar/funcs.py:193) */
+    int32_t lprop_gm_term;     /* 1: Lprop includes -(GM/Rm)*eta2*Mdisc/tvisc (synth funcs.py:222-223); 0: lib          */
+    int32_t reserved;
+} mp_model_cfg;
+
+typedef struct mp_handle mp_handle;
+
+int mp_abi_version(void);
+const char *mp_last_error(void);
+
+void mp_cfg_synth(mp_model_cfg *cfg); /* code/synthetic_datasets/funcs.py:146-147 defaults */
+void mp_cfg_lib(mp_model_cfg *cfg);   /* magnetar/funcs.py:105-106 defaults; ODE always n=1 (funcs.py:150-151) */
+
+/*
+ * Create an evaluator bound to HIP device `device` (-1: the calling thread's current
+ * device).  `tgrid` (host pointer, n_grid >= 2 strictly increasing doubles) is the
+ * output/integration grid: np.logspace(0,6,10001) or np.logspace(-3,6,10001)
+ * (magnetar/funcs.py:132-137).  The grid is copied to the device.
+ */
+mp_handle *mp_create(const mp_model_cfg *cfg, const double *tgrid, int n_grid, int device);
+int mp_destroy(mp_handle *h);
+
+/*
+ * Register (or replace) observed light curve `ds_id` (0 <= ds_id < MP_MAX_DATASETS):
+ * x = times [s], y = luminosity [1e50 erg/s], yerr = 1-sigma errors; host pointers.
+ * Returns MP_ERANGE if any x lies outside [tgrid[0], tgrid[n_grid-1]].
+ */
+int mp_set_dataset(mp_handle *h, int ds_id, const double *x, const double *y, const double *yerr, int n_obs);
+
+/*
+ * Box prior (inclusive), lower/upper[ndim].  Bit i of log_mask set: sampler
+ * coordinate i is log10 of the physical parameter and is un-logged before the
+ * model is evaluated (code/synthetic_datasets/mcmc_eqns.py:16-17).  ndim = 0
+ * disables the prior (lnlike only; pars then taken as given, un-logged per log_mask).
+ */
+int mp_set_prior(mp_handle *h, const double *lower, const double *upper, int ndim, uint32_t log_mask);
+
+/*
+ * Batched log-posterior, host buffers.  pars[n][ndim] row-major (ndim 6..9:
+ * B, P, MdiscI, RdiscI, epsilon, delta [, f_beam | dipeff, propeff [, f_beam]],
+ * magnetar/mcmc_eqns.py:22-34).  ds_id[n] selects the dataset per walker (NULL:
+ * dataset 0).  lnprob_out[n] required; status_out[n] and ltot_out[n][n_grid]
+ * (model light curve in 1e50 erg/s on the grid) optional (NULL).
+ */
+int mp_lnprob_batch(mp_handle *h, const double *pars, const int32_t *ds_id, int n, int ndim,
+                    double *lnprob_out, int32_t *status_out, double *ltot_out);
+
+/*
+ * Same, every pointer a DEVICE pointer on the handle's device; the kernel is
+ * enqueued on `stream` (a hipStream_t passed as void*, NULL = the handle's own
+ * stream) and the call returns without synchronising.
+ */
+int mp_lnprob_batch_dev(mp_handle *h, const double *d_pars, const int32_t *d_ds_id, int n, int ndim,
+                        double *d_lnprob, int32_t *d_status, double *d_ltot, void *stream);
+
+/*
+ * Full model light curve for one parameter vector in PHYSICAL units (no prior,
+ * no un-logging): out[4][n_grid] = tarr, Ltot, Lprop, Ldip (luminosities in
+ * 1e50 erg/s) as returned by model_lc/model_lum with xdata=None
+ * (magnetar/funcs.py:219-220).  traj (optional) receives [2][n_grid] = Mdisc, omega.
+ */
+int mp_model_lc(mp_handle *h, const double *pars, int ndim, double *out, double *traj, int32_t *status);
+
+/* wait for everything enqueued on the handle's own stream */
+int mp_synchronize(mp_handle *h);
+
+/* introspection used by the measurement harness */
+int mp_device(const mp_handle *h);
+int mp_n_grid(const mp_handle *h);
+/* mean Picard sweeps per 64-step tile of the most recent host-buffer batch (diagnostic) */
+double mp_last_mean_sweeps(const mp_handle *h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MAGPROP_AMD_H */

@@ -1,0 +1,221 @@
+"""ctypes binding of include/magprop_amd.h (libmagprop_amd.so: C ABI + gfx950 kernels).
+
+This is the stub a magprop maintainer would add next to ``magnetar/funcs.py`` to call the HIP path
+(see INTEGRATION.md).  There is no CPU fallback here: if the shared library is missing or no HIP
+device is visible, importing/creating raises ``MagpropAmdError`` loudly.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libmagprop_amd.so")
+
+MP_OK, MP_EINVAL, MP_EHIP, MP_ERANGE, MP_ENODEV, MP_ESTATE = 0, -1, -2, -3, -4, -5
+STATUS_OK, STATUS_FLAG, STATUS_NONFINITE, STATUS_PRIOR = 0, 1, 2, 3
+MAX_NDIM = 9
+MAX_DATASETS = 64
+
+EXPORTS = (
+    "mp_abi_version", "mp_last_error", "mp_cfg_synth", "mp_cfg_lib", "mp_create", "mp_destroy",
+    "mp_set_dataset", "mp_set_prior", "mp_lnprob_batch", "mp_lnprob_batch_dev", "mp_model_lc",
+    "mp_synchronize", "mp_device", "mp_n_grid", "mp_last_mean_sweeps",
+)
+
+
+class MagpropAmdError(RuntimeError):
+    pass
+
+
+class ModelCfg(C.Structure):
+    """mp_model_cfg (include/magprop_amd.h)."""
+    _fields_ = [(n, C.c_double) for n in (
+        "inertia_factor", "rm_massflow_factor", "n_ode", "n_lum", "alpha", "cs7", "k",
+        "dipeff", "propeff", "f_beam", "nacc_lum_threshold")] + [
+        ("lprop_gm_term", C.c_int32), ("reserved", C.c_int32)]
+
+
+def build(force=False, verbose=False):
+    """Compile the HIP library in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+    src = os.path.join(_PKG, "csrc")
+    args = ["make", "-C", src, "-s"] + (["-B"] if force else [])
+    subprocess.check_call(args, stdout=None if verbose else subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load libmagprop_amd.so (building it if hipcc is available and it is missing)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        try:
+            build()
+        except Exception as exc:  # noqa: BLE001
+            raise MagpropAmdError(
+                f"{LIB_PATH} is missing and could not be built ({exc}); run `python -c 'import "
+                "__graft_entry__ as g; g.build()'` on a machine with hipcc") from exc
+    try:
+        L = C.CDLL(LIB_PATH)
+    except OSError as exc:
+        raise MagpropAmdError(f"cannot load {LIB_PATH}: {exc}") from exc
+    dp, ip, vp = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_void_p
+    L.mp_abi_version.restype = C.c_int
+    L.mp_last_error.restype = C.c_char_p
+    L.mp_cfg_synth.argtypes = [C.POINTER(ModelCfg)]
+    L.mp_cfg_synth.restype = None
+    L.mp_cfg_lib.argtypes = [C.POINTER(ModelCfg)]
+    L.mp_cfg_lib.restype = None
+    L.mp_create.restype = vp
+    L.mp_create.argtypes = [C.POINTER(ModelCfg), dp, C.c_int, C.c_int]
+    L.mp_destroy.argtypes = [vp]
+    L.mp_set_dataset.argtypes = [vp, C.c_int, dp, dp, dp, C.c_int]
+    L.mp_set_prior.argtypes = [vp, dp, dp, C.c_int, C.c_uint32]
+    L.mp_lnprob_batch.argtypes = [vp, dp, ip, C.c_int, C.c_int, dp, ip, dp]
+    L.mp_lnprob_batch_dev.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]
+    L.mp_model_lc.argtypes = [vp, dp, C.c_int, dp, dp, ip]
+    L.mp_synchronize.argtypes = [vp]
+    L.mp_device.argtypes = [vp]
+    L.mp_n_grid.argtypes = [vp]
+    L.mp_last_mean_sweeps.argtypes = [vp]
+    L.mp_last_mean_sweeps.restype = C.c_double
+    for name in ("mp_destroy", "mp_set_dataset", "mp_set_prior", "mp_lnprob_batch", "mp_lnprob_batch_dev",
+                 "mp_model_lc", "mp_synchronize", "mp_device", "mp_n_grid"):
+        getattr(L, name).restype = C.c_int
+    _lib = L
+    return L
+
+
+def last_error():
+    return lib().mp_last_error().decode("utf-8", "replace")
+
+
+def check(rc, what):
+    if rc == MP_OK:
+        return
+    msg = last_error()
+    if rc == MP_ERANGE:
+        raise ValueError(msg)  # scipy's interp1d raises ValueError there (magnetar/funcs.py:214-215)
+    if rc == MP_EINVAL:
+        raise ValueError(f"{what}: {msg}")
+    raise MagpropAmdError(f"{what} failed (rc={rc}): {msg}")
+
+
+def cfg_synth(**kw):
+    c = ModelCfg()
+    lib().mp_cfg_synth(C.byref(c))
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
+
+
+def cfg_lib(**kw):
+    c = ModelCfg()
+    lib().mp_cfg_lib(C.byref(c))
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
+
+
+def _dptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _iptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+class Handle:
+    """Owns one mp_handle: a model configuration + time grid bound to one GPU."""
+
+    def __init__(self, cfg, tgrid, device=-1):
+        self._L = lib()
+        self.tgrid = np.ascontiguousarray(tgrid, dtype=np.float64)
+        self.cfg = cfg
+        self._h = self._L.mp_create(C.byref(cfg), _dptr(self.tgrid), int(self.tgrid.size), int(device))
+        if not self._h:
+            raise MagpropAmdError("mp_create failed: " + last_error())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.mp_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    @property
+    def device(self):
+        return self._L.mp_device(self._h)
+
+    def set_dataset(self, ds_id, x, y, yerr):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        yerr = np.ascontiguousarray(yerr, dtype=np.float64)
+        if not (x.ndim == y.ndim == yerr.ndim == 1 and x.size == y.size == yerr.size):
+            raise ValueError("x, y, yerr must be 1-D arrays of equal length")
+        check(self._L.mp_set_dataset(self._h, int(ds_id), _dptr(x), _dptr(y), _dptr(yerr), int(x.size)),
+              "mp_set_dataset")
+
+    def set_prior(self, lower, upper, log_mask=0):
+        if lower is None:
+            check(self._L.mp_set_prior(self._h, None, None, 0, C.c_uint32(log_mask)), "mp_set_prior")
+            return
+        lo = np.ascontiguousarray(lower, dtype=np.float64)
+        hi = np.ascontiguousarray(upper, dtype=np.float64)
+        if lo.shape != hi.shape or lo.ndim != 1:
+            raise ValueError("lower/upper must be 1-D arrays of equal length")
+        check(self._L.mp_set_prior(self._h, _dptr(lo), _dptr(hi), int(lo.size), C.c_uint32(log_mask)),
+              "mp_set_prior")
+
+    def lnprob_batch(self, pars, ds_id=None, want_status=False, want_ltot=False):
+        p = np.ascontiguousarray(pars, dtype=np.float64)
+        if p.ndim != 2:
+            raise ValueError("pars must be 2-D (n_walkers, ndim)")
+        n, nd = p.shape
+        out = np.empty(n, dtype=np.float64)
+        st = np.empty(n, dtype=np.int32)
+        lt = np.empty((n, self.tgrid.size), dtype=np.float64) if want_ltot else None
+        ids = None
+        if ds_id is not None:
+            ids = np.ascontiguousarray(np.broadcast_to(np.asarray(ds_id, dtype=np.int32), (n,)))
+        check(self._L.mp_lnprob_batch(self._h, _dptr(p), _iptr(ids) if ids is not None else None, n, nd,
+                                      _dptr(out), _iptr(st), _dptr(lt) if lt is not None else None),
+              "mp_lnprob_batch")
+        res = (out,)
+        if want_status:
+            res += (st,)
+        if want_ltot:
+            res += (lt,)
+        return res if len(res) > 1 else out
+
+    def lnprob_batch_dev(self, d_pars, n, ndim, d_lnprob, d_ds_id=0, d_status=0, d_ltot=0, stream=0):
+        """Device-pointer entry (ints from e.g. torch.Tensor.data_ptr()); asynchronous on `stream`."""
+        check(self._L.mp_lnprob_batch_dev(self._h, C.c_void_p(d_pars), C.c_void_p(d_ds_id or None), int(n),
+                                          int(ndim), C.c_void_p(d_lnprob), C.c_void_p(d_status or None),
+                                          C.c_void_p(d_ltot or None), C.c_void_p(stream or None)),
+              "mp_lnprob_batch_dev")
+
+    def model_lc(self, pars, want_traj=False):
+        p = np.ascontiguousarray(pars, dtype=np.float64).ravel()
+        out = np.empty((4, self.tgrid.size), dtype=np.float64)
+        traj = np.empty((2, self.tgrid.size), dtype=np.float64)
+        st = C.c_int32(0)
+        check(self._L.mp_model_lc(self._h, _dptr(p), int(p.size), _dptr(out), _dptr(traj), C.byref(st)),
+              "mp_model_lc")
+        return (st.value, out, traj) if want_traj else (st.value, out)
+
+    def synchronize(self):
+        check(self._L.mp_synchronize(self._h), "mp_synchronize")
+
+    @property
+    def last_mean_sweeps(self):
+        return self._L.mp_last_mean_sweeps(self._h)

@@ -1,0 +1,419 @@
+// mp_capi.cpp — host side of the C ABI declared in include/magprop_amd.h.
+//
+// Plain HIP runtime only (no torch, no hipBLAS): device buffers, one stream per handle, the
+// host-side digestion of observed light curves into the tile-bucketed layout the kernel reads,
+// and thin launch wrappers.  There is NO CPU fallback: without a HIP device mp_create() fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "mp_device.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail(MP_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+struct DeviceScope {  // make the handle's device current for the duration of a call
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceScope(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceScope() {
+        int cur = -1;
+        if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+    }
+};
+
+struct HostDataset {
+    bool set = false;
+    std::vector<int32_t> g, tile_ptr;
+    std::vector<double> dx, idt, y, yerr;
+};
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t n) {
+        if (n <= cap) return MP_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = std::max<size_t>(n, 16);
+        HIP_TRY(hipMalloc((void **)&p, want * sizeof(T)));
+        cap = want;
+        return MP_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+}  // namespace
+
+struct mp_handle {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::vector<double> tgrid;
+    int n_tiles = 0;
+    HostDataset ds[MP_MAX_DATASETS];
+    mp::DevShared sh{};
+    // device copies of the shared data
+    DevBuf<double> d_tgrid, d_obs_dx, d_obs_idt, d_obs_y, d_obs_yerr;
+    DevBuf<int32_t> d_obs_g, d_tile_ptr;
+    DevBuf<mp::DsDesc> d_ds;
+    // workspace of the host-buffer entry points
+    DevBuf<double> w_pars, w_lnprob, w_curves;
+    DevBuf<int32_t> w_dsid, w_status, w_sweeps;
+    double last_mean_sweeps = 0.0;
+};
+
+static int upload_datasets(mp_handle *h) {
+    std::vector<mp::DsDesc> desc(MP_MAX_DATASETS, mp::DsDesc{0, 0, 0, 0});
+    std::vector<int32_t> g, tp;
+    std::vector<double> dx, idt, y, ye;
+    int n_ds = 0;
+    for (int d = 0; d < MP_MAX_DATASETS; ++d) {
+        const HostDataset &s = h->ds[d];
+        if (!s.set) continue;
+        n_ds = d + 1;
+        desc[d].n_obs = (int32_t)s.g.size();
+        desc[d].obs_off = (int32_t)g.size();
+        desc[d].tile_off = (int32_t)tp.size();
+        g.insert(g.end(), s.g.begin(), s.g.end());
+        dx.insert(dx.end(), s.dx.begin(), s.dx.end());
+        idt.insert(idt.end(), s.idt.begin(), s.idt.end());
+        y.insert(y.end(), s.y.begin(), s.y.end());
+        ye.insert(ye.end(), s.yerr.begin(), s.yerr.end());
+        tp.insert(tp.end(), s.tile_ptr.begin(), s.tile_ptr.end());
+    }
+    // unset slots below n_ds point at an empty bucket table so a stray ds_id reads zeros, not garbage
+    const int32_t empty_off = (int32_t)tp.size();
+    tp.insert(tp.end(), (size_t)h->n_tiles + 1, 0);
+    for (int d = 0; d < n_ds; ++d)
+        if (!h->ds[d].set) desc[d].tile_off = empty_off;
+    HIP_TRY(hipDeviceSynchronize());  // nothing in flight may still read the old buffers
+    int rc;
+    if ((rc = h->d_obs_g.ensure(g.size())) || (rc = h->d_obs_dx.ensure(dx.size())) ||
+        (rc = h->d_obs_idt.ensure(idt.size())) || (rc = h->d_obs_y.ensure(y.size())) ||
+        (rc = h->d_obs_yerr.ensure(ye.size())) || (rc = h->d_tile_ptr.ensure(tp.size())) ||
+        (rc = h->d_ds.ensure(desc.size())))
+        return rc;
+    if (!g.empty()) {
+        HIP_TRY(hipMemcpy(h->d_obs_g.p, g.data(), g.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(h->d_obs_dx.p, dx.data(), dx.size() * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(h->d_obs_idt.p, idt.data(), idt.size() * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(h->d_obs_y.p, y.data(), y.size() * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(h->d_obs_yerr.p, ye.data(), ye.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    HIP_TRY(hipMemcpy(h->d_tile_ptr.p, tp.data(), tp.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->d_ds.p, desc.data(), desc.size() * sizeof(mp::DsDesc), hipMemcpyHostToDevice));
+    h->sh.ds = h->d_ds.p;
+    h->sh.n_ds = n_ds;
+    h->sh.tile_ptr = h->d_tile_ptr.p;
+    h->sh.obs_g = h->d_obs_g.p;
+    h->sh.obs_dx = h->d_obs_dx.p;
+    h->sh.obs_idt = h->d_obs_idt.p;
+    h->sh.obs_y = h->d_obs_y.p;
+    h->sh.obs_yerr = h->d_obs_yerr.p;
+    return MP_OK;
+}
+
+extern "C" {
+
+int mp_abi_version(void) { return MP_ABI_VERSION; }
+
+const char *mp_last_error(void) { return g_err.c_str(); }
+
+void mp_cfg_synth(mp_model_cfg *c) {
+    if (!c) return;
+    *c = mp_model_cfg{0.35, 3.0, 10.0, 10.0, 0.1, 1.0, 0.9, 1.0, 1.0, 1.0, 0.27, 1, 0};
+}
+
+void mp_cfg_lib(mp_model_cfg *c) {
+    if (!c) return;
+    *c = mp_model_cfg{0.8, 1.0, 1.0, 1.0, 0.1, 1.0, 0.9, 0.05, 0.4, 1.0, 0.0, 0, 0};
+}
+
+mp_handle *mp_create(const mp_model_cfg *cfg, const double *tgrid, int n_grid, int device) {
+    if (!cfg || !tgrid || n_grid < 2) {
+        fail(MP_EINVAL, "mp_create: cfg/tgrid NULL or n_grid < 2");
+        return nullptr;
+    }
+    for (int i = 1; i < n_grid; ++i)
+        if (!(tgrid[i] > tgrid[i - 1]) || !std::isfinite(tgrid[i])) {
+            fail(MP_EINVAL, "mp_create: tgrid must be finite and strictly increasing (index %d)", i);
+            return nullptr;
+        }
+    if (!(cfg->inertia_factor > 0) || !(cfg->alpha > 0) || !(cfg->cs7 > 0) || !(cfg->k > 0) ||
+        !(cfg->rm_massflow_factor > 0)) {
+        fail(MP_EINVAL, "mp_create: non-positive model constant in cfg");
+        return nullptr;
+    }
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        fail(MP_ENODEV, "mp_create: no HIP device visible (this library has no CPU fallback)");
+        return nullptr;
+    }
+    if (device < 0 && hipGetDevice(&device) != hipSuccess) device = 0;
+    if (device >= count) {
+        fail(MP_ENODEV, "mp_create: device %d out of range (%d visible)", device, count);
+        return nullptr;
+    }
+    mp_handle *h = new mp_handle();
+    h->device = device;
+    DeviceScope scope(device);
+    if (!scope.ok || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+        fail(MP_EHIP, "mp_create: cannot select device %d / create stream", device);
+        delete h;
+        return nullptr;
+    }
+    h->tgrid.assign(tgrid, tgrid + n_grid);
+    h->n_tiles = (n_grid - 1 + mp::kTile - 1) / mp::kTile;
+    if (h->d_tgrid.ensure((size_t)n_grid) != MP_OK ||
+        hipMemcpy(h->d_tgrid.p, tgrid, sizeof(double) * (size_t)n_grid, hipMemcpyHostToDevice) != hipSuccess) {
+        fail(MP_EHIP, "mp_create: cannot upload the time grid");
+        mp_destroy(h);
+        return nullptr;
+    }
+    mp::DevShared &s = h->sh;
+    s.tgrid = h->d_tgrid.p;
+    s.n_grid = n_grid;
+    s.n_tiles = h->n_tiles;
+    s.cfg = *cfg;
+    s.n_prior = 0;
+    s.log_mask = 0;
+    // star constants, magnetar/funcs.py:7-13,75-76
+    const double M = 1.4 * mp::kMsol;
+    s.GM = mp::kG * M;
+    s.inertia = cfg->inertia_factor * M * mp::kR * mp::kR;
+    s.inv_inertia = 1.0 / s.inertia;
+    const double beta = s.GM / (mp::kR * mp::kC * mp::kC);
+    const double modW = 0.6 * M * mp::kC * mp::kC * (beta / (1.0 - 0.5 * beta));
+    s.crot = 0.5 * s.inertia / modW;
+    s.sqrtGM = std::sqrt(s.GM);
+    s.inv_sqrtGM = 1.0 / s.sqrtGM;
+    s.sqrtR = std::sqrt(mp::kR);
+    if (upload_datasets(h) != MP_OK) {
+        mp_destroy(h);
+        return nullptr;
+    }
+    return h;
+}
+
+int mp_destroy(mp_handle *h) {
+    if (!h) return MP_OK;
+    DeviceScope scope(h->device);
+    (void)hipDeviceSynchronize();
+    h->d_tgrid.release(); h->d_obs_dx.release(); h->d_obs_idt.release(); h->d_obs_y.release();
+    h->d_obs_yerr.release(); h->d_obs_g.release(); h->d_tile_ptr.release(); h->d_ds.release();
+    h->w_pars.release(); h->w_lnprob.release(); h->w_curves.release();
+    h->w_dsid.release(); h->w_status.release(); h->w_sweeps.release();
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return MP_OK;
+}
+
+int mp_set_dataset(mp_handle *h, int ds_id, const double *x, const double *y, const double *yerr, int n_obs) {
+    if (!h || !x || !y || !yerr) return fail(MP_EINVAL, "mp_set_dataset: NULL argument");
+    if (ds_id < 0 || ds_id >= MP_MAX_DATASETS) return fail(MP_EINVAL, "mp_set_dataset: ds_id %d out of range", ds_id);
+    if (n_obs <= 0) return fail(MP_EINVAL, "mp_set_dataset: n_obs must be positive");
+    const std::vector<double> &t = h->tgrid;
+    const int n = (int)t.size();
+    for (int j = 0; j < n_obs; ++j) {
+        if (!(x[j] >= t.front()) || !(x[j] <= t.back()))  // interp1d(bounds_error=True), magnetar/funcs.py:214-215
+            return fail(MP_ERANGE, "A value in x_new is %s the interpolation range.",
+                        (x[j] < t.front()) ? "below" : "above");
+    }
+    std::vector<int> order(n_obs);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return x[a] < x[b]; });
+    HostDataset d;
+    d.set = true;
+    d.tile_ptr.assign((size_t)h->n_tiles + 1, 0);
+    for (int k = 0; k < n_obs; ++k) {
+        const int j = order[k];
+        int g = (int)(std::upper_bound(t.begin(), t.end(), x[j]) - t.begin()) - 1;  // t[g] <= x < t[g+1]
+        g = std::min(std::max(g, 0), n - 2);
+        d.g.push_back(g);
+        d.dx.push_back(x[j] - t[g]);
+        d.idt.push_back(1.0 / (t[g + 1] - t[g]));
+        d.y.push_back(y[j]);
+        d.yerr.push_back(yerr[j]);
+        d.tile_ptr[(size_t)(g / mp::kTile) + 1] += 1;
+    }
+    for (size_t k = 1; k < d.tile_ptr.size(); ++k) d.tile_ptr[k] += d.tile_ptr[k - 1];
+    h->ds[ds_id] = std::move(d);
+    DeviceScope scope(h->device);
+    return upload_datasets(h);
+}
+
+int mp_set_prior(mp_handle *h, const double *lower, const double *upper, int ndim, uint32_t log_mask) {
+    if (!h) return fail(MP_EINVAL, "mp_set_prior: NULL handle");
+    if (ndim < 0 || ndim > MP_MAX_NDIM) return fail(MP_EINVAL, "mp_set_prior: ndim %d out of range", ndim);
+    if (ndim > 0 && (!lower || !upper)) return fail(MP_EINVAL, "mp_set_prior: NULL bounds");
+    for (int i = 0; i < MP_MAX_NDIM; ++i) {
+        h->sh.lower[i] = i < ndim ? lower[i] : -INFINITY;
+        h->sh.upper[i] = i < ndim ? upper[i] : INFINITY;
+    }
+    h->sh.n_prior = ndim;
+    h->sh.log_mask = log_mask;
+    return MP_OK;
+}
+
+static int check_batch_args(const mp_handle *h, const void *pars, int n, int ndim, const void *lnprob) {
+    if (!h || !pars || !lnprob) return fail(MP_EINVAL, "lnprob batch: NULL argument");
+    if (n < 0) return fail(MP_EINVAL, "lnprob batch: negative n");
+    if (ndim < 6 || ndim > MP_MAX_NDIM) return fail(MP_EINVAL, "lnprob batch: ndim must be 6..9, got %d", ndim);
+    if (h->sh.n_ds <= 0) return fail(MP_ESTATE, "lnprob batch: no dataset registered (mp_set_dataset)");
+    return MP_OK;
+}
+
+int mp_lnprob_batch_dev(mp_handle *h, const double *d_pars, const int32_t *d_ds_id, int n, int ndim,
+                        double *d_lnprob, int32_t *d_status, double *d_ltot, void *stream) {
+    int rc = check_batch_args(h, d_pars, n, ndim, d_lnprob);
+    if (rc) return rc;
+    if (!d_ds_id && !h->ds[0].set) return fail(MP_ESTATE, "lnprob batch: ds_id is NULL but dataset 0 is not set");
+    DeviceScope scope(h->device);
+    mp::LaunchArgs a{};
+    a.pars = d_pars;
+    a.ds_id = d_ds_id;
+    a.n = n;
+    a.ndim = ndim;
+    a.physical = 0;
+    a.want_chi2 = 1;
+    a.lnprob = d_lnprob;
+    a.status = d_status;
+    a.ltot = d_ltot;
+    const int e = mp::launch_lnprob(h->sh, a, stream ? stream : (void *)h->stream);
+    if (e) return fail(MP_EHIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+    return MP_OK;
+}
+
+int mp_lnprob_batch(mp_handle *h, const double *pars, const int32_t *ds_id, int n, int ndim, double *lnprob_out,
+                    int32_t *status_out, double *ltot_out) {
+    int rc = check_batch_args(h, pars, n, ndim, lnprob_out);
+    if (rc) return rc;
+    if (n == 0) return MP_OK;
+    if (ds_id) {
+        for (int i = 0; i < n; ++i)
+            if (ds_id[i] < 0 || ds_id[i] >= MP_MAX_DATASETS || !h->ds[ds_id[i]].set)
+                return fail(MP_EINVAL, "lnprob batch: walker %d refers to unset dataset %d", i, ds_id[i]);
+    } else if (!h->ds[0].set) {
+        return fail(MP_ESTATE, "lnprob batch: ds_id is NULL but dataset 0 is not set");
+    }
+    DeviceScope scope(h->device);
+    const size_t ng = h->tgrid.size();
+    if ((rc = h->w_pars.ensure((size_t)n * ndim)) || (rc = h->w_lnprob.ensure(n)) || (rc = h->w_status.ensure(n)) ||
+        (rc = h->w_sweeps.ensure(n)) || (ds_id && (rc = h->w_dsid.ensure(n))) ||
+        (ltot_out && (rc = h->w_curves.ensure((size_t)n * ng))))
+        return rc;
+    hipStream_t st = h->stream;
+    HIP_TRY(hipMemcpyAsync(h->w_pars.p, pars, sizeof(double) * (size_t)n * ndim, hipMemcpyHostToDevice, st));
+    if (ds_id) HIP_TRY(hipMemcpyAsync(h->w_dsid.p, ds_id, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, st));
+    if (ltot_out) HIP_TRY(hipMemsetAsync(h->w_curves.p, 0xFF, sizeof(double) * (size_t)n * ng, st));  // NaN fill
+    mp::LaunchArgs a{};
+    a.pars = h->w_pars.p;
+    a.ds_id = ds_id ? h->w_dsid.p : nullptr;
+    a.n = n;
+    a.ndim = ndim;
+    a.physical = 0;
+    a.want_chi2 = 1;
+    a.lnprob = h->w_lnprob.p;
+    a.status = h->w_status.p;
+    a.sweeps = h->w_sweeps.p;
+    a.ltot = ltot_out ? h->w_curves.p : nullptr;
+    const int e = mp::launch_lnprob(h->sh, a, st);
+    if (e) return fail(MP_EHIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+    std::vector<int32_t> sweeps(n), status(n);
+    HIP_TRY(hipMemcpyAsync(lnprob_out, h->w_lnprob.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(status.data(), h->w_status.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(sweeps.data(), h->w_sweeps.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, st));
+    if (ltot_out)
+        HIP_TRY(hipMemcpyAsync(ltot_out, h->w_curves.p, sizeof(double) * (size_t)n * ng, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (status_out) std::memcpy(status_out, status.data(), sizeof(int32_t) * (size_t)n);
+    double tot = 0.0;
+    int cnt = 0;
+    for (int i = 0; i < n; ++i)
+        if (status[i] == MP_STATUS_OK) { tot += sweeps[i]; ++cnt; }
+    h->last_mean_sweeps = cnt ? tot / ((double)cnt * h->n_tiles) : 0.0;
+    return MP_OK;
+}
+
+int mp_model_lc(mp_handle *h, const double *pars, int ndim, double *out, double *traj, int32_t *status) {
+    if (!h || !pars || !out) return fail(MP_EINVAL, "mp_model_lc: NULL argument");
+    if (ndim < 6 || ndim > MP_MAX_NDIM) return fail(MP_EINVAL, "mp_model_lc: ndim must be 6..9, got %d", ndim);
+    DeviceScope scope(h->device);
+    const size_t ng = h->tgrid.size();
+    int rc;
+    if ((rc = h->w_pars.ensure(MP_MAX_NDIM)) || (rc = h->w_lnprob.ensure(1)) || (rc = h->w_status.ensure(1)) ||
+        (rc = h->w_curves.ensure(5 * ng)))
+        return rc;
+    hipStream_t st = h->stream;
+    HIP_TRY(hipMemcpyAsync(h->w_pars.p, pars, sizeof(double) * (size_t)ndim, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(h->w_curves.p, 0xFF, sizeof(double) * 5 * ng, st));
+    mp::LaunchArgs a{};
+    a.pars = h->w_pars.p;
+    a.n = 1;
+    a.ndim = ndim;
+    a.physical = 1;
+    a.want_chi2 = 0;
+    a.lnprob = h->w_lnprob.p;
+    a.status = h->w_status.p;
+    a.ltot = h->w_curves.p;
+    a.lprop = h->w_curves.p + ng;
+    a.ldip = h->w_curves.p + 2 * ng;
+    a.mdisc = h->w_curves.p + 3 * ng;
+    a.omega = h->w_curves.p + 4 * ng;
+    const int e = mp::launch_lnprob(h->sh, a, st);
+    if (e) return fail(MP_EHIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+    int32_t stt = 0;
+    std::memcpy(out, h->tgrid.data(), sizeof(double) * ng);
+    HIP_TRY(hipMemcpyAsync(out + ng, h->w_curves.p, sizeof(double) * 3 * ng, hipMemcpyDeviceToHost, st));
+    if (traj) HIP_TRY(hipMemcpyAsync(traj, h->w_curves.p + 3 * ng, sizeof(double) * 2 * ng, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&stt, h->w_status.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (status) *status = stt;
+    return MP_OK;
+}
+
+int mp_synchronize(mp_handle *h) {
+    if (!h) return fail(MP_EINVAL, "mp_synchronize: NULL handle");
+    DeviceScope scope(h->device);
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return MP_OK;
+}
+
+int mp_device(const mp_handle *h) { return h ? h->device : -1; }
+int mp_n_grid(const mp_handle *h) { return h ? (int)h->tgrid.size() : 0; }
+double mp_last_mean_sweeps(const mp_handle *h) { return h ? h->last_mean_sweeps : 0.0; }
+
+}  // extern "C"

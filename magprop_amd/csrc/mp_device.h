@@ -1,0 +1,71 @@
+// mp_device.h — structures shared by the host C-ABI (mp_capi.cpp) and the gfx950 kernels (mp_kernels.hip).
+#pragma once
+#include <stdint.h>
+
+#include "../../include/magprop_amd.h"
+
+namespace mp {
+
+constexpr int kTile = 64;  // time steps per tile = lanes per wavefront: one step per lane
+
+// physical constants, magnetar/funcs.py:7-13 (cgs)
+constexpr double kG = 6.674e-8;
+constexpr double kC = 3.0e10;
+constexpr double kR = 1.0e6;
+constexpr double kMsol = 1.99e33;
+
+// One observed light curve, pre-digested on the host for the grid it will be interpolated on.
+// Observations are sorted by time and bucketed by the 64-step tile whose light-curve values they need.
+struct DsDesc {
+    int32_t n_obs;
+    int32_t obs_off;   // first observation in the packed obs_* arrays
+    int32_t tile_off;  // first entry of this dataset's tile_ptr[n_tiles + 1]
+    int32_t pad;
+};
+
+// Everything the kernel reads that is shared by all walkers (resident in HBM, L2-hot).
+struct DevShared {
+    const double *tgrid;  // [n_grid]
+    int32_t n_grid;
+    int32_t n_tiles;      // ceil((n_grid - 1) / 64)
+    const DsDesc *ds;     // [n_ds]
+    int32_t n_ds;
+    int32_t pad0;
+    const int32_t *tile_ptr;  // per dataset: [n_tiles + 1] prefix offsets into the obs arrays (relative to obs_off)
+    const int32_t *obs_g;     // grid interval index g: tgrid[g] <= x <= tgrid[g + 1]
+    const double *obs_dx;     // x - tgrid[g]
+    const double *obs_idt;    // 1 / (tgrid[g + 1] - tgrid[g])
+    const double *obs_y;
+    const double *obs_yerr;
+    // prior
+    double lower[MP_MAX_NDIM];
+    double upper[MP_MAX_NDIM];
+    int32_t n_prior;
+    uint32_t log_mask;
+    // derived star constants (host-computed once from cfg)
+    double GM, inertia, inv_inertia, crot /* 0.5*I/|W| */, sqrtGM, inv_sqrtGM, sqrtR;
+    mp_model_cfg cfg;
+};
+
+// Per-launch arguments.
+struct LaunchArgs {
+    const double *pars;     // [n][ndim], device
+    const int32_t *ds_id;   // [n] or nullptr
+    int32_t n;
+    int32_t ndim;
+    int32_t physical;       // 1: pars are physical, skip prior + un-logging (model_lc)
+    int32_t want_chi2;      // 0: skip observations (model_lc only)
+    double *lnprob;         // [n]
+    int32_t *status;        // [n] or nullptr
+    int32_t *sweeps;        // [n] or nullptr: total Newton sweeps over all tiles
+    double *ltot;           // [n][n_grid] or nullptr   (1e50 erg/s)
+    double *lprop;          // [n][n_grid] or nullptr
+    double *ldip;           // [n][n_grid] or nullptr
+    double *mdisc;          // [n][n_grid] or nullptr
+    double *omega;          // [n][n_grid] or nullptr
+};
+
+// implemented in mp_kernels.hip; returns hipError_t as int
+int launch_lnprob(const DevShared &sh, const LaunchArgs &a, void *stream);
+
+}  // namespace mp

@@ -1,0 +1,430 @@
+// mp_kernels.hip — gfx950 (CDNA4) kernels of the magnetar log-posterior hot path.
+//
+// Layout: ONE WALKER PER WAVEFRONT, ONE TIME STEP PER LANE.  The 10 000 grid intervals are
+// processed in tiles of 64 consecutive steps; inside a tile the 64 lanes advance all 64 steps
+// at once (parallel in time):
+//
+//   1. Mdisc obeys dM/dt = Mdotfb(t) - M/tvisc (linear, omega-independent; reference RHS
+//      code/synthetic_datasets/funcs.py:122-129, magnetar/funcs.py:86-92).  Every lane builds the
+//      affine map M_{i+1} = a_i M_i + b_i of its own step (exponential integrator, quadratic
+//      source interpolant) and a wavefront scan of affine maps yields Mdisc at all 64 step ends.
+//   2. omega obeys a scalar nonlinear ODE fed by Mdisc(t).  Every lane applies one step of the
+//      exponential RK4 scheme (Krogstad ETD4RK around the frozen Jacobian lambda_i) to its current
+//      guess of omega at its step start; the step maps are linearised (slope exp(h lambda_i)) and a
+//      second affine scan propagates the tile's start value through all 64 steps.  This Newton-type
+//      sweep converges quadratically (2-4 sweeps); after k sweeps the first k steps are exact, so it
+//      always terminates and reproduces the serial recurrence to rounding.
+//   3. Each lane evaluates the luminosity at its step end (reference luminosity stage,
+//      code/synthetic_datasets/funcs.py:175-229, magnetar/funcs.py:157-210), the tile's light curve
+//      is staged in LDS, the observations that fall in the tile are interpolated from LDS
+//      (np.interp semantics) and accumulated into per-lane chi^2 partial sums; optional coalesced
+//      512-B-per-wave stores write the model light curve to HBM.
+//   4. A wavefront reduction gives -0.5*chi^2 (code/synthetic_datasets/mcmc_eqns.py:25).
+//
+// No MFMA (no dense contraction anywhere on this path), fp64 throughout.  The arithmetic is
+// algebraically simplified with respect to the reference formulas (e.g. fastness
+// w = (Rm/Rc)^1.5 = omega*Rm^1.5/sqrt(GM), eta1-eta2 = -tanh); oracle/mp_oracle.c keeps the literal
+// formulas and the tests compare the two.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+
+#include "mp_device.h"
+
+namespace mp {
+
+#define MP_DEV __device__ __forceinline__
+
+// ---------------------------------------------------------------- wavefront helpers
+MP_DEV double lane_bcast(double v, int src) { return __shfl(v, src, 64); }
+
+// Inclusive scan of affine maps x -> a*x + b over the 64 lanes: afterwards lane l holds
+// m_l o m_{l-1} o ... o m_0.
+MP_DEV void scan_affine(double &a, double &b, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const double pa = __shfl_up(a, d, 64);
+        const double pb = __shfl_up(b, d, 64);
+        if (lane >= d) {
+            b = fma(a, pb, b);
+            a = a * pa;
+        }
+    }
+}
+
+MP_DEV double wave_sum(double v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------- phi functions
+// phi_j(z) = sum_k z^k/(k+j)!  : phi_1 = (e^z-1)/z, phi_2 = (phi_1-1)/z, phi_3 = (phi_2-1/2)/z
+struct Phi {
+    double e, p1, p2, p3;
+};
+
+MP_DEV Phi phi123(double z) {
+    // Taylor series of phi_3 for |z| < 1/2 (14 terms: < 4e-17 relative), closed forms elsewhere
+    double s = 1.0 / 20922789888000.0;            // 1/16!
+    s = fma(s, z, 1.0 / 1307674368000.0);         // 1/15!
+    s = fma(s, z, 1.0 / 87178291200.0);           // 1/14!
+    s = fma(s, z, 1.0 / 6227020800.0);            // 1/13!
+    s = fma(s, z, 1.0 / 479001600.0);             // 1/12!
+    s = fma(s, z, 1.0 / 39916800.0);              // 1/11!
+    s = fma(s, z, 1.0 / 3628800.0);               // 1/10!
+    s = fma(s, z, 1.0 / 362880.0);                // 1/9!
+    s = fma(s, z, 1.0 / 40320.0);                 // 1/8!
+    s = fma(s, z, 1.0 / 5040.0);                  // 1/7!
+    s = fma(s, z, 1.0 / 720.0);                   // 1/6!
+    s = fma(s, z, 1.0 / 120.0);                   // 1/5!
+    s = fma(s, z, 1.0 / 24.0);                    // 1/4!
+    s = fma(s, z, 1.0 / 6.0);                     // 1/3!
+    const double t2 = fma(z, s, 0.5);
+    const double t1 = fma(z, t2, 1.0);
+    const double te = fma(z, t1, 1.0);
+    const double ce = exp(z);
+    const double rz = 1.0 / z;
+    const double c1 = (ce - 1.0) * rz;
+    const double c2 = (c1 - 1.0) * rz;
+    const double c3 = (c2 - 0.5) * rz;
+    const bool small = fabs(z) < 0.5;
+    Phi r;
+    r.e = small ? te : ce;
+    r.p1 = small ? t1 : c1;
+    r.p2 = small ? t2 : c2;
+    r.p3 = small ? s : c3;
+    return r;
+}
+
+// phi functions at 2z from those at z
+MP_DEV Phi phi_double(const Phi &h) {
+    Phi r;
+    r.e = h.e * h.e;
+    r.p1 = 0.5 * (h.e + 1.0) * h.p1;
+    r.p2 = 0.25 * fma(h.p1, h.p1, 2.0 * h.p2);
+    r.p3 = 0.125 * (fma(h.p1, h.p2, h.p2) + 2.0 * h.p3);
+    return r;
+}
+
+// ---------------------------------------------------------------- per-walker constants
+struct Walker {
+    double inv_tau;   // 1/tvisc
+    double S_amp;     // M0/tfb
+    double inv_tfb;   // 1/tfb
+    double Crm;       // mu^(4/7) GM^(-1/7) f_Rm^(-2/7)
+    double DI;        // mu^2/(6 c^3 I)          dipole torque / I = -DI*omega^3
+    double D;         // mu^2/(6 c^3)
+    double armI;      // sqrt(GM)/I
+    double kc;        // k*c
+    double dipeff, propeff, f_beam;
+};
+
+// fallback accretion rate Mdotfb(t), code/synthetic_datasets/funcs.py:128
+MP_DEV double mdot_fb(const Walker &w, double t) {
+    const double u = fma(t, w.inv_tfb, 1.0);  // (t + tfb)/tfb
+    const double r = rcbrt(u);
+    const double r2 = r * r;
+    return w.S_amp * (r2 * r2 * r);           // u^(-5/3)
+}
+
+// uncapped Alfven radius from the disc mass-flow rate, code/synthetic_datasets/funcs.py:105-106
+MP_DEV double alfven_radius(const Walker &w, double mdot) { return w.Crm * pow(mdot, -2.0 / 7.0); }
+
+// d(omega)/dt at (mdot = Mdisc/tvisc, rmu = uncapped Alfven radius, om); ODE right-hand side
+// code/synthetic_datasets/funcs.py:105-140 / magnetar/funcs.py:64-99 in simplified algebra.
+template <bool WANT_LAM>
+MP_DEV double omega_rhs(const DevShared &sh, const Walker &w, double mdot, double rmu, double om, double &rot,
+                        double &lam) {
+    const double rlc = w.kc / om;
+    const bool capped = rmu >= rlc;                      // Rm >= k*Rlc -> Rm = k*Rlc
+    const double Rm = capped ? rlc : rmu;
+    const double sq = sqrt(Rm);
+    const double fast = om * Rm * sq * sh.inv_sqrtGM;    // (Rm/Rc)^(3/2)
+    const double x = sh.cfg.n_ode * (fast - 1.0);
+    const double e = exp(-2.0 * fabs(x));
+    const double r = 1.0 / (1.0 + e);
+    const double th = copysign((1.0 - e) * r, x);        // tanh(x) = eta2 - eta1
+    rot = sh.crot * om * om;
+    const bool brk = rot > 0.27;                         // break-up: Nacc = 0
+    const bool big = Rm >= kR;
+    const double arm = w.armI * (big ? sq : sh.sqrtR);   // sqrt(GM*max(Rm,R))/I
+    const double nacc = brk ? 0.0 : -arm * mdot * th;    // Nacc/I, Macc - Mprop = -tanh * mdot
+    const double om2 = om * om;
+    if (WANT_LAM) {
+        const double dfast = (capped ? -0.5 : 1.0) * fast / om;
+        const double sech2 = 4.0 * e * r * r;
+        const double dth = sh.cfg.n_ode * sech2 * dfast;
+        const double darm = (capped && big) ? -0.5 * arm / om : 0.0;
+        const double dn = brk ? 0.0 : -mdot * fma(darm, th, arm * dth);
+        lam = fma(-3.0 * w.DI, om2, dn);
+    }
+    return fma(-w.DI * om2, om, nacc);
+}
+
+// luminosities (erg/s) at one grid point, reference luminosity stage
+MP_DEV void luminosity(const DevShared &sh, const Walker &w, double mdot, double rmu, double om, double &Ltot,
+                       double &Lprop, double &Ldip) {
+    const double rlc = w.kc / om;
+    const bool capped = rmu >= rlc;
+    const double Rm = capped ? rlc : rmu;
+    const double sq = sqrt(Rm);
+    const double fast = om * Rm * sq * sh.inv_sqrtGM;
+    const double x = sh.cfg.n_lum * (fast - 1.0);
+    const double e = exp(-2.0 * fabs(x));
+    const double r = 1.0 / (1.0 + e);
+    const double th = copysign((1.0 - e) * r, x);
+    const double eta2 = x >= 0.0 ? r : e * r;            // 0.5*(1 + tanh x)
+    const double rot = sh.crot * om * om;
+    const double arm = sh.sqrtGM * (Rm >= kR ? sq : sh.sqrtR);
+    const double Nacc = rot > sh.cfg.nacc_lum_threshold ? 0.0 : -arm * mdot * th;
+    const double om2 = om * om;
+    double ld = w.dipeff * (w.D * om2 * om2);
+    if (ld <= 0.0) ld = 0.0;
+    if (!isfinite(ld)) ld = 0.0;
+    double lp = -Nacc * om;
+    if (sh.cfg.lprop_gm_term) lp -= (sh.GM / Rm) * eta2 * mdot;
+    lp *= w.propeff;
+    if (lp <= 0.0) lp = 0.0;
+    if (!isfinite(lp)) lp = 0.0;
+    Ltot = w.f_beam * (ld + lp);
+    Lprop = lp;
+    Ldip = ld;
+}
+
+constexpr int kMaxSweeps = 72;     // > 64: the sweep is exact after at most 64 passes
+constexpr double kSweepTol = 1e-9; // relative change of the step-start values that ends the sweeps
+
+// ---------------------------------------------------------------- the kernel
+template <bool CURVES>
+__global__ __launch_bounds__(64) void lnprob_kernel(const DevShared sh, const LaunchArgs a) {
+    const int walker = blockIdx.x;
+    const int lane = threadIdx.x;
+    __shared__ double Lbuf[kTile + 1];
+
+    const int n_grid = sh.n_grid;
+    const int nsteps = n_grid - 1;
+    const size_t row = (size_t)walker * (size_t)n_grid;
+
+    // ---- parameters, prior, un-logging (code/synthetic_datasets/mcmc_eqns.py:16-17,28-49)
+    double par[MP_MAX_NDIM];
+    const double *pw = a.pars + (size_t)walker * a.ndim;
+#pragma unroll
+    for (int i = 0; i < MP_MAX_NDIM; ++i) par[i] = i < a.ndim ? pw[i] : 0.0;
+
+    int status = MP_STATUS_OK;
+    if (!a.physical) {
+        bool outside = false;
+#pragma unroll
+        for (int i = 0; i < MP_MAX_NDIM; ++i)
+            if (i < sh.n_prior && (!(par[i] >= sh.lower[i]) || !(par[i] <= sh.upper[i]))) outside = true;
+        if (outside) status = MP_STATUS_PRIOR;
+#pragma unroll
+        for (int i = 0; i < MP_MAX_NDIM; ++i)
+            if (i < a.ndim && ((sh.log_mask >> i) & 1u)) par[i] = pow(10.0, par[i]);
+    }
+
+    // ---- walker constants (code/synthetic_datasets/funcs.py:98-102)
+    Walker w;
+    {
+        const double B = par[0], MdiscI = par[2], RdiscI = par[3], epsilon = par[4], delta = par[5];
+        const double tau = (RdiscI * 1.0e5) / (sh.cfg.alpha * sh.cfg.cs7 * 1.0e7);
+        const double mu = 1.0e15 * B * (kR * kR * kR);
+        const double M0 = delta * MdiscI * kMsol;
+        const double tfb = epsilon * tau;
+        w.inv_tau = 1.0 / tau;
+        w.S_amp = M0 / tfb;
+        w.inv_tfb = 1.0 / tfb;
+        w.Crm = pow(mu, 4.0 / 7.0) * pow(sh.GM, -1.0 / 7.0) * pow(sh.cfg.rm_massflow_factor, -2.0 / 7.0);
+        w.D = (mu * mu) / (6.0 * kC * kC * kC);
+        w.DI = w.D * sh.inv_inertia;
+        w.armI = sh.sqrtGM * sh.inv_inertia;
+        w.kc = sh.cfg.k * kC;
+        w.dipeff = sh.cfg.dipeff;
+        w.propeff = sh.cfg.propeff;
+        w.f_beam = sh.cfg.f_beam;
+        // 7/8/9-parameter likelihoods, magnetar/mcmc_eqns.py:22-34
+        if (a.ndim == 7) w.f_beam = par[6];
+        if (a.ndim == 8) { w.dipeff = par[6]; w.propeff = par[7]; }
+        if (a.ndim == 9) { w.dipeff = par[6]; w.propeff = par[7]; w.f_beam = par[8]; }
+    }
+
+    // ---- initial conditions (code/synthetic_datasets/funcs.py:66-69)
+    double M_s = par[2] * kMsol;                         // Mdisc at the tile start
+    double om_s = (2.0 * M_PI) / (1.0e-3 * par[1]);      // omega at the tile start
+    double S_s = mdot_fb(w, sh.tgrid[0]);                // Mdotfb at the tile start
+    double md_s = M_s * w.inv_tau;
+    double rm_s = alfven_radius(w, md_s);
+    double L_s, Lp_s, Ld_s;
+    luminosity(sh, w, md_s, rm_s, om_s, L_s, Lp_s, Ld_s);
+
+    const int dsid = a.ds_id ? a.ds_id[walker] : 0;
+    const DsDesc dsd = sh.ds ? sh.ds[(dsid >= 0 && dsid < sh.n_ds) ? dsid : 0] : DsDesc{0, 0, 0, 0};
+    const int32_t *tptr = sh.tile_ptr + dsd.tile_off;
+    double chi = 0.0;
+    int sweeps_total = 0;
+
+    if (status == MP_STATUS_OK) {
+        if (CURVES && lane == 0) {
+            if (a.ltot) a.ltot[row] = L_s / 1.0e50;
+            if (a.lprop) a.lprop[row] = Lp_s / 1.0e50;
+            if (a.ldip) a.ldip[row] = Ld_s / 1.0e50;
+            if (a.mdisc) a.mdisc[row] = M_s;
+            if (a.omega) a.omega[row] = om_s;
+        }
+        for (int tile = 0; tile < sh.n_tiles; ++tile) {
+            const int i = tile * kTile + lane;           // this lane's step: tgrid[i] -> tgrid[i+1]
+            const bool active = i < nsteps;
+            const int ic = active ? i : nsteps - 1;
+            const double ta = sh.tgrid[ic], tb = sh.tgrid[ic + 1];
+            const double h = tb - ta;
+            const double tm = fma(0.5, h, ta);
+
+            // ---------------- Mdisc: exponential step + affine scan
+            const double S1 = mdot_fb(w, tm), S2 = mdot_fb(w, tb);
+            double S0 = __shfl_up(S2, 1, 64);
+            if (lane == 0) S0 = S_s;
+            const double c1 = -3.0 * S0 + 4.0 * S1 - S2, c2 = 2.0 * S0 - 4.0 * S1 + 2.0 * S2;
+            const Phi qh = phi123(-0.5 * h * w.inv_tau);
+            const Phi qf = phi_double(qh);
+            double aM = active ? qf.e : 1.0;
+            double bM = active ? h * fma(S0, qf.p1, fma(c1, qf.p2, 2.0 * c2 * qf.p3)) : 0.0;
+            const double a_half = qh.e;
+            const double b_half = 0.5 * h * fma(S0, qh.p1, fma(0.5 * c1, qh.p2, 0.5 * c2 * qh.p3));
+            scan_affine(aM, bM, lane);
+            const double M1 = fma(aM, M_s, bM);          // Mdisc at this lane's step end
+            double M0 = __shfl_up(M1, 1, 64);
+            if (lane == 0) M0 = M_s;
+            const double Mh = fma(a_half, M0, b_half);   // Mdisc at the step midpoint
+            const double md1 = M1 * w.inv_tau, mdh = Mh * w.inv_tau;
+            const double rm1 = alfven_radius(w, md1), rmh = alfven_radius(w, mdh);
+            double md0 = __shfl_up(md1, 1, 64), rm0 = __shfl_up(rm1, 1, 64);
+            if (lane == 0) { md0 = md_s; rm0 = rm_s; }
+
+            // ---------------- omega: predictor (exponential Euler from the tile start) ...
+            double wg;
+            {
+                double rot0, lam0;
+                const double f0 = omega_rhs<true>(sh, w, md_s, rm_s, om_s, rot0, lam0);
+                const double dt = ta - lane_bcast(ta, 0);
+                const Phi pp = phi123(dt * lam0);
+                wg = fma(dt * pp.p1, f0, om_s);
+            }
+            // ... and Newton-type sweeps of the linearised step maps
+            double w1 = om_s;        // omega at this lane's step end
+            double rmax = 0.0;
+            int sweep = 0;
+            bool done = false;
+            while (!done) {
+                ++sweep;
+                double r0, r2, r3, r4, lam, dummy;
+                const double f0 = omega_rhs<true>(sh, w, md0, rm0, wg, r0, lam);
+                const Phi ph = phi123(0.5 * h * lam);
+                const Phi pf = phi_double(ph);
+                const double N0 = fma(-lam, wg, f0);
+                const double U2 = fma(ph.e, wg, 0.5 * h * ph.p1 * N0);
+                const double N2 = fma(-lam, U2, omega_rhs<false>(sh, w, mdh, rmh, U2, r2, dummy));
+                const double U3 = fma(ph.e, wg, fma(0.5 * h * (ph.p1 - 2.0 * ph.p2), N0, h * ph.p2 * N2));
+                const double N3 = fma(-lam, U3, omega_rhs<false>(sh, w, mdh, rmh, U3, r3, dummy));
+                const double U4 = fma(pf.e, wg, fma(h * (pf.p1 - 2.0 * pf.p2), N0, 2.0 * h * pf.p2 * N3));
+                const double N4 = fma(-lam, U4, omega_rhs<false>(sh, w, md1, rm1, U4, r4, dummy));
+                const double v = fma(pf.e, wg,
+                                     h * fma(pf.p1 - 3.0 * pf.p2 + 4.0 * pf.p3, N0,
+                                             fma(2.0 * pf.p2 - 4.0 * pf.p3, N2 + N3, (4.0 * pf.p3 - pf.p2) * N4)));
+                // linearised step map about the current guess: omega_end = e^{h lam} (omega_start - wg) + v
+                double aW = active ? pf.e : 1.0;
+                double bW = active ? fma(-pf.e, wg, v) : 0.0;
+                scan_affine(aW, bW, lane);
+                w1 = fma(aW, om_s, bW);
+                double wn = __shfl_up(w1, 1, 64);
+                if (lane == 0) wn = om_s;
+                const double delta = fabs(wn - wg);
+                const bool ok = delta <= kSweepTol * fabs(wn);   // false for NaN
+                rmax = fmax(fmax(r0, r2), fmax(r3, r4));        // fmax drops NaN like the oracle's `>` test
+                wg = wn;
+                done = (__ballot(active && !ok) == 0ull) || sweep >= kMaxSweeps;
+            }
+            sweeps_total += sweep;
+
+            // ---------------- failure detection in time order (oracle/mp_oracle.c)
+            {
+                const bool bad = !(isfinite(M0) && isfinite(wg)) || M0 <= 0.0 || wg <= 0.0;
+                const bool flg = rmax > 0.27;
+                const unsigned long long mb = __ballot(active && bad), mf = __ballot(active && flg);
+                if (mb | mf) {
+                    const int first = __ffsll((unsigned long long)(mb | mf)) - 1;
+                    status = ((mb >> first) & 1ull) ? MP_STATUS_NONFINITE : MP_STATUS_FLAG;
+                    break;
+                }
+            }
+
+            // ---------------- luminosity at the step ends, light curve through LDS, chi^2
+            double Lt, Lp, Ld;
+            luminosity(sh, w, md1, rm1, w1, Lt, Lp, Ld);
+            if (CURVES && active) {
+                const size_t o = row + (size_t)i + 1;
+                if (a.ltot) a.ltot[o] = Lt / 1.0e50;
+                if (a.lprop) a.lprop[o] = Lp / 1.0e50;
+                if (a.ldip) a.ldip[o] = Ld / 1.0e50;
+                if (a.mdisc) a.mdisc[o] = M1;
+                if (a.omega) a.omega[o] = w1;
+            }
+            if (a.want_chi2) {
+                const int j0 = tptr[tile], j1 = tptr[tile + 1];
+                if (j1 > j0) {
+                    Lbuf[lane + 1] = Lt;
+                    if (lane == 0) Lbuf[0] = L_s;
+                    __syncthreads();
+                    for (int j = j0 + lane; j < j1; j += kTile) {
+                        const int jj = dsd.obs_off + j;
+                        const int g = sh.obs_g[jj] - tile * kTile;
+                        const double La = Lbuf[g], Lb = Lbuf[g + 1];
+                        const double slope = (Lb - La) * sh.obs_idt[jj];
+                        const double mod = fma(slope, sh.obs_dx[jj], La) / 1.0e50;
+                        const double res = (sh.obs_y[jj] - mod) / sh.obs_yerr[jj];
+                        chi = fma(res, res, chi);
+                    }
+                    __syncthreads();
+                }
+            }
+
+            // ---------------- carry the tile end to the next tile
+            const int last = (nsteps - tile * kTile) >= kTile ? kTile - 1 : (nsteps - tile * kTile - 1);
+            M_s = lane_bcast(M1, last);
+            om_s = lane_bcast(w1, last);
+            S_s = lane_bcast(S2, last);
+            md_s = lane_bcast(md1, last);
+            rm_s = lane_bcast(rm1, last);
+            L_s = lane_bcast(Lt, last);
+        }
+        if (status == MP_STATUS_OK) {
+            // state at the last grid point
+            if (!(isfinite(M_s) && isfinite(om_s)) || M_s <= 0.0 || om_s <= 0.0) status = MP_STATUS_NONFINITE;
+            else if (sh.crot * om_s * om_s > 0.27) status = MP_STATUS_FLAG;
+        }
+    }
+
+    double lnp = -INFINITY;
+    if (status == MP_STATUS_OK) {
+        lnp = -0.5 * wave_sum(chi);
+        if (!isfinite(lnp)) { lnp = -INFINITY; status = MP_STATUS_NONFINITE; }
+    }
+    if (lane == 0) {
+        a.lnprob[walker] = lnp;
+        if (a.status) a.status[walker] = status;
+        if (a.sweeps) a.sweeps[walker] = sweeps_total;
+    }
+}
+
+int launch_lnprob(const DevShared &sh, const LaunchArgs &a, void *stream) {
+    if (a.n <= 0) return 0;
+    const bool curves = a.ltot || a.lprop || a.ldip || a.mdisc || a.omega;
+    dim3 grid((unsigned)a.n), block(64);
+    if (curves)
+        hipLaunchKernelGGL(lnprob_kernel<true>, grid, block, 0, (hipStream_t)stream, sh, a);
+    else
+        hipLaunchKernelGGL(lnprob_kernel<false>, grid, block, 0, (hipStream_t)stream, sh, a);
+    return (int)hipGetLastError();
+}
+
+}  // namespace mp

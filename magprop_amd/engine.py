@@ -1,0 +1,78 @@
+"""Handle / dataset caches shared by the reference-shaped front ends (funcs, mcmc_eqns, synth, LogProb)."""
+import hashlib
+import threading
+
+import numpy as np
+
+from . import _capi
+
+_lock = threading.Lock()
+_handles = {}
+
+
+def grid(GRBtype=None):
+    """Time grid selection of magnetar/funcs.py:132-141 (same ValueError text)."""
+    if GRBtype is not None and GRBtype == "S":
+        return np.logspace(-3.0, 6.0, num=10001, base=10.0)
+    if GRBtype is None or GRBtype == "L":
+        return np.logspace(0.0, 6.0, num=10001, base=10.0)
+    raise ValueError("Please provide a valid value for GRBtype.\nOptions are: L, S, or None.")
+
+
+def _cfg_key(cfg):
+    return tuple(getattr(cfg, f[0]) for f in cfg._fields_)
+
+
+class Engine:
+    """One mp_handle plus a content-addressed cache of the datasets registered on it."""
+
+    def __init__(self, cfg, tgrid, device=-1):
+        self.handle = _capi.Handle(cfg, tgrid, device)
+        self._slots = {}      # digest -> slot
+        self._order = []      # LRU of digests
+        self._prior_key = None
+        self.lock = threading.Lock()
+
+    def dataset_slot(self, x, y, yerr):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        yerr = np.ascontiguousarray(yerr, dtype=np.float64)
+        dig = hashlib.blake2b(x.tobytes() + y.tobytes() + yerr.tobytes(), digest_size=16).digest()
+        slot = self._slots.get(dig)
+        if slot is None:
+            if len(self._order) >= _capi.MAX_DATASETS:
+                old = self._order.pop(0)
+                slot = self._slots.pop(old)
+            else:
+                slot = len(self._order)
+            self.handle.set_dataset(slot, x, y, yerr)
+            self._slots[dig] = slot
+        else:
+            self._order.remove(dig)
+        self._order.append(dig)
+        return slot
+
+    def set_prior(self, lower, upper, log_mask):
+        key = (None if lower is None else (tuple(np.asarray(lower, float)), tuple(np.asarray(upper, float))),
+               int(log_mask))
+        if key != self._prior_key:
+            self.handle.set_prior(lower, upper, log_mask)
+            self._prior_key = key
+
+
+def engine(cfg, GRBtype=None, device=-1):
+    """Cached Engine for (model configuration, grid, device)."""
+    key = (_cfg_key(cfg), "S" if GRBtype == "S" else "L", int(device))
+    with _lock:
+        e = _handles.get(key)
+        if e is None:
+            e = Engine(cfg, grid(GRBtype), device)
+            _handles[key] = e
+        return e
+
+
+def clear():
+    with _lock:
+        for e in _handles.values():
+            e.handle.close()
+        _handles.clear()

@@ -1,0 +1,57 @@
+"""Light-curve front end with the reference's signatures, evaluated by the gfx950 kernels.
+
+Mirrors ``magnetar/funcs.py`` (``init_conds`` :17-29, ``model_lc`` :105-220) and
+``code/synthetic_datasets/funcs.py`` (``model_lum`` :146-236).  Both physics variants are one kernel
+parametrised by ``mp_model_cfg``.
+"""
+import numpy as np
+
+from . import _capi, engine
+
+Msol = 1.99e33
+
+
+def init_conds(MdiscI, P):
+    """magnetar/funcs.py:17-29: disc mass [g] and angular frequency [rad/s]."""
+    return np.array([MdiscI * Msol, (2.0 * np.pi) / (1.0e-3 * P)])
+
+
+def _curve(cfg, pars, xdata, GRBtype, device):
+    pars = np.asarray(pars, dtype=np.float64)
+    if pars.shape != (6,):
+        raise ValueError("pars must hold the six parameters B, P, MdiscI, RdiscI, epsilon, delta")
+    eng = engine.engine(cfg, GRBtype, device)
+    with eng.lock:
+        status, out = eng.handle.model_lc(pars)
+    if status != _capi.STATUS_OK:
+        return "flag"  # magnetar/funcs.py:153-154
+    if xdata is None:
+        return out
+    x = np.asarray(xdata, dtype=np.float64)
+    t = eng.handle.tgrid
+    if np.any(x < t[0]):
+        raise ValueError("A value in x_new is below the interpolation range.")
+    if np.any(x > t[-1]):
+        raise ValueError("A value in x_new is above the interpolation range.")
+    return np.interp(x, t, out[1])
+
+
+def model_lc(pars, xdata=None, GRBtype=None, dipeff=0.05, propeff=0.4, f_beam=1.0, n=1.0, alpha=0.1, cs7=1.0,
+             k=0.9, device=-1):
+    """magnetar/funcs.py:105-220.  As in the reference, ``n``, ``alpha``, ``cs7`` and ``k`` reach only
+    the luminosity stage: its ``odeint`` call passes five arguments (:150-151), so the ODE always runs
+    with n=1, alpha=0.1, cs7=1, k=0.9.  alpha/cs7/k different from those defaults are rejected here
+    instead of silently integrating one model and lighting another."""
+    engine.grid(GRBtype)  # ValueError for a bad GRBtype before anything else, as :138-141
+    if (alpha, cs7, k) != (0.1, 1.0, 0.9):
+        raise NotImplementedError("model_lc: alpha, cs7, k other than the reference defaults are not forwarded "
+                                  "to the ODE by the reference (magnetar/funcs.py:150-151); unsupported")
+    cfg = _capi.cfg_lib(dipeff=dipeff, propeff=propeff, f_beam=f_beam, n_lum=n)
+    return _curve(cfg, pars, xdata, GRBtype, device)
+
+
+def model_lum(pars, xdata=None, n=10.0, alpha=0.1, cs7=1.0, k=0.9, dipeff=1.0, propeff=1.0, f_beam=1.0, device=-1):
+    """code/synthetic_datasets/funcs.py:146-236 (fixed logspace(0,6,10001) grid, all keywords forwarded)."""
+    cfg = _capi.cfg_synth(n_ode=n, n_lum=n, alpha=alpha, cs7=cs7, k=k, dipeff=dipeff, propeff=propeff,
+                          f_beam=f_beam)
+    return _curve(cfg, pars, xdata, None, device)

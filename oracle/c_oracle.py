@@ -1,0 +1,134 @@
+"""ctypes loader for oracle/libmp_oracle.so — TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+module.  It wraps the serial C restatement in oracle/mp_oracle.c (see that file's header
+for the reference file:line each function follows).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libmp_oracle.so")
+
+STATUS_OK, STATUS_FLAG, STATUS_NONFINITE, STATUS_PRIOR = 0, 1, 2, 3
+
+
+class Cfg(C.Structure):
+    _fields_ = [(n, C.c_double) for n in (
+        "inertia_factor", "rm_massflow_factor", "n_ode", "n_lum", "alpha", "cs7", "k",
+        "dipeff", "propeff", "f_beam", "nacc_lum_threshold")] + [
+        ("lprop_gm_term", C.c_int32), ("reserved", C.c_int32)]
+
+
+def cfg_synth(**kw):
+    """code/synthetic_datasets/funcs.py:17,105,146-147,206,222-223."""
+    c = Cfg(0.35, 3.0, 10.0, 10.0, 0.1, 1.0, 0.9, 1.0, 1.0, 1.0, 0.27, 1, 0)
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
+
+
+def cfg_lib(**kw):
+    """magnetar/funcs.py:12,33-34,64,105-106,150-151,193,206 (the ODE always runs with n=1)."""
+    c = Cfg(0.8, 1.0, 1.0, 1.0, 0.1, 1.0, 0.9, 0.05, 0.4, 1.0, 0.0, 0, 0)
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
+
+
+def build(force=False):
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(
+            os.path.join(_HERE, "mp_oracle.c")):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB)
+        dp = C.POINTER(C.c_double)
+        ip = C.POINTER(C.c_int32)
+        L.mpo_trajectory.restype = C.c_int
+        L.mpo_trajectory.argtypes = [C.POINTER(Cfg), dp, C.c_int, dp, C.c_int, C.c_int, dp, dp]
+        L.mpo_model_lc.restype = C.c_int
+        L.mpo_model_lc.argtypes = [C.POINTER(Cfg), dp, C.c_int, dp, C.c_int, C.c_int, dp, dp]
+        L.mpo_lnlike.restype = C.c_double
+        L.mpo_lnlike.argtypes = [C.POINTER(Cfg), dp, C.c_int, dp, C.c_int, dp, dp, dp, C.c_int,
+                                 C.POINTER(C.c_int)]
+        L.mpo_lnprob_batch.restype = None
+        L.mpo_lnprob_batch.argtypes = [C.POINTER(Cfg), dp, C.c_int, C.c_int, dp, dp, C.c_int, C.c_uint32,
+                                       dp, C.c_int, dp, dp, dp, C.c_int, dp, ip]
+        _lib = L
+    return _lib
+
+
+def _d(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def trajectory(cfg, pars, tgrid, nsub=1):
+    """(status, Mdisc[n], omega[n]) for PHYSICAL parameters."""
+    p, pp = _d(pars)
+    t, tp = _d(tgrid)
+    M = np.empty(t.size)
+    W = np.empty(t.size)
+    st = lib().mpo_trajectory(C.byref(cfg), pp, p.size, tp, t.size, nsub,
+                              M.ctypes.data_as(C.POINTER(C.c_double)), W.ctypes.data_as(C.POINTER(C.c_double)))
+    return st, M, W
+
+
+def model_lc(cfg, pars, tgrid, nsub=1, want_traj=False):
+    """(status, out[4][n]) like model_lc/model_lum(xdata=None); PHYSICAL parameters."""
+    p, pp = _d(pars)
+    t, tp = _d(tgrid)
+    out = np.empty((4, t.size))
+    traj = np.empty((2, t.size))
+    st = lib().mpo_model_lc(C.byref(cfg), pp, p.size, tp, t.size, nsub,
+                            out.ctypes.data_as(C.POINTER(C.c_double)),
+                            traj.ctypes.data_as(C.POINTER(C.c_double)))
+    return (st, out, traj) if want_traj else (st, out)
+
+
+def lnlike(cfg, pars, tgrid, x, y, yerr):
+    """(lnlike, status) for PHYSICAL parameters."""
+    p, pp = _d(pars)
+    t, tp = _d(tgrid)
+    x, xp = _d(x)
+    y, yp = _d(y)
+    e, ep = _d(yerr)
+    st = C.c_int(0)
+    ll = lib().mpo_lnlike(C.byref(cfg), pp, p.size, tp, t.size, xp, yp, ep, x.size, C.byref(st))
+    return ll, st.value
+
+
+def lnprob_batch(cfg, pars, tgrid, x, y, yerr, lower=None, upper=None, log_mask=0):
+    """(lnprob[n], status[n]) in sampler coordinates (box prior + un-logging per log_mask)."""
+    pars = np.atleast_2d(np.ascontiguousarray(pars, dtype=np.float64))
+    nw, nd = pars.shape
+    t, tp = _d(tgrid)
+    x, xp = _d(x)
+    y, yp = _d(y)
+    e, ep = _d(yerr)
+    if lower is None:
+        lo, lop = _d(np.zeros(1))
+        hi, hip = _d(np.zeros(1))
+        npr = 0
+    else:
+        lo, lop = _d(lower)
+        hi, hip = _d(upper)
+        npr = lo.size
+    out = np.empty(nw)
+    st = np.empty(nw, dtype=np.int32)
+    lib().mpo_lnprob_batch(C.byref(cfg), pars.ctypes.data_as(C.POINTER(C.c_double)), nw, nd, lop, hip, npr,
+                           C.c_uint32(log_mask), tp, t.size, xp, yp, ep, x.size,
+                           out.ctypes.data_as(C.POINTER(C.c_double)), st.ctypes.data_as(C.POINTER(C.c_int32)))
+    return out, st

@@ -1,0 +1,284 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by IMPORTING the real reference.
+
+Runs only in the development container, where the reference checkout is mounted read-only at
+/root/reference (it does not exist on the GPU box and never travels).  Nothing from the
+reference is copied: this script calls its functions and stores inputs + outputs as data.
+
+    PYTHONDONTWRITEBYTECODE=1 python3 tests/golden/make_golden.py [--flag-scan N]
+
+What is called (paths relative to /root/reference):
+  synth variant : code/synthetic_datasets/funcs.py  model_lum (:146), ODEs (:75), init_conds (:51), tarr (:19)
+                  code/synthetic_datasets/mcmc_eqns.py  lnprior (:28)
+                  lnlike/lnprob cannot be called under numpy>=2 (`mod == 'flag'` on an ndarray, :22), so the
+                  three arithmetic lines :16-17 and :25 are applied here around the real model_lum.
+  lib variant   : magnetar/funcs.py  model_lc (:105), odes (:33), init_conds (:17)
+                  magnetar/mcmc_eqns.py:37 chi-square line applied around the real model_lc.
+  data recipe   : code/synthetic_datasets/generate_data.py:61-67 with np.random.seed(20261003 + k).
+  in-tree fixtures (data the reference's tests hold): tests/test_data/odes_integrated_by_odeint.csv,
+                  tests/test_data/model_light_curve.csv — decimated (every 20th row) copies.
+`*_tight` arrays: the same reference code with its odeint call given rtol=atol=1e-12 (integrator noise
+removed; see tight_lsoda).
+Outputs: golden_synth.npz, golden_lib.npz, golden_flagscan.npz, MANIFEST.json.
+"""
+import argparse
+import contextlib
+import io
+import json
+import os
+import sys
+
+import numpy as np
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.dont_write_bytecode = True
+sys.path.insert(0, os.path.join(REF, "code", "synthetic_datasets"))
+sys.path.insert(0, REF)
+
+import funcs as sf            # noqa: E402  (reference, synth variant)
+import mcmc_eqns as sm        # noqa: E402
+import magnetar as lib        # noqa: E402  (reference, lib variant)
+from scipy.integrate import odeint  # noqa: E402
+
+GRB_PARS = {  # generate_data.py:10-15 (inputs to the reference; restated as data)
+    "Humped": [1.0, 5.0, 1.0e-3, 100.0, 0.1, 1.0],
+    "Classic": [1.0, 5.0, 1.0e-3, 1000.0, 0.1, 1.0],
+    "Sloped": [1.0, 1.0, 1.0e-3, 100.0, 10.0, 10.0],
+    "Stuttering": [1.0, 5.0, 1.0e-5, 100.0, 0.1, 100.0],
+}
+TRUTHS = {  # synth_mcmc.py:16-21
+    "Humped": [1.0, 5.0, -3.0, 2.0, -1.0, 0.0],
+    "Classic": [1.0, 5.0, -3.0, 3.0, -1.0, 0.0],
+    "Sloped": [1.0, 1.0, -3.0, 2.0, 1.0, 1.0],
+    "Stuttering": [1.0, 5.0, -5.0, 2.0, -1.0, 2.0],
+}
+TYPES = list(GRB_PARS)
+SEED0 = 20261003
+LOWER = np.array([1.0e-3, 0.69, -6.0, np.log10(50.0), -2.0, -1.0])   # mcmc_eqns.py:41
+UPPER = np.array([10.0, 10.0, -2.0, np.log10(2000.0), 2.0, 3.0])     # mcmc_eqns.py:40
+DECIM = 50
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stderr(io.StringIO()):
+        return fn(*a, **k)
+
+
+def synth_dataset(name, seed):
+    """generate_data.py:55-67 around the real model_lum, with a fixed legacy seed."""
+    model = sf.model_lum(np.array(GRB_PARS[name]))
+    np.random.seed(seed)
+    inx = np.sort(np.random.randint(low=0, high=model.shape[1], size=50))
+    x = model[0, inx].copy()
+    y = model[1, inx].copy()
+    yerr = 0.25 * y
+    y += np.random.normal(loc=0.0, scale=yerr, size=len(yerr))
+    return inx, x, y, yerr
+
+
+@contextlib.contextmanager
+def tight_lsoda(tol=1.0e-12, mxstep=100000):
+    """Run the reference's model_lum with its odeint call (funcs.py:169-170) given tight tolerances:
+    same reference RHS / luminosity / interpolation code, integrator noise removed."""
+    orig = sf.odeint
+
+    def wrapped(func, y0, t, **kw):
+        kw.update(rtol=tol, atol=tol, mxstep=mxstep)
+        return orig(func, y0, t, **kw)
+    sf.odeint = wrapped
+    try:
+        yield
+    finally:
+        sf.odeint = orig
+
+
+def synth_lnprob(p, x, y, yerr):
+    """mcmc_eqns.py:52-81 with :16-17, :22-25 restated around the real model_lum/lnprior."""
+    if not np.isfinite(sm.lnprior(np.asarray(p))):
+        return -np.inf, 3
+    arr = np.array(p, dtype=float)
+    arr[2:] = 10.0 ** arr[2:]
+    mod = quiet(sf.model_lum, arr, xdata=x)
+    if isinstance(mod, str):
+        return -np.inf, 1
+    ll = -0.5 * np.sum(((y - mod) / yerr) ** 2.0)
+    if not np.isfinite(ll):
+        return -np.inf, 2
+    return ll, 0
+
+
+def synth_param_cloud(name, rng):
+    """64 sampler-coordinate vectors: near-truth, +-5 %, prior-wide, edges."""
+    t = np.array(TRUTHS[name])
+    out = [t.copy()]
+    out += [t + 1.0e-4 * rng.standard_normal(6) for _ in range(23)]          # synth_mcmc.py:175-176
+    out += [t + 0.05 * np.maximum(np.abs(t), 0.5) * rng.standard_normal(6) for _ in range(12)]
+    out += [LOWER + (UPPER - LOWER) * rng.random(6) for _ in range(22)]
+    e = t.copy(); e[5] = 3.5; out.append(e)                                  # outside prior (upper)
+    e = t.copy(); e[0] = 1.0e-4; out.append(e)                               # outside prior (lower)
+    e = t.copy(); e[1] = 0.69; out.append(e)                                 # on the lower P edge
+    e = t.copy(); e[3] = np.log10(2000.0); out.append(e)                     # on the upper Rdisc edge
+    out.append(np.array([1.8171068, 3.68147895, -2.61786801, 1.99840102, -0.33083576, 2.95613803]))  # SURVEY flag
+    out.append(np.array([10.0, 0.69, -2.0, np.log10(50.0), -2.0, 3.0]))      # prior corner
+    return np.array(out[:64])
+
+
+def make_synth():
+    tarr = sf.tarr.copy()
+    g = {"tarr_first_last": np.array([tarr[0], tarr[1], tarr[-2], tarr[-1]]), "prior_lower": LOWER,
+         "prior_upper": UPPER, "decim": np.array(DECIM)}
+    rng = np.random.default_rng(SEED0)
+    for k, name in enumerate(TYPES):
+        inx, x, y, yerr = synth_dataset(name, SEED0 + k)
+        g[f"{name}_inx"], g[f"{name}_x"], g[f"{name}_y"], g[f"{name}_yerr"] = inx, x, y, yerr
+        # full light curve + trajectory of the canonical parameter set
+        pars = np.array(GRB_PARS[name])
+        lc = sf.model_lum(pars)
+        g[f"{name}_lc"] = lc[:, ::DECIM]
+        y0 = sf.init_conds(pars[2], pars[1])
+        args = (pars[0], pars[2], pars[3], pars[4], pars[5], 10.0, 0.1, 1.0, 0.9)
+        soln, info = odeint(sf.ODEs, y0, tarr, args=args, full_output=True)
+        g[f"{name}_traj"] = soln[::DECIM].T.copy()
+        g[f"{name}_lsoda_counts"] = np.array([info["nst"][-1], info["nfe"][-1], info["nje"][-1]])
+        tight = odeint(sf.ODEs, y0, tarr, args=args, rtol=1e-12, atol=1e-12, mxstep=5000)
+        g[f"{name}_traj_tight"] = tight[::DECIM].T.copy()
+        # posterior values on the parameter cloud
+        P = synth_param_cloud(name, rng)
+        lnp = np.empty(len(P)); st = np.empty(len(P), dtype=np.int32)
+        for i, p in enumerate(P):
+            lnp[i], st[i] = synth_lnprob(p, x, y, yerr)
+        g[f"{name}_pars"], g[f"{name}_lnprob"], g[f"{name}_status"] = P, lnp, st
+        with tight_lsoda():
+            g[f"{name}_lnprob_tight"] = np.array([synth_lnprob(p, x, y, yerr)[0] if s == 0 else np.nan
+                                                  for p, s in zip(P, st)])
+        print(name, "lnprob(truth) =", repr(lnp[0]), "flags:", int((st == 1).sum()), "prior:", int((st == 3).sum()))
+    # a few prior-wide light curves (model_lum with xdata=None) for curve-level parity
+    wide = []
+    wide_lc = []
+    while len(wide) < 6:
+        p = LOWER + (UPPER - LOWER) * rng.random(6)
+        arr = p.copy(); arr[2:] = 10.0 ** arr[2:]
+        lc = quiet(sf.model_lum, arr)
+        if isinstance(lc, str):
+            continue
+        wide.append(arr); wide_lc.append(lc[1:, ::DECIM])
+    g["wide_pars_physical"] = np.array(wide)
+    g["wide_lc"] = np.array(wide_lc)
+    np.savez_compressed(os.path.join(HERE, "golden_synth.npz"), **g)
+    return g
+
+
+def make_flagscan(n):
+    """Oracle flag status over the uniform prior box (Humped dataset): validates the deterministic rule."""
+    rng = np.random.default_rng(SEED0 + 77)
+    _, x, y, yerr = synth_dataset("Humped", SEED0)
+    P = LOWER + (UPPER - LOWER) * rng.random((n, 6))
+    lnp = np.empty(n); st = np.empty(n, dtype=np.int32)
+    for i, p in enumerate(P):
+        lnp[i], st[i] = synth_lnprob(p, x, y, yerr)
+        if i % 200 == 0:
+            print("flagscan", i, n, flush=True)
+    ntight = min(n, 400)
+    tight = np.full(n, np.nan)
+    with tight_lsoda():
+        for i in range(ntight):
+            if st[i] == 0:
+                tight[i] = synth_lnprob(P[i], x, y, yerr)[0]
+    np.savez_compressed(os.path.join(HERE, "golden_flagscan.npz"), pars=P, lnprob=lnp, status=st,
+                        lnprob_tight=tight)
+    print("flag rate", (st == 1).mean())
+
+
+def make_lib():
+    os.chdir(REF)  # magnetar/mcmc_eqns.py:55 reads a cwd-relative CSV
+    import pandas as pd
+    g = {}
+    pars = np.array(GRB_PARS["Humped"])
+    for kind in ("L", "S"):
+        lc = lib.model_lc(pars, GRBtype=kind)
+        g[f"lc_{kind}"] = lc[:, ::DECIM]
+    g["lc_None_equals_L"] = np.array(np.array_equal(lib.model_lc(pars), lib.model_lc(pars, GRBtype="L")))
+    # non-default keyword arguments (n only reaches the luminosity stage: funcs.py:150-151 vs :185)
+    g["lc_L_n10_dip1_prop1"] = lib.model_lc(pars, GRBtype="L", n=10.0, dipeff=1.0, propeff=1.0)[:, ::DECIM]
+    g["lc_L_fbeam"] = lib.model_lc(pars, GRBtype="L", f_beam=25.0, dipeff=0.3, propeff=0.7)[:, ::DECIM]
+    # in-tree fixtures of the reference's own tests, decimated (data, not source)
+    ode = pd.read_csv(os.path.join(REF, "tests/test_data/odes_integrated_by_odeint.csv"), index_col=False)
+    mlc = pd.read_csv(os.path.join(REF, "tests/test_data/model_light_curve.csv"), index_col=False)
+    g["intree_odes"] = np.array([ode["Mdisc"].values, ode["omega"].values, ode["t"].values])[:, ::20]
+    g["intree_odes_pars"] = np.array([1.0, 1.0, 1.0e-3, 100.0, 1.0, 10.0])  # tests/test_funcs.py:36-41 (B,P,MdiscI,RdiscI,eps,delta)
+    g["intree_lc"] = np.array([mlc["Ldip"].values, mlc["Lprop"].values, mlc["Ltot"].values, mlc["t"].values])[:, ::20]
+    g["intree_lc_pars"] = pars                                               # tests/test_funcs.py:55
+    # lib-variant likelihood on physical parameters (magnetar/mcmc_eqns.py:17-37) for 6/7/8/9 parameters
+    rng = np.random.default_rng(SEED0 + 5)
+    for kind in ("L", "S"):
+        lc = lib.model_lc(pars, GRBtype=kind)
+        np.random.seed(SEED0 + (10 if kind == "L" else 11))
+        inx = np.sort(np.random.randint(0, lc.shape[1], 60))
+        x = lc[0, inx] * (1.0 + 3.0e-4 * rng.random(60))      # off-knot times, inside the grid
+        x = np.clip(x, lc[0, 0], lc[0, -1])
+        y0 = np.interp(x, lc[0], lc[1])
+        yerr = 0.2 * y0
+        y = y0 + rng.normal(0.0, yerr)
+        data = pd.DataFrame({"t": x, "Lum50": y, "Lum50err": yerr})
+        g[f"ds_{kind}"] = np.array([x, y, yerr])
+        cases = []
+        vals = []
+        for nd in (6, 7, 8, 9):
+            for _ in range(4):
+                p6 = pars * (1.0 + 0.2 * rng.standard_normal(6))
+                p6 = np.abs(p6)
+                extra = {6: [], 7: [rng.uniform(1, 600)], 8: [rng.uniform(0.01, 1), rng.uniform(0.01, 1)],
+                         9: [rng.uniform(0.01, 1), rng.uniform(0.01, 1), rng.uniform(1, 600)]}[nd]
+                p = np.concatenate([p6, extra])
+                ll = lib.lnlike(p, data, kind)
+                row = np.full(9, np.nan); row[:nd] = p
+                cases.append(row); vals.append(ll)
+        g[f"lnlike_{kind}_pars"] = np.array(cases)
+        g[f"lnlike_{kind}"] = np.array(vals)
+    # lnprior behaviour incl. the 7-parameter special case (magnetar/mcmc_eqns.py:64-79)
+    lims = pd.read_csv(os.path.join(REF, "magnetar/mcmc_limits.csv"), index_col="pars")
+    g["limits_lower"] = lims["lower"].values
+    g["limits_upper"] = lims["upper"].values
+    pri_cases = [
+        [1.0, 5.0, -2.0, 2.0, 0.0, 0.0],
+        [1.0, 5.0, -3.5, 2.0, 0.0, 0.0],
+        [1.0, 5.0, -2.0, 2.0, 0.0, 0.0, 300.0],
+        [1.0, 5.0, -2.0, 2.0, 0.0, 0.0, 0.5],
+        [1.0, 5.0, -2.0, 2.0, 0.0, 0.0, 0.5, 0.5],
+        [1.0, 5.0, -2.0, 2.0, 0.0, 0.0, 0.5, 1.5],
+        [1.0, 5.0, -2.0, 2.0, 0.0, 0.0, 0.5, 0.5, 300.0],
+        [1.0, 5.0, -2.0, 2.0, 0.0, 0.0, 0.5, 0.5, 0.5],
+    ]
+    rows = []; vals = []
+    for p in pri_cases:
+        row = np.full(9, np.nan); row[:len(p)] = p
+        rows.append(row); vals.append(lib.lnprior(np.array(p)))
+    g["lnprior_pars"] = np.array(rows)
+    g["lnprior"] = np.array(vals)
+    np.savez_compressed(os.path.join(HERE, "golden_lib.npz"), **g)
+    print("lib lnlike L:", g["lnlike_L"][:4])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--flag-scan", type=int, default=1500)
+    a = ap.parse_args()
+    import scipy, pandas
+    make_synth()
+    make_flagscan(a.flag_scan)
+    make_lib()
+    manifest = {
+        "generator": "tests/golden/make_golden.py",
+        "reference": "sgibson91/magprop mounted at /root/reference (magnetar v%s)" % lib.__version__
+        if hasattr(lib, "__version__") else "sgibson91/magprop mounted at /root/reference",
+        "versions": {"python": sys.version.split()[0], "numpy": np.__version__, "scipy": scipy.__version__,
+                     "pandas": pandas.__version__},
+        "seed0": SEED0, "decimation": DECIM, "flag_scan_n": a.flag_scan,
+    }
+    with open(os.path.join(HERE, "MANIFEST.json"), "w") as f:
+        json.dump(manifest, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()
