@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""bench.py — walker-lnprob evaluations/sec of the HIP hot path (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one ensemble of proposals: every walker's lnprior + ODE
+integration over the 10 001-point grid + luminosity curve + interpolation + chi^2.  Workload at N=1:
+BASELINE.json configs[1] — Humped synthetic dataset, N_walk = 1024, fp64.  With N GPUs the ensemble is
+N x 1024 walkers (weak scaling; N=8 is configs[3], 8192 walkers), sharded contiguously over the ranks,
+followed by ONE RCCL all-gather of the lnprob slices so every rank sees the full ensemble (what the
+stretch move needs).  Proposals are resident in HBM before the timed region (they are generated on
+device, replicated on every rank from a common seed, like a replicated-RNG sampler would).
+
+Prints one JSON line on rank 0 (contract in the task description) with two extra objects:
+  roofline     — the lnprob kernel's algorithmic HBM bytes / measured kernel time vs the 8 TB/s peak.
+                 This path is NOT HBM-bound (and has no MFMA work): it is a latency-bound fp64 VALU
+                 recurrence, so the HBM fraction is tiny by construction; "valu" prices the same kernel
+                 against the fp64 vector peak with the flop-equivalent convention of SURVEY.md 8(d).
+  cpu_baseline — oracle/lsoda_port.py (scipy odeint + Python RHS: the reference's cost structure) timed
+                 on this box's host cores over a bounded sample of the same walkers (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+TRUTH = {"Humped": [1.0, 5.0, -3.0, 2.0, -1.0, 0.0], "Classic": [1.0, 5.0, -3.0, 3.0, -1.0, 0.0],
+         "Sloped": [1.0, 1.0, -3.0, 2.0, 1.0, 1.0], "Stuttering": [1.0, 5.0, -5.0, 2.0, -1.0, 2.0]}
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X fp64 vector peak (spec)
+FLOP_EQ_PER_EVAL = 1.3e7       # SURVEY.md 8(d) flop-equivalent convention for ONE serial evaluation
+BYTES_PER_EVAL_A = 48 + 8 + 4  # mode A: 6 fp64 parameters in, lnprob + status out
+BYTES_LTOT = 10001 * 8         # mode B adds the model light curve
+
+
+def usable_cores():
+    """CPU threads this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 64))
+
+
+def cpu_baseline(grb, budget_s, seed):
+    """Time the scipy/LSODA port over a bounded sample; must run BEFORE this process touches the GPU
+    (it forks worker processes)."""
+    import multiprocessing as mp
+
+    from oracle import lsoda_port as lp
+    g = np.load(os.path.join(ROOT, "tests", "golden", "golden_synth.npz"))
+    x, y, yerr = g[grb + "_x"], g[grb + "_y"], g[grb + "_yerr"]
+    tarr = lp.grid("L")
+    cores = usable_cores()
+    rng = np.random.default_rng(seed)
+    P = np.array(TRUTH[grb]) + 1.0e-4 * rng.standard_normal((4096, 6))
+    ctx = mp.get_context("fork")
+    done, t_used, vals = 0, 0.0, []
+    with ctx.Pool(cores, initializer=lp._pool_init, initargs=(tarr, x, y, yerr)) as pool:
+        pool.map(lp._pool_eval, list(P[:cores]))                 # warm the workers (imports, first call)
+        chunk = cores * 2
+        while t_used < budget_s and done + chunk <= len(P):
+            t0 = time.perf_counter()
+            vals += pool.map(lp._pool_eval, list(P[done:done + chunk]))
+            t_used += time.perf_counter() - t0
+            done += chunk
+    return {"value": done / t_used, "unit": "evals/s", "cores": cores, "kind": "port",
+            "sample": f"{done} of the step-0 style walkers ({grb}, truth+1e-4*randn) through oracle/lsoda_port.py "
+                      f"(scipy {__import__('scipy').__version__} odeint/LSODA + Python RHS, multiprocessing.Pool({cores}))"
+                      f" in {t_used:.1f} s",
+            "ms_per_eval_per_core": 1e3 * t_used * cores / done, "check_lnprob0": float(vals[0])}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--nwalk", type=int, default=1024, help="walkers per GPU")
+    ap.add_argument("--grb", default="Humped", choices=list(TRUTH))
+    ap.add_argument("--curve", action="store_true", help="mode B: also write the model light curve to HBM")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--seed", type=int, default=20261003)
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched through torch.distributed.run (see the docstring)")
+        a.gpus = world
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(a.grb, a.cpu_seconds, a.seed)        # before any GPU initialisation (forks)
+
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from magprop_amd import LogProb
+    from magprop_amd.distributed import ShardedLnprob, shard_range
+    g = np.load(os.path.join(ROOT, "tests", "golden", "golden_synth.npz"))
+    x, y, yerr = g[a.grb + "_x"], g[a.grb + "_y"], g[a.grb + "_yerr"]
+    lp = LogProb(x, y, yerr, device=local_rank)
+
+    n_global = a.nwalk * world
+    total = a.warmup + a.steps
+    gen = torch.Generator(device=dev).manual_seed(a.seed)        # same seed on every rank: replicated proposals
+    truth = torch.tensor(TRUTH[a.grb], dtype=torch.float64, device=dev)
+    props = truth + 1.0e-4 * torch.randn(total, n_global, 6, dtype=torch.float64, device=dev, generator=gen)
+    lo, hi, per = shard_range(n_global, rank, world)
+    n_local = hi - lo
+    ltot = torch.empty(n_local, 10001, dtype=torch.float64, device=dev) if a.curve else None
+    status = torch.zeros(n_local, dtype=torch.int32, device=dev)
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(total)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(total)]
+    step_idx = [0]
+    stream = torch.cuda.current_stream(dev)
+
+    def eval_local(p):
+        i = step_idx[0]
+        out = torch.empty(p.shape[0], dtype=torch.float64, device=dev)
+        ev0[i].record(stream)
+        lp.handle.lnprob_batch_dev(p.data_ptr(), p.shape[0], 6, out.data_ptr(), d_status=status.data_ptr(),
+                                   d_ltot=ltot.data_ptr() if ltot is not None else 0, stream=stream.cuda_stream)
+        ev1[i].record(stream)
+        return out
+
+    sharded = ShardedLnprob(eval_local)
+    checksum = torch.zeros((), dtype=torch.float64, device=dev)
+
+    def run(i):
+        step_idx[0] = i
+        p = props[i]
+        full = sharded(p if world > 1 else p)                  # shard -> kernel -> all-gather (RCCL) of lnprob
+        return full
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for i in range(a.warmup):
+        run(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(a.warmup, total):
+        full = run(i)
+        checksum += full.sum()
+    fence()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    kern_ms = np.array([ev0[i].elapsed_time(ev1[i]) for i in range(a.warmup, total)])
+    n_flag = int((status != 0).sum().item())
+    first = float(full[0].item())
+    if rank == 0:
+        evals = n_global * a.steps
+        value = evals / dt
+        kavg = float(kern_ms.mean()) * 1e-3
+        bytes_eval = BYTES_PER_EVAL_A + (BYTES_LTOT if a.curve else 0)
+        achieved = bytes_eval * n_local / kavg / 1e9
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tf):
+            try:
+                traffic = json.load(open(tf)).get("curve" if a.curve else "lnprob", {}).get(str(n_local))
+            except Exception:  # noqa: BLE001
+                traffic = None
+        out = {
+            "metric": "walker_lnprob_evals_per_sec", "value": value, "unit": "evals/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{a.grb} synthetic dataset (N_obs=50), N_walk={a.nwalk} per GPU "
+                                   f"({n_global} walkers total), walkers at truth+1e-4*randn, 10001-point grid, "
+                                   f"mode {'B (lnprob + model light curve written to HBM)' if a.curve else 'A (lnprob only)'}",
+                       "n_walk_per_gpu": a.nwalk, "n_walk_total": n_global, "n_grid": 10001, "n_obs": int(x.size),
+                       "variant": "synth", "parallelism": f"walker-shard x{world} + RCCL all-gather(lnprob)"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "mp::lnprob_kernel", "kernel_ms_avg": 1e3 * kavg, "kernel_ms_min": float(kern_ms.min()),
+                         "algorithmic_bytes_per_eval": bytes_eval, "evals_per_launch": n_local,
+                         "note": "latency-bound fp64 VALU recurrence: neither HBM nor MFMA binds; see valu"},
+            "valu": {"flop_eq_per_eval": FLOP_EQ_PER_EVAL, "achieved_tflop_eq": FLOP_EQ_PER_EVAL * n_local / kavg / 1e12,
+                     "peak_tflops_fp64_vector": FP64_VALU_PEAK_TFLOPS,
+                     "frac": FLOP_EQ_PER_EVAL * n_local / kavg / 1e12 / FP64_VALU_PEAK_TFLOPS},
+            "kernel_evals_per_sec_per_gpu": n_local / kavg,
+            "check": {"lnprob0": first, "n_not_ok": n_flag, "checksum": float(checksum.item())},
+        }
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+            out["speedup_vs_cpu_baseline"] = value / cpu["value"]
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

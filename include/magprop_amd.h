@@ -125,8 +125,9 @@ int mp_lnprob_batch(mp_handle *h, const double *pars, const int32_t *ds_id, int 
 
 /*
  * Same, every pointer a DEVICE pointer on the handle's device; the kernel is
- * enqueued on `stream` (a hipStream_t passed as void*, NULL = the handle's own
- * stream) and the call returns without synchronising.
+ * enqueued on `stream` (a hipStream_t passed as void*; NULL is HIP's default
+ * stream, mp_stream(h) the handle's own) and the call returns without
+ * synchronising.
  */
 int mp_lnprob_batch_dev(mp_handle *h, const double *d_pars, const int32_t *d_ds_id, int n, int ndim,
                         double *d_lnprob, int32_t *d_status, double *d_ltot, void *stream);
@@ -144,6 +145,7 @@ int mp_synchronize(mp_handle *h);
 
 /* introspection used by the measurement harness */
 int mp_device(const mp_handle *h);
+void *mp_stream(const mp_handle *h); /* the handle's own hipStream_t */
 int mp_n_grid(const mp_handle *h);
 /* mean Picard sweeps per 64-step tile of the most recent host-buffer batch (diagnostic) */
 double mp_last_mean_sweeps(const mp_handle *h);

@@ -21,7 +21,7 @@ MAX_DATASETS = 64
 EXPORTS = (
     "mp_abi_version", "mp_last_error", "mp_cfg_synth", "mp_cfg_lib", "mp_create", "mp_destroy",
     "mp_set_dataset", "mp_set_prior", "mp_lnprob_batch", "mp_lnprob_batch_dev", "mp_model_lc",
-    "mp_synchronize", "mp_device", "mp_n_grid", "mp_last_mean_sweeps",
+    "mp_synchronize", "mp_device", "mp_stream", "mp_n_grid", "mp_last_mean_sweeps",
 )
 
 
@@ -81,6 +81,8 @@ def lib():
     L.mp_model_lc.argtypes = [vp, dp, C.c_int, dp, dp, ip]
     L.mp_synchronize.argtypes = [vp]
     L.mp_device.argtypes = [vp]
+    L.mp_stream.argtypes = [vp]
+    L.mp_stream.restype = vp
     L.mp_n_grid.argtypes = [vp]
     L.mp_last_mean_sweeps.argtypes = [vp]
     L.mp_last_mean_sweeps.restype = C.c_double
@@ -198,7 +200,8 @@ class Handle:
         return res if len(res) > 1 else out
 
     def lnprob_batch_dev(self, d_pars, n, ndim, d_lnprob, d_ds_id=0, d_status=0, d_ltot=0, stream=0):
-        """Device-pointer entry (ints from e.g. torch.Tensor.data_ptr()); asynchronous on `stream`."""
+        """Device-pointer entry (ints from e.g. torch.Tensor.data_ptr()); asynchronous on `stream`
+        (a hipStream_t as int; 0 = HIP's default stream, which is also torch's default stream)."""
         check(self._L.mp_lnprob_batch_dev(self._h, C.c_void_p(d_pars), C.c_void_p(d_ds_id or None), int(n),
                                           int(ndim), C.c_void_p(d_lnprob), C.c_void_p(d_status or None),
                                           C.c_void_p(d_ltot or None), C.c_void_p(stream or None)),

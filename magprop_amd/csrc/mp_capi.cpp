@@ -312,7 +312,7 @@ int mp_lnprob_batch_dev(mp_handle *h, const double *d_pars, const int32_t *d_ds_
     a.lnprob = d_lnprob;
     a.status = d_status;
     a.ltot = d_ltot;
-    const int e = mp::launch_lnprob(h->sh, a, stream ? stream : (void *)h->stream);
+    const int e = mp::launch_lnprob(h->sh, a, stream);
     if (e) return fail(MP_EHIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
     return MP_OK;
 }
@@ -413,6 +413,7 @@ int mp_synchronize(mp_handle *h) {
 }
 
 int mp_device(const mp_handle *h) { return h ? h->device : -1; }
+void *mp_stream(const mp_handle *h) { return h ? (void *)h->stream : nullptr; }
 int mp_n_grid(const mp_handle *h) { return h ? (int)h->tgrid.size() : 0; }
 double mp_last_mean_sweeps(const mp_handle *h) { return h ? h->last_mean_sweeps : 0.0; }
 

@@ -35,27 +35,115 @@ namespace mp {
 
 #define MP_DEV __device__ __forceinline__
 
-// ---------------------------------------------------------------- wavefront helpers
-MP_DEV double lane_bcast(double v, int src) { return __shfl(v, src, 64); }
+// ---------------------------------------------------------------- wavefront helpers (DPP, no LDS)
+// DPP controls (GFX9 encoding): row_shr:n = 0x110+n, wave_shr:1 = 0x138, row_bcast:15 = 0x142, row_bcast:31 = 0x143.
+template <int CTRL, int ROW_MASK>
+MP_DEV double dpp_move(double keep, double src) {
+    // lanes with a valid DPP source (and enabled by ROW_MASK) receive src from that lane, all others `keep`
+    const int klo = __double2loint(keep), khi = __double2hiint(keep);
+    const int slo = __double2loint(src), shi = __double2hiint(src);
+    const int lo = __builtin_amdgcn_update_dpp(klo, slo, CTRL, ROW_MASK, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(khi, shi, CTRL, ROW_MASK, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+
+// value of lane-1 (lane 0 receives `first`)
+MP_DEV double lane_prev(double v, double first) { return dpp_move<0x138, 0xF>(first, v); }
+
+// broadcast lane `src` (wave-uniform index) to all lanes
+MP_DEV double lane_bcast(double v, int src) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
 
 // Inclusive scan of affine maps x -> a*x + b over the 64 lanes: afterwards lane l holds
-// m_l o m_{l-1} o ... o m_0.
-MP_DEV void scan_affine(double &a, double &b, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const double pa = __shfl_up(a, d, 64);
-        const double pb = __shfl_up(b, d, 64);
-        if (lane >= d) {
-            b = fma(a, pb, b);
-            a = a * pa;
-        }
-    }
+// m_l o m_{l-1} o ... o m_0.  Lanes without a DPP source combine with the identity (1, 0).
+template <int CTRL, int ROW_MASK>
+MP_DEV void scan_step(double &a, double &b) {
+    const double pa = dpp_move<CTRL, ROW_MASK>(1.0, a);
+    const double pb = dpp_move<CTRL, ROW_MASK>(0.0, b);
+    b = fma(a, pb, b);
+    a = a * pa;
+}
+
+MP_DEV void scan_affine(double &a, double &b) {
+    scan_step<0x111, 0xF>(a, b);  // row_shr:1
+    scan_step<0x112, 0xF>(a, b);  // row_shr:2
+    scan_step<0x114, 0xF>(a, b);  // row_shr:4
+    scan_step<0x118, 0xF>(a, b);  // row_shr:8   -> every 16-lane row scanned
+    scan_step<0x142, 0xA>(a, b);  // row_bcast:15 into rows 1 and 3
+    scan_step<0x143, 0xC>(a, b);  // row_bcast:31 into rows 2 and 3
 }
 
 MP_DEV double wave_sum(double v) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
     return v;
+}
+
+// ---------------------------------------------------------------- fp64 elementary functions
+// Hand-rolled for this kernel's argument ranges (positive, normal, far from overflow): hardware
+// seed (v_rcp_f64 / v_rsq_f64, ~2^-23) + two Newton steps, without the scaling / fix-up code the
+// general-purpose library versions carry.  All are accurate to ~1-2 ulp.
+MP_DEV double rcp_fast(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+
+MP_DEV double rsqrt_fast(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    const double hx = 0.5 * x;
+    y = fma(y, fma(-hx * y, y, 0.5), y);
+    y = fma(y, fma(-hx * y, y, 0.5), y);
+    return y;
+}
+
+// e^x for x in [-750, 700]; underflows cleanly to 0 below
+MP_DEV double exp_fast(double x) {
+    const double k = __builtin_rint(x * 1.4426950408889634074);
+    double r = fma(k, -6.93147180369123816490e-01, x);
+    r = fma(k, -1.90821492927058770002e-10, r);
+    double p = 1.0 / 479001600.0;                 // Taylor degree 12 on |r| <= ln2/2: 1.7e-16
+    p = fma(p, r, 1.0 / 39916800.0);
+    p = fma(p, r, 1.0 / 3628800.0);
+    p = fma(p, r, 1.0 / 362880.0);
+    p = fma(p, r, 1.0 / 40320.0);
+    p = fma(p, r, 1.0 / 5040.0);
+    p = fma(p, r, 1.0 / 720.0);
+    p = fma(p, r, 1.0 / 120.0);
+    p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)k);
+}
+
+// natural log of a positive normal number
+MP_DEV double log_fast(double x) {
+    int e = __builtin_amdgcn_frexp_exp(x);
+    double m = __builtin_amdgcn_frexp_mant(x);    // [0.5, 1)
+    const bool lt = m < 0.70710678118654752440;
+    m = lt ? 2.0 * m : m;                         // [sqrt(1/2), sqrt(2))
+    e = lt ? e - 1 : e;
+    const double f = m - 1.0;
+    const double s = f * rcp_fast(2.0 + f);       // |s| <= 0.1716
+    const double z = s * s;
+    double p = 1.0 / 21.0;                        // atanh series: log(m) = 2s(1 + z/3 + z^2/5 + ...)
+    p = fma(p, z, 1.0 / 19.0);
+    p = fma(p, z, 1.0 / 17.0);
+    p = fma(p, z, 1.0 / 15.0);
+    p = fma(p, z, 1.0 / 13.0);
+    p = fma(p, z, 1.0 / 11.0);
+    p = fma(p, z, 1.0 / 9.0);
+    p = fma(p, z, 1.0 / 7.0);
+    p = fma(p, z, 1.0 / 5.0);
+    p = fma(p, z, 1.0 / 3.0);
+    p = fma(p, z, 1.0);
+    return fma((double)e, 6.93147180559945309417e-01, 2.0 * s * p);
 }
 
 // ---------------------------------------------------------------- phi functions
@@ -80,20 +168,23 @@ MP_DEV Phi phi123(double z) {
     s = fma(s, z, 1.0 / 120.0);                   // 1/5!
     s = fma(s, z, 1.0 / 24.0);                    // 1/4!
     s = fma(s, z, 1.0 / 6.0);                     // 1/3!
-    const double t2 = fma(z, s, 0.5);
-    const double t1 = fma(z, t2, 1.0);
-    const double te = fma(z, t1, 1.0);
-    const double ce = exp(z);
-    const double rz = 1.0 / z;
-    const double c1 = (ce - 1.0) * rz;
-    const double c2 = (c1 - 1.0) * rz;
-    const double c3 = (c2 - 0.5) * rz;
-    const bool small = fabs(z) < 0.5;
     Phi r;
-    r.e = small ? te : ce;
-    r.p1 = small ? t1 : c1;
-    r.p2 = small ? t2 : c2;
-    r.p3 = small ? s : c3;
+    r.p3 = s;
+    r.p2 = fma(z, s, 0.5);
+    r.p1 = fma(z, r.p2, 1.0);
+    r.e = fma(z, r.p1, 1.0);
+    const bool big = !(fabs(z) < 0.5);
+    if (__any(big)) {                              // wave-uniform: only stiff / late-time tiles pay for this
+        const double ce = exp_fast(fmax(z, -750.0));
+        const double rz = rcp_fast(big ? z : 1.0);
+        const double c1 = (ce - 1.0) * rz;
+        const double c2 = (c1 - 1.0) * rz;
+        const double c3 = (c2 - 0.5) * rz;
+        r.e = big ? ce : r.e;
+        r.p1 = big ? c1 : r.p1;
+        r.p2 = big ? c2 : r.p2;
+        r.p3 = big ? c3 : r.p3;
+    }
     return r;
 }
 
@@ -112,78 +203,117 @@ struct Walker {
     double inv_tau;   // 1/tvisc
     double S_amp;     // M0/tfb
     double inv_tfb;   // 1/tfb
-    double Crm;       // mu^(4/7) GM^(-1/7) f_Rm^(-2/7)
+    double lnCrm;     // ln( mu^(4/7) GM^(-1/7) f_Rm^(-2/7) )
     double DI;        // mu^2/(6 c^3 I)          dipole torque / I = -DI*omega^3
     double D;         // mu^2/(6 c^3)
     double armI;      // sqrt(GM)/I
     double kc;        // k*c
+    double sqrt_kc;   // sqrt(k*c)
+    double Kc;        // (k*c)^1.5 / sqrt(GM): fastness of a capped Alfven radius = Kc/sqrt(omega)
     double dipeff, propeff, f_beam;
 };
 
-// fallback accretion rate Mdotfb(t), code/synthetic_datasets/funcs.py:128
-MP_DEV double mdot_fb(const Walker &w, double t) {
-    const double u = fma(t, w.inv_tfb, 1.0);  // (t + tfb)/tfb
-    const double r = rcbrt(u);
-    const double r2 = r * r;
-    return w.S_amp * (r2 * r2 * r);           // u^(-5/3)
+// What the omega equation needs to know about the disc at one time point (all omega-independent,
+// computed once per tile in the time-parallel Mdisc phase).
+struct DiscPt {
+    double mdot;  // Mdisc/tvisc
+    double rmu;   // uncapped Alfven radius, code/synthetic_datasets/funcs.py:105-106
+    double squ;   // sqrt(rmu)
+    double qu;    // rmu^1.5/sqrt(GM): uncapped fastness = omega*qu
+};
+
+MP_DEV DiscPt disc_point(const DevShared &sh, const Walker &w, double Mdisc) {
+    DiscPt p;
+    p.mdot = Mdisc * w.inv_tau;
+    p.rmu = exp_fast(fma(-2.0 / 7.0, log_fast(p.mdot), w.lnCrm));   // Crm * mdot^(-2/7)
+    p.squ = p.rmu * rsqrt_fast(p.rmu);
+    p.qu = p.rmu * p.squ * sh.inv_sqrtGM;
+    return p;
 }
 
-// uncapped Alfven radius from the disc mass-flow rate, code/synthetic_datasets/funcs.py:105-106
-MP_DEV double alfven_radius(const Walker &w, double mdot) { return w.Crm * pow(mdot, -2.0 / 7.0); }
+MP_DEV DiscPt disc_prev(const DiscPt &p, const DiscPt &first) {  // the previous lane's point (lane 0: `first`)
+    DiscPt r;
+    r.mdot = lane_prev(p.mdot, first.mdot);
+    r.rmu = lane_prev(p.rmu, first.rmu);
+    r.squ = lane_prev(p.squ, first.squ);
+    r.qu = lane_prev(p.qu, first.qu);
+    return r;
+}
 
-// d(omega)/dt at (mdot = Mdisc/tvisc, rmu = uncapped Alfven radius, om); ODE right-hand side
-// code/synthetic_datasets/funcs.py:105-140 / magnetar/funcs.py:64-99 in simplified algebra.
+MP_DEV DiscPt disc_bcast(const DiscPt &p, int src) {
+    DiscPt r;
+    r.mdot = lane_bcast(p.mdot, src);
+    r.rmu = lane_bcast(p.rmu, src);
+    r.squ = lane_bcast(p.squ, src);
+    r.qu = lane_bcast(p.qu, src);
+    return r;
+}
+
+// fallback accretion rate Mdotfb(t), code/synthetic_datasets/funcs.py:128
+MP_DEV double mdot_fb(const Walker &w, double t) {
+    const double u = fma(t, w.inv_tfb, 1.0);                        // (t + tfb)/tfb >= 1
+    return w.S_amp * exp_fast(-5.0 / 3.0 * log_fast(u));            // u^(-5/3)
+}
+
+// Radii / fastness / switch shared by the ODE right-hand side and the luminosity stage
+// (code/synthetic_datasets/funcs.py:105-123 / magnetar/funcs.py:64-84 in simplified algebra):
+//   Rm = min(rmu, k c/omega);  fastness = (Rm/Rc)^1.5 = omega Rm^1.5/sqrt(GM);  tanh(n (fastness-1)).
+struct Flow {
+    double inv_om, Rm, sq, fast, e, r, th;
+    bool capped, big;
+};
+
+MP_DEV Flow flow_state(const Walker &w, double n, const DiscPt &p, double om) {
+    Flow f;
+    const double y = rsqrt_fast(om);
+    f.inv_om = y * y;
+    const double rlc = w.kc * f.inv_om;
+    f.capped = p.rmu >= rlc;                                        // Rm >= k*Rlc -> Rm = k*Rlc
+    f.Rm = f.capped ? rlc : p.rmu;
+    f.sq = f.capped ? w.sqrt_kc * y : p.squ;                        // sqrt(Rm)
+    f.fast = f.capped ? w.Kc * y : om * p.qu;
+    const double x = fma(n, f.fast, -n);
+    f.e = exp_fast(fmax(-2.0 * fabs(x), -750.0));
+    f.r = rcp_fast(1.0 + f.e);
+    f.th = copysign((1.0 - f.e) * f.r, x);                          // tanh(x) = eta2 - eta1
+    f.big = f.Rm >= kR;
+    return f;
+}
+
+// d(omega)/dt, code/synthetic_datasets/funcs.py:119,131-140; lam = d(omega_dot)/d(omega)
 template <bool WANT_LAM>
-MP_DEV double omega_rhs(const DevShared &sh, const Walker &w, double mdot, double rmu, double om, double &rot,
-                        double &lam) {
-    const double rlc = w.kc / om;
-    const bool capped = rmu >= rlc;                      // Rm >= k*Rlc -> Rm = k*Rlc
-    const double Rm = capped ? rlc : rmu;
-    const double sq = sqrt(Rm);
-    const double fast = om * Rm * sq * sh.inv_sqrtGM;    // (Rm/Rc)^(3/2)
-    const double x = sh.cfg.n_ode * (fast - 1.0);
-    const double e = exp(-2.0 * fabs(x));
-    const double r = 1.0 / (1.0 + e);
-    const double th = copysign((1.0 - e) * r, x);        // tanh(x) = eta2 - eta1
-    rot = sh.crot * om * om;
-    const bool brk = rot > 0.27;                         // break-up: Nacc = 0
-    const bool big = Rm >= kR;
-    const double arm = w.armI * (big ? sq : sh.sqrtR);   // sqrt(GM*max(Rm,R))/I
-    const double nacc = brk ? 0.0 : -arm * mdot * th;    // Nacc/I, Macc - Mprop = -tanh * mdot
+MP_DEV double omega_rhs(const DevShared &sh, const Walker &w, const DiscPt &p, double om, double &rot, double &lam) {
+    const Flow f = flow_state(w, sh.cfg.n_ode, p, om);
     const double om2 = om * om;
+    rot = sh.crot * om2;
+    const bool brk = rot > 0.27;                                    // break-up: Nacc = 0
+    const double arm = w.armI * (f.big ? f.sq : sh.sqrtR);          // sqrt(GM*max(Rm,R))/I
+    const double nacc = brk ? 0.0 : -arm * p.mdot * f.th;           // Nacc/I ; Macc - Mprop = -tanh * mdot
     if (WANT_LAM) {
-        const double dfast = (capped ? -0.5 : 1.0) * fast / om;
-        const double sech2 = 4.0 * e * r * r;
-        const double dth = sh.cfg.n_ode * sech2 * dfast;
-        const double darm = (capped && big) ? -0.5 * arm / om : 0.0;
-        const double dn = brk ? 0.0 : -mdot * fma(darm, th, arm * dth);
+        const double dfast = (f.capped ? -0.5 : 1.0) * f.fast * f.inv_om;
+        const double dth = sh.cfg.n_ode * (4.0 * f.e * f.r * f.r) * dfast;   // n sech^2 dfast
+        const double darm = (f.capped && f.big) ? -0.5 * arm * f.inv_om : 0.0;
+        const double dn = brk ? 0.0 : -p.mdot * fma(darm, f.th, arm * dth);
         lam = fma(-3.0 * w.DI, om2, dn);
     }
     return fma(-w.DI * om2, om, nacc);
 }
 
 // luminosities (erg/s) at one grid point, reference luminosity stage
-MP_DEV void luminosity(const DevShared &sh, const Walker &w, double mdot, double rmu, double om, double &Ltot,
+// (code/synthetic_datasets/funcs.py:204-229, magnetar/funcs.py:191-210)
+MP_DEV void luminosity(const DevShared &sh, const Walker &w, const DiscPt &p, double om, double &Ltot,
                        double &Lprop, double &Ldip) {
-    const double rlc = w.kc / om;
-    const bool capped = rmu >= rlc;
-    const double Rm = capped ? rlc : rmu;
-    const double sq = sqrt(Rm);
-    const double fast = om * Rm * sq * sh.inv_sqrtGM;
-    const double x = sh.cfg.n_lum * (fast - 1.0);
-    const double e = exp(-2.0 * fabs(x));
-    const double r = 1.0 / (1.0 + e);
-    const double th = copysign((1.0 - e) * r, x);
-    const double eta2 = x >= 0.0 ? r : e * r;            // 0.5*(1 + tanh x)
-    const double rot = sh.crot * om * om;
-    const double arm = sh.sqrtGM * (Rm >= kR ? sq : sh.sqrtR);
-    const double Nacc = rot > sh.cfg.nacc_lum_threshold ? 0.0 : -arm * mdot * th;
+    const Flow f = flow_state(w, sh.cfg.n_lum, p, om);
+    const double eta2 = f.th >= 0.0 ? f.r : f.e * f.r;              // 0.5*(1 + tanh x)
     const double om2 = om * om;
+    const double rot = sh.crot * om2;
+    const double arm = sh.sqrtGM * (f.big ? f.sq : sh.sqrtR);
+    const double Nacc = rot > sh.cfg.nacc_lum_threshold ? 0.0 : -arm * p.mdot * f.th;
     double ld = w.dipeff * (w.D * om2 * om2);
     if (ld <= 0.0) ld = 0.0;
     if (!isfinite(ld)) ld = 0.0;
     double lp = -Nacc * om;
-    if (sh.cfg.lprop_gm_term) lp -= (sh.GM / Rm) * eta2 * mdot;
+    if (sh.cfg.lprop_gm_term) lp -= sh.GM * rcp_fast(f.Rm) * eta2 * p.mdot;
     lp *= w.propeff;
     if (lp <= 0.0) lp = 0.0;
     if (!isfinite(lp)) lp = 0.0;
@@ -235,11 +365,13 @@ __global__ __launch_bounds__(64) void lnprob_kernel(const DevShared sh, const La
         w.inv_tau = 1.0 / tau;
         w.S_amp = M0 / tfb;
         w.inv_tfb = 1.0 / tfb;
-        w.Crm = pow(mu, 4.0 / 7.0) * pow(sh.GM, -1.0 / 7.0) * pow(sh.cfg.rm_massflow_factor, -2.0 / 7.0);
+        w.lnCrm = (4.0 / 7.0) * log(mu) - (1.0 / 7.0) * log(sh.GM) - (2.0 / 7.0) * log(sh.cfg.rm_massflow_factor);
         w.D = (mu * mu) / (6.0 * kC * kC * kC);
         w.DI = w.D * sh.inv_inertia;
         w.armI = sh.sqrtGM * sh.inv_inertia;
         w.kc = sh.cfg.k * kC;
+        w.sqrt_kc = sqrt(w.kc);
+        w.Kc = w.kc * w.sqrt_kc * sh.inv_sqrtGM;
         w.dipeff = sh.cfg.dipeff;
         w.propeff = sh.cfg.propeff;
         w.f_beam = sh.cfg.f_beam;
@@ -252,17 +384,18 @@ __global__ __launch_bounds__(64) void lnprob_kernel(const DevShared sh, const La
     // ---- initial conditions (code/synthetic_datasets/funcs.py:66-69)
     double M_s = par[2] * kMsol;                         // Mdisc at the tile start
     double om_s = (2.0 * M_PI) / (1.0e-3 * par[1]);      // omega at the tile start
+    double om_m1 = om_s, om_m2 = om_s;                   // omega one / two grid points before the tile start
     double S_s = mdot_fb(w, sh.tgrid[0]);                // Mdotfb at the tile start
-    double md_s = M_s * w.inv_tau;
-    double rm_s = alfven_radius(w, md_s);
+    DiscPt d_s = disc_point(sh, w, M_s);
     double L_s, Lp_s, Ld_s;
-    luminosity(sh, w, md_s, rm_s, om_s, L_s, Lp_s, Ld_s);
+    luminosity(sh, w, d_s, om_s, L_s, Lp_s, Ld_s);
 
     const int dsid = a.ds_id ? a.ds_id[walker] : 0;
     const DsDesc dsd = sh.ds ? sh.ds[(dsid >= 0 && dsid < sh.n_ds) ? dsid : 0] : DsDesc{0, 0, 0, 0};
     const int32_t *tptr = sh.tile_ptr + dsd.tile_off;
     double chi = 0.0;
     int sweeps_total = 0;
+    const double fl = (double)lane;
 
     if (status == MP_STATUS_OK) {
         if (CURVES && lane == 0) {
@@ -282,8 +415,7 @@ __global__ __launch_bounds__(64) void lnprob_kernel(const DevShared sh, const La
 
             // ---------------- Mdisc: exponential step + affine scan
             const double S1 = mdot_fb(w, tm), S2 = mdot_fb(w, tb);
-            double S0 = __shfl_up(S2, 1, 64);
-            if (lane == 0) S0 = S_s;
+            const double S0 = lane_prev(S2, S_s);
             const double c1 = -3.0 * S0 + 4.0 * S1 - S2, c2 = 2.0 * S0 - 4.0 * S1 + 2.0 * S2;
             const Phi qh = phi123(-0.5 * h * w.inv_tau);
             const Phi qf = phi_double(qh);
@@ -291,26 +423,22 @@ __global__ __launch_bounds__(64) void lnprob_kernel(const DevShared sh, const La
             double bM = active ? h * fma(S0, qf.p1, fma(c1, qf.p2, 2.0 * c2 * qf.p3)) : 0.0;
             const double a_half = qh.e;
             const double b_half = 0.5 * h * fma(S0, qh.p1, fma(0.5 * c1, qh.p2, 0.5 * c2 * qh.p3));
-            scan_affine(aM, bM, lane);
+            scan_affine(aM, bM);
             const double M1 = fma(aM, M_s, bM);          // Mdisc at this lane's step end
-            double M0 = __shfl_up(M1, 1, 64);
-            if (lane == 0) M0 = M_s;
+            const double M0 = lane_prev(M1, M_s);
             const double Mh = fma(a_half, M0, b_half);   // Mdisc at the step midpoint
-            const double md1 = M1 * w.inv_tau, mdh = Mh * w.inv_tau;
-            const double rm1 = alfven_radius(w, md1), rmh = alfven_radius(w, mdh);
-            double md0 = __shfl_up(md1, 1, 64), rm0 = __shfl_up(rm1, 1, 64);
-            if (lane == 0) { md0 = md_s; rm0 = rm_s; }
+            const DiscPt d1 = disc_point(sh, w, M1), dh = disc_point(sh, w, Mh);
+            const DiscPt d0 = disc_prev(d1, d_s);
 
-            // ---------------- omega: predictor (exponential Euler from the tile start) ...
+            // ---------------- omega: predictor = quadratic extrapolation of the last three grid values in the
+            // step index (the grid is logarithmic, so power laws are smooth in the index) ...
             double wg;
             {
-                double rot0, lam0;
-                const double f0 = omega_rhs<true>(sh, w, md_s, rm_s, om_s, rot0, lam0);
-                const double dt = ta - lane_bcast(ta, 0);
-                const Phi pp = phi123(dt * lam0);
-                wg = fma(dt * pp.p1, f0, om_s);
+                const double g1 = om_s - om_m1, g2 = (om_s - om_m1) - (om_m1 - om_m2);
+                wg = fma(fl, g1, fma(0.5 * fl * (fl + 1.0), g2, om_s));
+                if (!(wg > 0.0)) wg = om_s;
             }
-            // ... and Newton-type sweeps of the linearised step maps
+            // ... then Newton-type sweeps of the linearised step maps
             double w1 = om_s;        // omega at this lane's step end
             double rmax = 0.0;
             int sweep = 0;
@@ -318,26 +446,25 @@ __global__ __launch_bounds__(64) void lnprob_kernel(const DevShared sh, const La
             while (!done) {
                 ++sweep;
                 double r0, r2, r3, r4, lam, dummy;
-                const double f0 = omega_rhs<true>(sh, w, md0, rm0, wg, r0, lam);
+                const double f0 = omega_rhs<true>(sh, w, d0, wg, r0, lam);
                 const Phi ph = phi123(0.5 * h * lam);
                 const Phi pf = phi_double(ph);
                 const double N0 = fma(-lam, wg, f0);
                 const double U2 = fma(ph.e, wg, 0.5 * h * ph.p1 * N0);
-                const double N2 = fma(-lam, U2, omega_rhs<false>(sh, w, mdh, rmh, U2, r2, dummy));
+                const double N2 = fma(-lam, U2, omega_rhs<false>(sh, w, dh, U2, r2, dummy));
                 const double U3 = fma(ph.e, wg, fma(0.5 * h * (ph.p1 - 2.0 * ph.p2), N0, h * ph.p2 * N2));
-                const double N3 = fma(-lam, U3, omega_rhs<false>(sh, w, mdh, rmh, U3, r3, dummy));
+                const double N3 = fma(-lam, U3, omega_rhs<false>(sh, w, dh, U3, r3, dummy));
                 const double U4 = fma(pf.e, wg, fma(h * (pf.p1 - 2.0 * pf.p2), N0, 2.0 * h * pf.p2 * N3));
-                const double N4 = fma(-lam, U4, omega_rhs<false>(sh, w, md1, rm1, U4, r4, dummy));
+                const double N4 = fma(-lam, U4, omega_rhs<false>(sh, w, d1, U4, r4, dummy));
                 const double v = fma(pf.e, wg,
                                      h * fma(pf.p1 - 3.0 * pf.p2 + 4.0 * pf.p3, N0,
                                              fma(2.0 * pf.p2 - 4.0 * pf.p3, N2 + N3, (4.0 * pf.p3 - pf.p2) * N4)));
                 // linearised step map about the current guess: omega_end = e^{h lam} (omega_start - wg) + v
                 double aW = active ? pf.e : 1.0;
                 double bW = active ? fma(-pf.e, wg, v) : 0.0;
-                scan_affine(aW, bW, lane);
+                scan_affine(aW, bW);
                 w1 = fma(aW, om_s, bW);
-                double wn = __shfl_up(w1, 1, 64);
-                if (lane == 0) wn = om_s;
+                const double wn = lane_prev(w1, om_s);
                 const double delta = fabs(wn - wg);
                 const bool ok = delta <= kSweepTol * fabs(wn);   // false for NaN
                 rmax = fmax(fmax(r0, r2), fmax(r3, r4));        // fmax drops NaN like the oracle's `>` test
@@ -360,7 +487,7 @@ __global__ __launch_bounds__(64) void lnprob_kernel(const DevShared sh, const La
 
             // ---------------- luminosity at the step ends, light curve through LDS, chi^2
             double Lt, Lp, Ld;
-            luminosity(sh, w, md1, rm1, w1, Lt, Lp, Ld);
+            luminosity(sh, w, d1, w1, Lt, Lp, Ld);
             if (CURVES && active) {
                 const size_t o = row + (size_t)i + 1;
                 if (a.ltot) a.ltot[o] = Lt / 1.0e50;
@@ -389,12 +516,14 @@ __global__ __launch_bounds__(64) void lnprob_kernel(const DevShared sh, const La
             }
 
             // ---------------- carry the tile end to the next tile
-            const int last = (nsteps - tile * kTile) >= kTile ? kTile - 1 : (nsteps - tile * kTile - 1);
+            const int nact = nsteps - tile * kTile;              // active steps in this tile (>= 1)
+            const int last = nact >= kTile ? kTile - 1 : nact - 1;
+            om_m2 = last >= 2 ? lane_bcast(w1, last - 2) : (last == 1 ? om_s : om_m1);
+            om_m1 = last >= 1 ? lane_bcast(w1, last - 1) : om_s;
             M_s = lane_bcast(M1, last);
             om_s = lane_bcast(w1, last);
             S_s = lane_bcast(S2, last);
-            md_s = lane_bcast(md1, last);
-            rm_s = lane_bcast(rm1, last);
+            d_s = disc_bcast(d1, last);
             L_s = lane_bcast(Lt, last);
         }
         if (status == MP_STATUS_OK) {

@@ -1,0 +1,61 @@
+"""Batched, device-resident log-posterior callables (the emcee ``log_prob_fn`` drop-in).
+
+``LogProb`` binds a model variant, one or more observed light curves and the prior to a GPU once, and
+is then called with ``(n_walkers, ndim)`` arrays (``emcee.EnsembleSampler(..., vectorize=True)``) or a
+single parameter vector.  ``lnprob_device`` works on torch tensors already resident in HBM.
+"""
+import numpy as np
+
+from . import _capi, engine, synth
+
+
+class LogProb:
+    def __init__(self, x, y, yerr, variant="synth", GRBtype=None, lower="default", upper="default", log_mask=None,
+                 device=-1, fbad=None):
+        if variant == "synth":
+            cfg = _capi.cfg_synth()
+            lo, hi, mask = synth.PRIOR_LOWER, synth.PRIOR_UPPER, synth.LOG_MASK
+        elif variant == "lib":
+            from . import mcmc_eqns
+            cfg = _capi.cfg_lib()
+            lo, hi = mcmc_eqns._bounds(6)
+            mask = mcmc_eqns.LIB_LOG_MASK
+        else:
+            raise ValueError("variant must be 'synth' or 'lib'")
+        if not isinstance(lower, str):
+            lo, hi = lower, upper
+        if log_mask is not None:
+            mask = log_mask
+        # a private handle: the prior and datasets of this object are never swapped out by other callers
+        self.handle = _capi.Handle(cfg, engine.grid(GRBtype), device)
+        self.handle.set_prior(lo, hi, mask)
+        self.n_datasets = 0
+        self.add_dataset(x, y, yerr)
+        self.fbad = fbad
+
+    def add_dataset(self, x, y, yerr):
+        """Register a further light curve (mixed lengths allowed); returns its ds_id."""
+        slot = self.n_datasets
+        self.handle.set_dataset(slot, x, y, yerr)
+        self.n_datasets += 1
+        return slot
+
+    def __call__(self, pars, ds_id=None):
+        p = np.asarray(pars, dtype=np.float64)
+        if p.ndim == 1:
+            return float(self.handle.lnprob_batch(p[None, :], ds_id=ds_id)[0])
+        return self.handle.lnprob_batch(p, ds_id=ds_id)
+
+    def lnprob_device(self, pars, out=None, ds_id=None, status=None):
+        """pars: contiguous float64 CUDA tensor (n, ndim) on this handle's device.  Asynchronous on torch's
+        current stream; returns the lnprob tensor."""
+        import torch
+        assert pars.is_cuda and pars.dtype == torch.float64 and pars.is_contiguous()
+        n, nd = pars.shape
+        if out is None:
+            out = torch.empty(n, dtype=torch.float64, device=pars.device)
+        stream = torch.cuda.current_stream(pars.device).cuda_stream
+        self.handle.lnprob_batch_dev(pars.data_ptr(), n, nd, out.data_ptr(),
+                                     d_ds_id=ds_id.data_ptr() if ds_id is not None else 0,
+                                     d_status=status.data_ptr() if status is not None else 0, stream=stream)
+        return out

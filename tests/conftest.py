@@ -1,0 +1,59 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+TYPES = ("Humped", "Classic", "Sloped", "Stuttering")
+CANON = {  # generate_data.py:10-15 parameter sets (physical units)
+    "Humped": [1.0, 5.0, 1.0e-3, 100.0, 0.1, 1.0],
+    "Classic": [1.0, 5.0, 1.0e-3, 1000.0, 0.1, 1.0],
+    "Sloped": [1.0, 1.0, 1.0e-3, 100.0, 10.0, 10.0],
+    "Stuttering": [1.0, 5.0, 1.0e-5, 100.0, 0.1, 100.0],
+}
+TRUTHS = {  # synth_mcmc.py:16-21 (sampler coordinates)
+    "Humped": [1.0, 5.0, -3.0, 2.0, -1.0, 0.0],
+    "Classic": [1.0, 5.0, -3.0, 3.0, -1.0, 0.0],
+    "Sloped": [1.0, 1.0, -3.0, 2.0, 1.0, 1.0],
+    "Stuttering": [1.0, 5.0, -5.0, 2.0, -1.0, 2.0],
+}
+
+# |lnprob - reference| tolerances.  The reference integrates with LSODA at
+# rtol = atol ~ 1.5e-8 and its own lnprob carries up to 1.4e-5 relative integrator noise; against the
+# same reference code run with a tight integrator (rtol = atol = 1e-12) the agreement is <= 8e-9 relative (median 2e-12).
+REF_ATOL, REF_RTOL = 1.0e-5, 2.0e-5
+TIGHT_ATOL, TIGHT_RTOL = 1.0e-7, 2.0e-8
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def gsynth():
+    return np.load(os.path.join(GOLDEN, "golden_synth.npz"))
+
+
+@pytest.fixture(scope="session")
+def glib():
+    return np.load(os.path.join(GOLDEN, "golden_lib.npz"))
+
+
+@pytest.fixture(scope="session")
+def gflag():
+    return np.load(os.path.join(GOLDEN, "golden_flagscan.npz"))
+
+
+@pytest.fixture(scope="session")
+def tarr():
+    return np.logspace(0.0, 6.0, num=10001, base=10.0)
+
+
+@pytest.fixture(scope="session")
+def tarr_S():
+    return np.logspace(-3.0, 6.0, num=10001, base=10.0)

@@ -1,0 +1,101 @@
+"""CPU-side checks of the C ABI library and the host logic (no GPU compute)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from magprop_amd import _capi, engine, mcmc_eqns, synth
+
+
+def _declared_functions():
+    hdr = open(os.path.join(ROOT, "include", "magprop_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(mp_[a-z_0-9]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = _capi.lib()
+    names = _declared_functions()
+    assert len(names) >= 14
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/magprop_amd.h but not exported"
+    assert set(names) == set(_capi.EXPORTS)
+    assert L.mp_abi_version() == 1
+
+
+def test_cfg_struct_layout_and_presets():
+    assert ctypes.sizeof(_capi.ModelCfg) == 11 * 8 + 2 * 4
+    s, l = _capi.cfg_synth(), _capi.cfg_lib()
+    assert (s.inertia_factor, s.rm_massflow_factor, s.n_ode, s.n_lum, s.nacc_lum_threshold, s.lprop_gm_term) == \
+        (0.35, 3.0, 10.0, 10.0, 0.27, 1)
+    assert (l.inertia_factor, l.rm_massflow_factor, l.n_ode, l.dipeff, l.propeff, l.nacc_lum_threshold,
+            l.lprop_gm_term) == (0.8, 1.0, 1.0, 0.05, 0.4, 0.0, 0)
+
+
+def test_no_silent_cpu_fallback():
+    """Without a GPU the product path must fail loudly (there is no CPU fallback)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    with pytest.raises(_capi.MagpropAmdError, match="no HIP device"):
+        _capi.Handle(_capi.cfg_synth(), engine.grid(None))
+
+
+def test_create_argument_validation():
+    L = _capi.lib()
+    t = np.array([1.0, 1.0, 2.0])
+    assert not L.mp_create(ctypes.byref(_capi.cfg_synth()), t.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), 3, 0)
+    assert "strictly increasing" in _capi.last_error()
+    assert not L.mp_create(None, None, 0, 0)
+
+
+def test_product_never_imports_oracle():
+    """The product package must not reference oracle/ in any way."""
+    pkg = os.path.join(ROOT, "magprop_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src and "libmp_oracle" not in src, f
+                assert "scipy.integrate" not in src and "odeint(" not in src, f
+
+
+def test_grid_selection_matches_reference():
+    assert np.array_equal(engine.grid(None), np.logspace(0.0, 6.0, num=10001, base=10.0))
+    assert np.array_equal(engine.grid("L"), engine.grid(None))
+    assert np.array_equal(engine.grid("S"), np.logspace(-3.0, 6.0, num=10001, base=10.0))
+    with pytest.raises(ValueError, match="valid value for GRBtype"):
+        engine.grid("X")
+
+
+def test_synth_lnprior(gsynth):
+    assert np.array_equal(synth.PRIOR_LOWER, gsynth["prior_lower"])
+    assert np.array_equal(synth.PRIOR_UPPER, gsynth["prior_upper"])
+    assert synth.lnprior([1, 5, -3, 2, -1, 0]) == 0.0
+    assert synth.lnprior([1, 5, -3, 2, -1, 3.5]) == -np.inf
+    assert synth.lnprior(synth.PRIOR_LOWER) == 0.0 and synth.lnprior(synth.PRIOR_UPPER) == 0.0  # inclusive
+    out = synth.lnprior(np.array([[1, 5, -3, 2, -1, 0], [11, 5, -3, 2, -1, 0]]))
+    assert out.tolist() == [0.0, -np.inf]
+
+
+def test_lib_lnprior_matches_reference(glib):
+    """magnetar/mcmc_eqns.py:40-84 incl. the 7-parameter special case, on golden cases."""
+    assert np.array_equal(mcmc_eqns._read_limits(mcmc_eqns._LIMITS_CSV)[0], glib["limits_lower"])
+    assert np.array_equal(mcmc_eqns._read_limits(mcmc_eqns._LIMITS_CSV)[1], glib["limits_upper"])
+    for row, ref in zip(glib["lnprior_pars"], glib["lnprior"]):
+        p = row[~np.isnan(row)]
+        assert mcmc_eqns.lnprior(p) == ref
+
+
+def test_lib_lnprior_custom_limits(tmp_path):
+    p = tmp_path / "lims.csv"
+    p.write_text("pars,lower,upper\nB,0,1\nP,0,1\na,0,1\nb,0,1\nc,0,1\nd,0,1\ne,0,1\nf,0,1\ng,5,6\n")
+    assert mcmc_eqns.lnprior([0.5] * 6, custom_lims=str(p)) == 0.0
+    assert mcmc_eqns.lnprior([0.5] * 5 + [2.0], custom_lims=str(p)) == -np.inf
+    assert mcmc_eqns.lnprior([0.5] * 6 + [5.5], custom_lims=str(p)) == 0.0      # 7th -> last row
+    assert mcmc_eqns.lnprior([0.5] * 6 + [0.5], custom_lims=str(p)) == -np.inf
+    with pytest.raises(ValueError, match="valid file path"):
+        mcmc_eqns.lnprior([0.5] * 6, custom_lims=str(tmp_path / "missing.csv"))

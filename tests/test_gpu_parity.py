@@ -1,0 +1,309 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI, against
+  (1) the C oracle on the same seeded inputs (tight: same deterministic scheme),
+  (2) the golden vectors captured from the real reference (loose: LSODA noise; tight-LSODA values),
+  (3) size-independent properties at BASELINE.json's full sizes.
+Tolerances are written next to each comparison; DESIGN.md section 5 explains them.
+"""
+import numpy as np
+import pytest
+
+from conftest import CANON, REF_ATOL, REF_RTOL, TIGHT_ATOL, TIGHT_RTOL, TRUTHS, TYPES
+
+pytestmark = pytest.mark.gpu
+
+GPU_VS_C_RTOL = 1e-10   # HIP kernel vs serial C oracle: same scheme, different evaluation order / algebra
+LOG_MASK = 0b111100
+
+
+@pytest.fixture(scope="module")
+def mpa():
+    import magprop_amd
+    return magprop_amd
+
+
+@pytest.fixture(scope="module")
+def co():
+    from oracle import c_oracle
+    return c_oracle
+
+
+@pytest.fixture(scope="module")
+def synth_handle(mpa, tarr, gsynth):
+    from magprop_amd import _capi, synth
+    h = _capi.Handle(_capi.cfg_synth(), tarr)
+    for k, name in enumerate(TYPES):
+        h.set_dataset(k, gsynth[name + "_x"], gsynth[name + "_y"], gsynth[name + "_yerr"])
+    h.set_prior(synth.PRIOR_LOWER, synth.PRIOR_UPPER, synth.LOG_MASK)
+    yield h
+    h.close()
+
+
+def test_native_library_is_loaded(mpa):
+    """The tests below run the HIP extension, not a fallback: the in-tree .so is mapped into this process."""
+    from magprop_amd import _capi
+    _capi.lib()
+    maps = open("/proc/self/maps").read()
+    assert "magprop_amd/libmagprop_amd.so" in maps
+
+
+@pytest.mark.parametrize("k,name", list(enumerate(TYPES)))
+def test_lnprob_vs_c_oracle_and_reference(synth_handle, co, gsynth, tarr, k, name):
+    x, y, yerr = gsynth[name + "_x"], gsynth[name + "_y"], gsynth[name + "_yerr"]
+    P = gsynth[name + "_pars"]
+    out, st = synth_handle.lnprob_batch(P, ds_id=k, want_status=True)
+    ref_c, st_c = co.lnprob_batch(co.cfg_synth(), P, tarr, x, y, yerr, gsynth["prior_lower"], gsynth["prior_upper"],
+                                  LOG_MASK)
+    assert np.array_equal(st, st_c)
+    ok = np.isfinite(ref_c)
+    assert np.array_equal(np.isfinite(out), ok)
+    assert np.all(out[~ok] == -np.inf)
+    assert np.all(np.abs(out[ok] - ref_c[ok]) <= GPU_VS_C_RTOL * np.abs(ref_c[ok]))
+    # reference itself (default LSODA), and the same reference code with a tight integrator
+    ref, rst = gsynth[name + "_lnprob"], gsynth[name + "_status"]
+    assert np.array_equal(st, rst)
+    assert np.all(np.abs(out[ok] - ref[ok]) <= REF_ATOL + REF_RTOL * np.abs(ref[ok]))
+    tight = gsynth[name + "_lnprob_tight"]
+    assert np.all(np.abs(out[ok] - tight[ok]) <= TIGHT_ATOL + TIGHT_RTOL * np.abs(tight[ok]))
+
+
+def test_known_answer(mpa, gsynth):
+    """SURVEY.md 8(c) posterior known answers through the reference-shaped front end."""
+    x, y, yerr = gsynth["Humped_x"], gsynth["Humped_y"], gsynth["Humped_yerr"]
+    assert abs(mpa.synth.lnprob([1, 5, -3, 2, -1, 0.0], x, y, yerr, None) - (-33.89800480033379)) < 1e-5
+    assert mpa.synth.lnprob([1, 5, -3, 2, -1, 3.5], x, y, yerr, None) == -np.inf
+    assert mpa.synth.lnprob([1.8171068, 3.68147895, -2.61786801, 1.99840102, -0.33083576, 2.95613803],
+                            x, y, yerr, None) == -np.inf
+
+
+def test_flag_scan(synth_handle, gflag):
+    """1500 prior-wide points: the failure rule agrees with LSODA's 'flag' everywhere; values within tolerance."""
+    out, st = synth_handle.lnprob_batch(gflag["pars"], ds_id=0, want_status=True)
+    rst = gflag["status"]
+    assert np.array_equal(st, rst)
+    ok = rst == 0
+    ref = gflag["lnprob"]
+    assert np.all(np.abs(out[ok] - ref[ok]) <= REF_ATOL + REF_RTOL * np.abs(ref[ok]))
+    tight = gflag["lnprob_tight"]
+    m = ok & np.isfinite(tight)
+    assert np.all(np.abs(out[m] - tight[m]) <= TIGHT_ATOL + TIGHT_RTOL * np.abs(tight[m]))
+    assert 2.0 <= synth_handle.last_mean_sweeps <= 6.0
+
+
+@pytest.mark.parametrize("name", TYPES)
+def test_model_lum_curves(mpa, co, gsynth, tarr, name):
+    out = mpa.model_lum(CANON[name])
+    assert out.shape == (4, 10001)
+    st, ref_c, traj_c = co.model_lc(co.cfg_synth(), CANON[name], tarr, want_traj=True)
+    assert np.array_equal(out[0], tarr)
+    scale = np.max(ref_c[1])
+    for r in (1, 2, 3):   # Lprop is a difference of two large terms: absolute floor relative to the curve's scale
+        err = np.abs(out[r] - ref_c[r]) / (1e-9 * np.abs(ref_c[r]) + 1e-13 * scale)
+        assert np.all(err <= 1.0), (r, int(np.argmax(err)), float(np.max(err)))
+    d = int(gsynth["decim"])
+    ref = gsynth[name + "_lc"]
+    for r in (1, 2, 3):
+        assert np.all(np.abs(out[r, ::d] - ref[r]) <= 1e-12 + 5e-6 * np.abs(ref[r]))   # LSODA noise ~1e-6
+    # trajectory against the reference RHS at rtol=atol=1e-12
+    from magprop_amd import _capi, engine
+    st, _, traj = engine.engine(_capi.cfg_synth()).handle.model_lc(CANON[name], want_traj=True)
+    tt = gsynth[name + "_traj_tight"]
+    assert np.max(np.abs(traj[0, ::d] / tt[0] - 1.0)) < 5e-10
+    assert np.max(np.abs(traj[1, ::d] / tt[1] - 1.0)) < 1e-10
+    assert np.max(np.abs(traj[0] / traj_c[0] - 1.0)) < 1e-12 and np.max(np.abs(traj[1] / traj_c[1] - 1.0)) < 1e-11
+
+
+def test_model_lum_xdata_and_flag(mpa, gsynth):
+    x = gsynth["Humped_x"]
+    full = mpa.model_lum(CANON["Humped"])
+    at = mpa.model_lum(CANON["Humped"], xdata=x)
+    assert np.allclose(at, full[1, gsynth["Humped_inx"]], rtol=1e-12, atol=0)
+    p = np.array([1.8171068, 3.68147895, 10 ** -2.61786801, 10 ** 1.99840102, 10 ** -0.33083576, 10 ** 2.95613803])
+    assert mpa.model_lum(p) == "flag"
+    with pytest.raises(ValueError, match="interpolation range"):
+        mpa.model_lum(CANON["Humped"], xdata=np.array([0.5]))
+    with pytest.raises(ValueError, match="interpolation range"):
+        mpa.model_lum(CANON["Humped"], xdata=np.array([2.0e6]))
+
+
+def test_wide_light_curves(mpa, gsynth):
+    d = int(gsynth["decim"])
+    for p, ref in zip(gsynth["wide_pars_physical"], gsynth["wide_lc"]):
+        out = mpa.model_lum(p)
+        assert np.all(np.abs(out[1:, ::d] - ref) <= 1e-12 + 2e-5 * np.abs(ref))
+
+
+# ---------------------------------------------------------------- library variant
+def test_lib_intree_fixtures(mpa, glib):
+    """The reference's own fixtures (tests/test_funcs.py:28-63) with its own tolerance (np.isclose defaults)."""
+    out = mpa.model_lc(glib["intree_lc_pars"])
+    fx = glib["intree_lc"]
+    assert np.isclose(out[0, ::20], fx[3]).all()
+    assert np.isclose(out[3, ::20], fx[0]).all() and np.isclose(out[2, ::20], fx[1]).all()
+    assert np.isclose(out[1, ::20], fx[2]).all()
+    from magprop_amd import _capi, engine
+    st, _, traj = engine.engine(_capi.cfg_lib()).handle.model_lc(glib["intree_odes_pars"], want_traj=True)
+    fo = glib["intree_odes"]
+    assert st == 0 and np.isclose(traj[0, ::20], fo[0]).all() and np.isclose(traj[1, ::20], fo[1]).all()
+    assert np.array_equal(mpa.init_conds(0.001, 1.0), np.array([0.001 * 1.99e33, (2.0 * np.pi) / 1.0e-3]))
+
+
+@pytest.mark.parametrize("kind", ["L", "S"])
+def test_lib_light_curves_and_keywords(mpa, glib, kind):
+    p = glib["intree_lc_pars"]
+    out = mpa.model_lc(p, GRBtype=kind)
+    ref = glib["lc_" + kind]
+    assert np.array_equal(out[0, ::50], ref[0])
+    assert np.all(np.abs(out[1:, ::50] - ref[1:]) <= 1e-14 + 2e-6 * np.abs(ref[1:]))
+    if kind == "L":
+        assert np.array_equal(mpa.model_lc(p), out)
+        o2 = mpa.model_lc(p, GRBtype="L", n=10.0, dipeff=1.0, propeff=1.0)
+        assert np.all(np.abs(o2[1:, ::50] - glib["lc_L_n10_dip1_prop1"][1:]) <= 1e-14 + 2e-6 * np.abs(o2[1:, ::50]))
+        o3 = mpa.model_lc(p, GRBtype="L", f_beam=25.0, dipeff=0.3, propeff=0.7)
+        assert np.all(np.abs(o3[1:, ::50] - glib["lc_L_fbeam"][1:]) <= 1e-14 + 2e-6 * np.abs(o3[1:, ::50]))
+    with pytest.raises(ValueError, match="valid value for GRBtype"):
+        mpa.model_lc(p, GRBtype="X")
+
+
+@pytest.mark.parametrize("kind", ["L", "S"])
+def test_lib_lnlike_6_to_9_parameters(mpa, glib, kind):
+    import pandas as pd
+    x, y, yerr = glib["ds_" + kind]
+    data = pd.DataFrame({"t": x, "Lum50": y, "Lum50err": yerr})
+    rows = glib[f"lnlike_{kind}_pars"]
+    for row, ref in zip(rows, glib[f"lnlike_{kind}"]):
+        p = row[~np.isnan(row)]
+        ll = mpa.lnlike(p, data, kind)
+        assert abs(ll - ref) <= REF_ATOL + REF_RTOL * abs(ref), (p, ll, ref)
+    # batched form, one launch per ndim
+    for nd in (6, 7, 8, 9):
+        sel = [i for i, r in enumerate(rows) if (~np.isnan(r)).sum() == nd]
+        P = rows[sel][:, :nd]
+        out = mpa.lnlike(P, data, kind)
+        assert np.all(np.abs(out - glib[f"lnlike_{kind}"][sel]) <= REF_ATOL + REF_RTOL * np.abs(out))
+
+
+def test_lib_lnprob_intent(mpa, glib):
+    """lnprob = box prior in log space + un-logged likelihood."""
+    import pandas as pd
+    x, y, yerr = glib["ds_L"]
+    data = pd.DataFrame({"t": x, "Lum50": y, "Lum50err": yerr})
+    p_log = np.array([1.0, 5.0, -2.5, 2.0, 0.0, 0.0])
+    p_phys = p_log.copy()
+    p_phys[2:] = 10.0 ** p_phys[2:]
+    assert mpa.lnprob(p_log, data, "L") == pytest.approx(mpa.lnlike(p_phys, data, "L"), rel=1e-12)
+    assert mpa.lnprob([1.0, 5.0, -3.5, 2.0, 0.0, 0.0], data, "L") == -np.inf
+    assert mpa.lnprob([1.0, 5.0, -2.5, 2.0, 0.0, 0.0, 700.0], data, "L") == -np.inf     # f_beam above 600
+
+
+# ---------------------------------------------------------------- batching, datasets, edges
+def test_mixed_datasets_and_lengths(mpa, co, gsynth, tarr):
+    """Config 5: several light curves of different lengths in one launch, selected per walker."""
+    from magprop_amd import LogProb
+    rng = np.random.default_rng(7)
+    lens = [1, 8, 50, 63, 64, 65, 410, 1944]
+    sets = []
+    base = mpa.model_lum(CANON["Humped"])
+    for n in lens:
+        x = np.sort(10.0 ** rng.uniform(0.0, 6.0, n))
+        x[0] = max(x[0], 1.0)
+        if n >= 8:
+            x[0], x[-1] = tarr[0], tarr[-1]          # exactly on the first / last knot
+        y0 = np.interp(x, tarr, base[1])
+        yerr = 0.25 * y0
+        sets.append((x, y0 + rng.normal(0, yerr), yerr))
+    lp_ = LogProb(*sets[0])
+    for s in sets[1:]:
+        lp_.add_dataset(*s)
+    nw = 96
+    P = np.array(TRUTHS["Humped"]) + 0.02 * rng.standard_normal((nw, 6))
+    ids = rng.integers(0, len(lens), nw).astype(np.int32)
+    out = lp_(P, ds_id=ids)
+    for i in range(nw):
+        x, y, yerr = sets[ids[i]]
+        ref, _ = co.lnprob_batch(co.cfg_synth(), P[i], tarr, x, y, yerr, gsynth["prior_lower"],
+                                 gsynth["prior_upper"], LOG_MASK)
+        assert abs(out[i] - ref[0]) <= GPU_VS_C_RTOL * abs(ref[0]) * 10, (i, ids[i], out[i], ref[0])
+    # scalar call and default dataset
+    assert lp_(P[0]) == pytest.approx(lp_(P[:1], ds_id=np.zeros(1, np.int32))[0], rel=0, abs=0)
+    with pytest.raises(ValueError):
+        lp_(P, ds_id=np.full(nw, 40, np.int32))     # unset dataset
+
+
+def test_edge_cases(mpa, synth_handle, gsynth):
+    from magprop_amd import _capi
+    out = synth_handle.lnprob_batch(np.empty((0, 6)), ds_id=0)
+    assert out.shape == (0,)
+    one = synth_handle.lnprob_batch(np.array([TRUTHS["Humped"]]), ds_id=0)
+    assert one.shape == (1,) and np.isfinite(one[0])
+    with pytest.raises(ValueError):
+        synth_handle.lnprob_batch(np.zeros((4, 5)), ds_id=0)                       # ndim < 6
+    with pytest.raises(ValueError, match="interpolation range"):
+        synth_handle.set_dataset(9, [0.5, 2.0], [1.0, 1.0], [0.1, 0.1])            # x below the grid
+    with pytest.raises(ValueError, match="interpolation range"):
+        synth_handle.set_dataset(9, [2.0, 1.0e6 * (1 + 1e-12)], [1.0, 1.0], [0.1, 0.1])
+    # NaN / inf parameters: outside the prior, never NaN out
+    bad = np.array([TRUTHS["Humped"]] * 3)
+    bad[0, 0] = np.nan
+    bad[1, 3] = np.inf
+    bad[2, 5] = -np.inf
+    out, st = synth_handle.lnprob_batch(bad, ds_id=0, want_status=True)
+    assert np.all(out == -np.inf) and np.all(st == _capi.STATUS_PRIOR)
+
+
+def test_fbad_file(mpa, gsynth, tmp_path):
+    x, y, yerr = gsynth["Humped_x"], gsynth["Humped_y"], gsynth["Humped_yerr"]
+    f = tmp_path / "bad.csv"
+    P = np.array([[1, 5, -3, 2, -1, 0.0], [1.8171068, 3.68147895, -2.61786801, 1.99840102, -0.33083576, 2.95613803],
+                  [1, 5, -3, 2, -1, 3.5]])
+    out = mpa.synth.lnprob(P, x, y, yerr, str(f))
+    assert np.isfinite(out[0]) and out[1] == -np.inf and out[2] == -np.inf
+    lines = f.read_text().strip().splitlines()
+    assert len(lines) == 1 and lines[0].startswith("1.8171068, 3.68147895")    # only the flagged set (:72-79)
+
+
+# ---------------------------------------------------------------- full-size properties
+@pytest.mark.parametrize("name,nwalk", [("Humped", 1024), ("Classic", 4096), ("Humped", 8192)])
+def test_full_size_properties(synth_handle, gsynth, name, nwalk):
+    """BASELINE.json configs 2-4 sizes: permutation / batch-split invariance and chi^2 scaling laws."""
+    k = TYPES.index(name)
+    rng = np.random.default_rng(nwalk)
+    P = np.array(TRUTHS[name]) + 1.0e-4 * rng.standard_normal((nwalk, 6))     # synth_mcmc.py:175-176
+    P[::97] = synth_handle_prior_sample(rng, len(P[::97]))                     # sprinkle prior-wide walkers
+    out = synth_handle.lnprob_batch(P, ds_id=k)
+    assert out.shape == (nwalk,) and not np.any(np.isnan(out))
+    perm = rng.permutation(nwalk)
+    assert np.array_equal(synth_handle.lnprob_batch(P[perm], ds_id=k), out[perm])          # bit-exact
+    half = nwalk // 2
+    split = np.concatenate([synth_handle.lnprob_batch(P[:half], ds_id=k), synth_handle.lnprob_batch(P[half:], ds_id=k)])
+    assert np.array_equal(split, out)                                                       # bit-exact
+    # chi^2 laws: errors x2 -> lnlike / 4 ; dataset duplicated -> lnlike x 2
+    x, y, yerr = gsynth[name + "_x"], gsynth[name + "_y"], gsynth[name + "_yerr"]
+    synth_handle.set_dataset(20, x, y, 2.0 * yerr)
+    synth_handle.set_dataset(21, np.tile(x, 2), np.tile(y, 2), np.tile(yerr, 2))
+    sub = P[:256]
+    base = out[:256]
+    fin = np.isfinite(base)
+    assert np.allclose(synth_handle.lnprob_batch(sub, ds_id=20)[fin], base[fin] / 4.0, rtol=1e-13, atol=0)
+    assert np.allclose(synth_handle.lnprob_batch(sub, ds_id=21)[fin], base[fin] * 2.0, rtol=1e-13, atol=0)
+
+
+def synth_handle_prior_sample(rng, n):
+    from magprop_amd import synth
+    return synth.PRIOR_LOWER + (synth.PRIOR_UPPER - synth.PRIOR_LOWER) * rng.random((n, 6))
+
+
+def test_device_pointer_entry_matches_host_entry(gsynth):
+    """mp_lnprob_batch_dev on torch tensors resident in HBM == host-buffer entry, bit for bit."""
+    import torch
+    from magprop_amd import LogProb
+    x, y, yerr = gsynth["Humped_x"], gsynth["Humped_y"], gsynth["Humped_yerr"]
+    lp_ = LogProb(x, y, yerr, device=0)
+    rng = np.random.default_rng(3)
+    P = np.array(TRUTHS["Humped"]) + 1e-3 * rng.standard_normal((512, 6))
+    host = lp_(P)
+    tp = torch.from_numpy(P).to("cuda:0")
+    st = torch.empty(512, dtype=torch.int32, device="cuda:0")
+    dev = lp_.lnprob_device(tp, status=st)
+    torch.cuda.synchronize()
+    assert np.array_equal(dev.cpu().numpy(), host)
+    assert int(st.sum()) == 0

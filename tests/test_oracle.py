@@ -1,0 +1,197 @@
+"""Pin the oracle (CPU checker) against golden vectors captured from the real reference.
+
+oracle/mp_oracle.c  — serial C restatement with the deterministic exponential scheme.
+oracle/lsoda_port.py — scipy.odeint restatement with the reference's own integrator.
+Golden data: tests/golden/*.npz, produced by tests/golden/make_golden.py (imports the reference).
+"""
+import numpy as np
+import pytest
+
+from conftest import CANON, REF_ATOL, REF_RTOL, TIGHT_ATOL, TIGHT_RTOL, TYPES
+from oracle import c_oracle as co
+from oracle import lsoda_port as lp
+
+LOG_MASK = 0b111100
+
+
+@pytest.fixture(scope="module")
+def cfg():
+    return co.cfg_synth()
+
+
+def test_grid_matches_reference(gsynth, tarr):
+    assert np.array_equal(gsynth["tarr_first_last"], tarr[[0, 1, -2, -1]])
+    assert np.array_equal(lp.grid("L"), tarr)
+
+
+@pytest.mark.parametrize("name", TYPES)
+def test_c_oracle_lnprob_vs_reference(gsynth, tarr, cfg, name):
+    x, y, yerr = gsynth[name + "_x"], gsynth[name + "_y"], gsynth[name + "_yerr"]
+    P, ref, rst = gsynth[name + "_pars"], gsynth[name + "_lnprob"], gsynth[name + "_status"]
+    out, st = co.lnprob_batch(cfg, P, tarr, x, y, yerr, gsynth["prior_lower"], gsynth["prior_upper"], LOG_MASK)
+    assert np.array_equal(st, rst)                       # ok / flag / prior agree everywhere
+    assert np.array_equal(np.isfinite(out), np.isfinite(ref))
+    ok = np.isfinite(ref)
+    assert np.all(np.abs(out[ok] - ref[ok]) <= REF_ATOL + REF_RTOL * np.abs(ref[ok]))
+    tight = gsynth[name + "_lnprob_tight"]
+    assert np.all(np.abs(out[ok] - tight[ok]) <= TIGHT_ATOL + TIGHT_RTOL * np.abs(tight[ok]))
+
+
+def test_known_answer_humped_truth(gsynth, tarr, cfg):
+    """lnprob(truth) = -33.89800480033379 on the seeded Humped dataset."""
+    x, y, yerr = gsynth["Humped_x"], gsynth["Humped_y"], gsynth["Humped_yerr"]
+    assert gsynth["Humped_inx"][:5].tolist() == [263, 768, 1717, 1787, 1986]
+    out, st = co.lnprob_batch(cfg, [[1, 5, -3, 2, -1, 0.0], [1, 5, -3, 2, -1, 3.5],
+                                    [1.8171068, 3.68147895, -2.61786801, 1.99840102, -0.33083576, 2.95613803]],
+                              tarr, x, y, yerr, gsynth["prior_lower"], gsynth["prior_upper"], LOG_MASK)
+    assert abs(out[0] - (-33.89800480033379)) < 1e-5
+    assert out[1] == -np.inf and st[1] == co.STATUS_PRIOR
+    assert out[2] == -np.inf and st[2] == co.STATUS_FLAG
+
+
+@pytest.mark.parametrize("name", TYPES)
+def test_c_oracle_trajectory_vs_tight_lsoda(gsynth, tarr, cfg, name):
+    """Scheme truncation error: (Mdisc, omega) against the reference RHS integrated at rtol=atol=1e-12."""
+    st, M, W = co.trajectory(cfg, CANON[name], tarr)
+    assert st == 0
+    tt = gsynth[name + "_traj_tight"]
+    d = int(gsynth["decim"])
+    assert np.max(np.abs(M[::d] / tt[0] - 1.0)) < 5e-10
+    assert np.max(np.abs(W[::d] / tt[1] - 1.0)) < 1e-10
+    # and against the reference's default-tolerance run, which is what its users see
+    td = gsynth[name + "_traj"]
+    assert np.max(np.abs(M[::d] / td[0] - 1.0)) < 5e-7
+    assert np.max(np.abs(W[::d] / td[1] - 1.0)) < 5e-7
+
+
+@pytest.mark.parametrize("name", TYPES)
+def test_c_oracle_light_curve_vs_reference(gsynth, tarr, cfg, name):
+    st, out = co.model_lc(cfg, CANON[name], tarr)
+    d = int(gsynth["decim"])
+    ref = gsynth[name + "_lc"]
+    assert np.array_equal(out[0, ::d], ref[0])
+    for row in (1, 2, 3):
+        a, b = out[row, ::d], ref[row]
+        assert np.all(np.abs(a - b) <= 1e-12 + 5e-6 * np.abs(b))
+
+
+def test_c_oracle_wide_light_curves(gsynth, tarr, cfg):
+    d = int(gsynth["decim"])
+    for p, ref in zip(gsynth["wide_pars_physical"], gsynth["wide_lc"]):
+        st, out = co.model_lc(cfg, p, tarr)
+        assert st == 0
+        assert np.all(np.abs(out[1:, ::d] - ref) <= 1e-12 + 2e-5 * np.abs(ref))
+
+
+def test_flag_rule_confusion_matrix(gsynth, gflag, tarr, cfg):
+    """The deterministic break-up rule reproduces LSODA's 'flag' on 1500 prior-wide points."""
+    x, y, yerr = gsynth["Humped_x"], gsynth["Humped_y"], gsynth["Humped_yerr"]
+    out, st = co.lnprob_batch(cfg, gflag["pars"], tarr, x, y, yerr, gsynth["prior_lower"], gsynth["prior_upper"],
+                              LOG_MASK)
+    rst = gflag["status"]
+    assert int(((rst == 1) & (st != 1)).sum()) == 0 and int(((rst == 0) & (st != 0)).sum()) == 0
+    assert (rst == 1).sum() >= 10
+    ok = rst == 0
+    ref = gflag["lnprob"]
+    assert np.all(np.abs(out[ok] - ref[ok]) <= REF_ATOL + REF_RTOL * np.abs(ref[ok]))
+    tight = gflag["lnprob_tight"]
+    m = ok & np.isfinite(tight)
+    assert m.sum() >= 300
+    assert np.all(np.abs(out[m] - tight[m]) <= TIGHT_ATOL + TIGHT_RTOL * np.abs(tight[m]))
+
+
+def test_scheme_converges_with_substeps(tarr, cfg, gsynth):
+    """A stiff prior-wide case (plain RK4 on the grid is 24 % off there): 1 vs 8 sub-steps agree."""
+    p = gsynth["Classic_pars"][55].copy()
+    p[2:] = 10.0 ** p[2:]
+    _, M1, W1 = co.trajectory(cfg, p, tarr, nsub=1)
+    _, M8, W8 = co.trajectory(cfg, p, tarr, nsub=8)
+    assert np.max(np.abs(W1 / W8 - 1.0)) < 1e-7
+    assert np.max(np.abs(M1 / M8 - 1.0)) < 1e-9
+
+
+# ---------------------------------------------------------------- library variant (magnetar/)
+def test_lib_intree_fixture_odes(glib, tarr):
+    """The reference's own test_odes_integrated_by_odeint fixture (tests/test_funcs.py:28-48), np.isclose defaults."""
+    fx = glib["intree_odes"]
+    st, M, W = co.trajectory(co.cfg_lib(), glib["intree_odes_pars"], tarr)
+    assert st == 0
+    assert np.allclose(tarr[::20], fx[2])
+    assert np.isclose(M[::20], fx[0]).all() and np.isclose(W[::20], fx[1]).all()
+
+
+def test_lib_intree_fixture_light_curve(glib, tarr):
+    """The reference's own test_model_light_curve fixture (tests/test_funcs.py:51-63), np.isclose defaults."""
+    fx = glib["intree_lc"]
+    st, out = co.model_lc(co.cfg_lib(), glib["intree_lc_pars"], tarr)
+    assert st == 0
+    assert np.isclose(out[3, ::20], fx[0]).all()      # Ldip
+    assert np.isclose(out[2, ::20], fx[1]).all()      # Lprop (identically zero in the lib variant)
+    assert np.isclose(out[1, ::20], fx[2]).all()      # Ltot
+    assert np.all(out[2] == 0.0)
+
+
+@pytest.mark.parametrize("kind", ["L", "S"])
+def test_lib_light_curves(glib, kind):
+    t = lp.grid(kind)
+    st, out = co.model_lc(co.cfg_lib(), glib["intree_lc_pars"], t)
+    ref = glib["lc_" + kind]
+    assert np.array_equal(out[0, ::50], ref[0])
+    assert np.all(np.abs(out[1:, ::50] - ref[1:]) <= 1e-14 + 2e-6 * np.abs(ref[1:]))
+
+
+def test_lib_keyword_variants(glib, tarr):
+    st, out = co.model_lc(co.cfg_lib(n_lum=10.0, dipeff=1.0, propeff=1.0), glib["intree_lc_pars"], tarr)
+    ref = glib["lc_L_n10_dip1_prop1"]
+    assert np.all(np.abs(out[1:, ::50] - ref[1:]) <= 1e-14 + 2e-6 * np.abs(ref[1:]))
+    st, out = co.model_lc(co.cfg_lib(f_beam=25.0, dipeff=0.3, propeff=0.7), glib["intree_lc_pars"], tarr)
+    ref = glib["lc_L_fbeam"]
+    assert np.all(np.abs(out[1:, ::50] - ref[1:]) <= 1e-14 + 2e-6 * np.abs(ref[1:]))
+
+
+@pytest.mark.parametrize("kind", ["L", "S"])
+def test_lib_lnlike_6_to_9_parameters(glib, kind):
+    t = lp.grid(kind)
+    x, y, yerr = glib["ds_" + kind]
+    for row, ref in zip(glib[f"lnlike_{kind}_pars"], glib[f"lnlike_{kind}"]):
+        p = row[~np.isnan(row)]
+        ll, st = co.lnlike(co.cfg_lib(), p, t, x, y, yerr)
+        assert st == 0
+        assert abs(ll - ref) <= REF_ATOL + REF_RTOL * abs(ref), (p, ll, ref)
+
+
+# ---------------------------------------------------------------- scipy/LSODA port
+@pytest.mark.parametrize("name", TYPES)
+def test_lsoda_port_matches_reference(gsynth, tarr, name):
+    """Same integrator, same formulas: agreement far below LSODA's own noise."""
+    x, y, yerr = gsynth[name + "_x"], gsynth[name + "_y"], gsynth[name + "_yerr"]
+    P, ref, rst = gsynth[name + "_pars"], gsynth[name + "_lnprob"], gsynth[name + "_status"]
+    sel = list(range(0, 8)) + list(range(36, 44)) + list(range(58, 64))
+    for i in sel:
+        v, st = lp.lnprob(P[i], tarr, x, y, yerr)
+        assert st == rst[i]
+        if np.isfinite(ref[i]):
+            assert abs(v - ref[i]) <= 1e-7 + 2e-6 * abs(ref[i])
+        else:
+            assert v == -np.inf
+
+
+def test_lsoda_port_work_counters(gsynth, tarr):
+    """LSODA does the same amount of work as in the reference (nst/nfe/nje within 2 %)."""
+    for name in TYPES:
+        _, info = lp.integrate(CANON[name], tarr)
+        got = np.array([info["nst"][-1], info["nfe"][-1], info["nje"][-1]], dtype=float)
+        ref = gsynth[name + "_lsoda_counts"].astype(float)
+        assert np.all(np.abs(got[:2] / ref[:2] - 1.0) < 0.02), (name, got, ref)
+
+
+def test_lsoda_port_lib_light_curve(glib, tarr):
+    out = lp.model(glib["intree_lc_pars"], tarr, v=lp.LIB)
+    assert np.all(np.abs(out[1:, ::50] - glib["lc_L"][1:]) <= 1e-14 + 1e-7 * np.abs(glib["lc_L"][1:]))
+
+
+def test_out_of_grid_times_raise(tarr):
+    with pytest.raises(ValueError):
+        lp.model(CANON["Humped"], tarr, xdata=np.array([0.5, 10.0]))
+    with pytest.raises(ValueError):
+        lp.grid("X")
