@@ -172,6 +172,18 @@ mp_handle *mp_create(const mp_model_cfg *cfg, const double *tgrid, int n_grid, i
             fail(MP_EINVAL, "mp_create: tgrid must be finite and strictly increasing (index %d)", i);
             return nullptr;
         }
+    // The integrator is built on a geometric grid (np.logspace), the only kind the reference uses
+    // (magnetar/funcs.py:132-137, code/synthetic_datasets/funcs.py:19).
+    const double q = std::exp(std::log(tgrid[n_grid - 1] / tgrid[0]) / (double)(n_grid - 1));
+    if (!(tgrid[0] > 0.0)) {
+        fail(MP_EINVAL, "mp_create: tgrid must be positive");
+        return nullptr;
+    }
+    for (int i = 1; i < n_grid; ++i)
+        if (std::fabs(tgrid[i] / (tgrid[i - 1] * q) - 1.0) > 1.0e-9) {
+            fail(MP_EINVAL, "mp_create: tgrid must be log-spaced (np.logspace); ratio breaks at index %d", i);
+            return nullptr;
+        }
     if (!(cfg->inertia_factor > 0) || !(cfg->alpha > 0) || !(cfg->cs7 > 0) || !(cfg->k > 0) ||
         !(cfg->rm_massflow_factor > 0)) {
         fail(MP_EINVAL, "mp_create: non-positive model constant in cfg");
@@ -221,6 +233,26 @@ mp_handle *mp_create(const mp_model_cfg *cfg, const double *tgrid, int n_grid, i
     s.sqrtGM = std::sqrt(s.GM);
     s.inv_sqrtGM = 1.0 / s.sqrtGM;
     s.sqrtR = std::sqrt(mp::kR);
+    s.q = q;
+    s.inv_q = 1.0 / q;
+    {   // exponential Adams-Moulton quadrature matrix for nodes t_{j+1}, t_j, t_{j-1}, t_{j-2}:
+        // W[k][m] = m! * [theta^m] l_k(theta), l_k the Lagrange basis on theta = 1, 0, -1/q, -(1/q + 1/q^2)
+        const double x[4] = {1.0, 0.0, -1.0 / q, -(1.0 / q + 1.0 / (q * q))};
+        const double fact[4] = {1.0, 1.0, 2.0, 6.0};
+        for (int k = 0; k < 4; ++k) {
+            double co[4] = {1.0, 0.0, 0.0, 0.0};
+            int deg = 0;
+            double denom = 1.0;
+            for (int j = 0; j < 4; ++j) {
+                if (j == k) continue;
+                for (int m = deg + 1; m >= 1; --m) co[m] = co[m - 1] - x[j] * co[m];
+                co[0] = -x[j] * co[0];
+                ++deg;
+                denom *= x[k] - x[j];
+            }
+            for (int m = 0; m < 4; ++m) s.eamW[k][m] = fact[m] * co[m] / denom;
+        }
+    }
     if (upload_datasets(h) != MP_OK) {
         mp_destroy(h);
         return nullptr;

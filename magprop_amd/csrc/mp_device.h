@@ -44,6 +44,9 @@ struct DevShared {
     uint32_t log_mask;
     // derived star constants (host-computed once from cfg)
     double GM, inertia, inv_inertia, crot /* 0.5*I/|W| */, sqrtGM, inv_sqrtGM, sqrtR;
+    // geometric grid: ratio q = t_{j+1}/t_j and the exponential Adams-Moulton quadrature matrix for it
+    double q, inv_q;
+    double eamW[4][4];
     mp_model_cfg cfg;
 };
 

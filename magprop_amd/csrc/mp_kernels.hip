@@ -2,18 +2,21 @@
 //
 // Layout: ONE WALKER PER WAVEFRONT, ONE TIME STEP PER LANE.  The 10 000 grid intervals are
 // processed in tiles of 64 consecutive steps; inside a tile the 64 lanes advance all 64 steps
-// at once (parallel in time):
+// at once (parallel in time).  Scheme = exponential Adams-Moulton of order 4 on the geometric
+// output grid (serial restatement: oracle/mp_oracle.c mpo_trajectory):
 //
 //   1. Mdisc obeys dM/dt = Mdotfb(t) - M/tvisc (linear, omega-independent; reference RHS
-//      code/synthetic_datasets/funcs.py:122-129, magnetar/funcs.py:86-92).  Every lane builds the
-//      affine map M_{i+1} = a_i M_i + b_i of its own step (exponential integrator, quadratic
-//      source interpolant) and a wavefront scan of affine maps yields Mdisc at all 64 step ends.
-//   2. omega obeys a scalar nonlinear ODE fed by Mdisc(t).  Every lane applies one step of the
-//      exponential RK4 scheme (Krogstad ETD4RK around the frozen Jacobian lambda_i) to its current
-//      guess of omega at its step start; the step maps are linearised (slope exp(h lambda_i)) and a
-//      second affine scan propagates the tile's start value through all 64 steps.  This Newton-type
-//      sweep converges quadratically (2-4 sweeps); after k sweeps the first k steps are exact, so it
-//      always terminates and reproduces the serial recurrence to rounding.
+//      code/synthetic_datasets/funcs.py:122-129, magnetar/funcs.py:86-92).  Every lane evaluates
+//      Mdotfb at its step end, fetches the three previous values from its neighbours (DPP), and builds
+//      the affine map M_{j+1} = e^{-h/tvisc} M_j + b_j of its own step; a wavefront scan of affine
+//      maps yields Mdisc at all 64 step ends.
+//   2. omega obeys a scalar nonlinear ODE fed by Mdisc(t).  Every lane evaluates omega_dot and its
+//      Jacobian lambda ONCE per sweep, at its current guess of omega at its step end, fetches
+//      (omega_dot, omega) of the three previous grid points from its neighbours, and forms the step
+//      map omega_{j+1} = e^{h lambda} omega_j + h sum_m phi_{m+1}(h lambda) g_m.  A second affine
+//      scan propagates the tile's start value through all 64 linearised maps.  This Newton-type sweep
+//      converges quadratically (about 2 sweeps from an extrapolated guess), terminates in at most
+//      ~64 sweeps in any case, and reproduces the serial recurrence to rounding.
 //   3. Each lane evaluates the luminosity at its step end (reference luminosity stage,
 //      code/synthetic_datasets/funcs.py:175-229, magnetar/funcs.py:157-210), the tile's light curve
 //      is staged in LDS, the observations that fall in the tile are interpolated from LDS
@@ -21,10 +24,10 @@
 //      512-B-per-wave stores write the model light curve to HBM.
 //   4. A wavefront reduction gives -0.5*chi^2 (code/synthetic_datasets/mcmc_eqns.py:25).
 //
-// No MFMA (no dense contraction anywhere on this path), fp64 throughout.  The arithmetic is
-// algebraically simplified with respect to the reference formulas (e.g. fastness
-// w = (Rm/Rc)^1.5 = omega*Rm^1.5/sqrt(GM), eta1-eta2 = -tanh); oracle/mp_oracle.c keeps the literal
-// formulas and the tests compare the two.
+// No MFMA (no dense contraction anywhere on this path), fp64 throughout; the kernel is bound by the
+// fp64 VALU issue rate of one wave per SIMD (profiles/).  The arithmetic is algebraically simplified
+// with respect to the reference formulas (e.g. fastness w = (Rm/Rc)^1.5 = omega*Rm^1.5/sqrt(GM),
+// eta1-eta2 = -tanh); oracle/mp_oracle.c keeps the literal formulas and the tests compare the two.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -147,13 +150,13 @@ MP_DEV double log_fast(double x) {
 }
 
 // ---------------------------------------------------------------- phi functions
-// phi_j(z) = sum_k z^k/(k+j)!  : phi_1 = (e^z-1)/z, phi_2 = (phi_1-1)/z, phi_3 = (phi_2-1/2)/z
+// phi_j(z) = sum_k z^k/(k+j)!  : phi_1 = (e^z-1)/z, phi_{j+1} = (phi_j - 1/j!)/z
 struct Phi {
-    double e, p1, p2, p3;
+    double e, p1, p2, p3, p4;
 };
 
-MP_DEV Phi phi123(double z) {
-    // Taylor series of phi_3 for |z| < 1/2 (14 terms: < 4e-17 relative), closed forms elsewhere
+MP_DEV Phi phi1234(double z) {
+    // Taylor series of phi_4 for |z| < 1/2 (13 terms: < 2e-17 relative), closed forms elsewhere
     double s = 1.0 / 20922789888000.0;            // 1/16!
     s = fma(s, z, 1.0 / 1307674368000.0);         // 1/15!
     s = fma(s, z, 1.0 / 87178291200.0);           // 1/14!
@@ -167,10 +170,10 @@ MP_DEV Phi phi123(double z) {
     s = fma(s, z, 1.0 / 720.0);                   // 1/6!
     s = fma(s, z, 1.0 / 120.0);                   // 1/5!
     s = fma(s, z, 1.0 / 24.0);                    // 1/4!
-    s = fma(s, z, 1.0 / 6.0);                     // 1/3!
     Phi r;
-    r.p3 = s;
-    r.p2 = fma(z, s, 0.5);
+    r.p4 = s;
+    r.p3 = fma(z, s, 1.0 / 6.0);
+    r.p2 = fma(z, r.p3, 0.5);
     r.p1 = fma(z, r.p2, 1.0);
     r.e = fma(z, r.p1, 1.0);
     const bool big = !(fabs(z) < 0.5);
@@ -180,22 +183,27 @@ MP_DEV Phi phi123(double z) {
         const double c1 = (ce - 1.0) * rz;
         const double c2 = (c1 - 1.0) * rz;
         const double c3 = (c2 - 0.5) * rz;
+        const double c4 = (c3 - 1.0 / 6.0) * rz;
         r.e = big ? ce : r.e;
         r.p1 = big ? c1 : r.p1;
         r.p2 = big ? c2 : r.p2;
         r.p3 = big ? c3 : r.p3;
+        r.p4 = big ? c4 : r.p4;
     }
     return r;
 }
 
-// phi functions at 2z from those at z
-MP_DEV Phi phi_double(const Phi &h) {
-    Phi r;
-    r.e = h.e * h.e;
-    r.p1 = 0.5 * (h.e + 1.0) * h.p1;
-    r.p2 = 0.25 * fma(h.p1, h.p1, 2.0 * h.p2);
-    r.p3 = 0.125 * (fma(h.p1, h.p2, h.p2) + 2.0 * h.p3);
-    return r;
+// h * int_0^1 e^{z(1-theta)} P(theta) dtheta for the cubic P through the node values v0..v3 at
+// t_{j+1}, t_j, t_{j-1}, t_{j-2} (quadrature matrix W of the geometric grid, DevShared::eamW)
+MP_DEV double eam4_increment(const DevShared &sh, const Phi &p, double h, double v0, double v1, double v2, double v3) {
+    double acc = 0.0;
+    const double ph[4] = {p.p1, p.p2, p.p3, p.p4};
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const double g = fma(sh.eamW[0][m], v0, fma(sh.eamW[1][m], v1, fma(sh.eamW[2][m], v2, sh.eamW[3][m] * v3)));
+        acc = fma(ph[m], g, acc);
+    }
+    return h * acc;
 }
 
 // ---------------------------------------------------------------- per-walker constants
@@ -322,8 +330,8 @@ MP_DEV void luminosity(const DevShared &sh, const Walker &w, const DiscPt &p, do
     Ldip = ld;
 }
 
-constexpr int kMaxSweeps = 72;     // > 64: the sweep is exact after at most 64 passes
-constexpr double kSweepTol = 1e-9; // relative change of the step-start values that ends the sweeps
+constexpr int kMaxSweeps = 80;      // > 64 + Newton margin: the sweeps always terminate
+constexpr double kSweepTol = 1e-9;  // relative change of the step-end values that ends the sweeps
 
 // ---------------------------------------------------------------- the kernel
 template <bool CURVES>
@@ -381,12 +389,24 @@ __global__ __launch_bounds__(64) void lnprob_kernel(const DevShared sh, const La
         if (a.ndim == 9) { w.dipeff = par[6]; w.propeff = par[7]; w.f_beam = par[8]; }
     }
 
-    // ---- initial conditions (code/synthetic_datasets/funcs.py:66-69)
-    double M_s = par[2] * kMsol;                         // Mdisc at the tile start
-    double om_s = (2.0 * M_PI) / (1.0e-3 * par[1]);      // omega at the tile start
-    double om_m1 = om_s, om_m2 = om_s;                   // omega one / two grid points before the tile start
-    double S_s = mdot_fb(w, sh.tgrid[0]);                // Mdotfb at the tile start
+    // ---- state carried from tile to tile (all wave-uniform).  Index 0 = the tile's start point P0,
+    // 1 = P0-1, 2 = P0-2: the history the multistep formulas reach back to.
+    const double t0 = sh.tgrid[0];
+    double t_s = t0;
+    double M_s = par[2] * kMsol;                         // initial conditions, code/synthetic_datasets/funcs.py:66-69
+    double om_s = (2.0 * M_PI) / (1.0e-3 * par[1]);
+    double cS0 = mdot_fb(w, t0), cS1 = mdot_fb(w, t0 * sh.inv_q), cS2 = mdot_fb(w, t0 * sh.inv_q * sh.inv_q);
     DiscPt d_s = disc_point(sh, w, M_s);
+    double cf0, cf1, cf2, cw1 = om_s, cw2 = om_s;        // (omega_dot, omega) history; cw0 == om_s
+    {
+        double rot0, dummy;
+        cf0 = omega_rhs<false>(sh, w, d_s, om_s, rot0, dummy);
+        cf1 = cf2 = cf0;
+        if (status == MP_STATUS_OK) {
+            if (!(isfinite(M_s) && isfinite(om_s)) || M_s <= 0.0 || om_s <= 0.0) status = MP_STATUS_NONFINITE;
+            else if (rot0 > 0.27) status = MP_STATUS_FLAG;
+        }
+    }
     double L_s, Lp_s, Ld_s;
     luminosity(sh, w, d_s, om_s, L_s, Lp_s, Ld_s);
 
@@ -395,7 +415,7 @@ __global__ __launch_bounds__(64) void lnprob_kernel(const DevShared sh, const La
     const int32_t *tptr = sh.tile_ptr + dsd.tile_off;
     double chi = 0.0;
     int sweeps_total = 0;
-    const double fl = (double)lane;
+    const double fl1 = (double)(lane + 1);
 
     if (status == MP_STATUS_OK) {
         if (CURVES && lane == 0) {
@@ -405,82 +425,79 @@ __global__ __launch_bounds__(64) void lnprob_kernel(const DevShared sh, const La
             if (a.mdisc) a.mdisc[row] = M_s;
             if (a.omega) a.omega[row] = om_s;
         }
+        // this lane's step end time, fetched one tile ahead of its use
+        double tb_next = sh.tgrid[min(lane + 1, nsteps)];
         for (int tile = 0; tile < sh.n_tiles; ++tile) {
             const int i = tile * kTile + lane;           // this lane's step: tgrid[i] -> tgrid[i+1]
             const bool active = i < nsteps;
-            const int ic = active ? i : nsteps - 1;
-            const double ta = sh.tgrid[ic], tb = sh.tgrid[ic + 1];
-            const double h = tb - ta;
-            const double tm = fma(0.5, h, ta);
+            const double tb = tb_next;
+            tb_next = sh.tgrid[min(i + kTile + 1, nsteps)];
+            const double ta = lane_prev(tb, t_s);
+            const double h = active ? tb - ta : 1.0;
 
-            // ---------------- Mdisc: exponential step + affine scan
-            const double S1 = mdot_fb(w, tm), S2 = mdot_fb(w, tb);
-            const double S0 = lane_prev(S2, S_s);
-            const double c1 = -3.0 * S0 + 4.0 * S1 - S2, c2 = 2.0 * S0 - 4.0 * S1 + 2.0 * S2;
-            const Phi qh = phi123(-0.5 * h * w.inv_tau);
-            const Phi qf = phi_double(qh);
-            double aM = active ? qf.e : 1.0;
-            double bM = active ? h * fma(S0, qf.p1, fma(c1, qf.p2, 2.0 * c2 * qf.p3)) : 0.0;
-            const double a_half = qh.e;
-            const double b_half = 0.5 * h * fma(S0, qh.p1, fma(0.5 * c1, qh.p2, 0.5 * c2 * qh.p3));
+            // ---------------- Mdisc: exponential Adams-Moulton step (explicit: the source is known) + affine scan
+            const double S1 = mdot_fb(w, tb);
+            const double Sj = lane_prev(S1, cS0), Sj1 = lane_prev(Sj, cS1), Sj2 = lane_prev(Sj1, cS2);
+            const Phi pm = phi1234(-h * w.inv_tau);
+            double aM = active ? pm.e : 1.0;
+            double bM = active ? eam4_increment(sh, pm, h, S1, Sj, Sj1, Sj2) : 0.0;
             scan_affine(aM, bM);
             const double M1 = fma(aM, M_s, bM);          // Mdisc at this lane's step end
-            const double M0 = lane_prev(M1, M_s);
-            const double Mh = fma(a_half, M0, b_half);   // Mdisc at the step midpoint
-            const DiscPt d1 = disc_point(sh, w, M1), dh = disc_point(sh, w, Mh);
-            const DiscPt d0 = disc_prev(d1, d_s);
+            const DiscPt d1 = disc_point(sh, w, M1);
 
             // ---------------- omega: predictor = quadratic extrapolation of the last three grid values in the
             // step index (the grid is logarithmic, so power laws are smooth in the index) ...
-            double wg;
+            double wg;                                    // current guess of omega at this lane's step end
             {
-                const double g1 = om_s - om_m1, g2 = (om_s - om_m1) - (om_m1 - om_m2);
-                wg = fma(fl, g1, fma(0.5 * fl * (fl + 1.0), g2, om_s));
-                if (!(wg > 0.0)) wg = om_s;
+                const double g1 = om_s - cw1, g2 = (om_s - cw1) - (cw1 - cw2);
+                wg = fma(fl1, g1, fma(0.5 * fl1 * (fl1 + 1.0), g2, om_s));
             }
             // ... then Newton-type sweeps of the linearised step maps
-            double w1 = om_s;        // omega at this lane's step end
-            double rmax = 0.0;
+            double f1 = 0.0, wj = om_s;
+            unsigned long long flagged = 0ull, pending = ~0ull;
+            bool settled = false;    // this lane's guess moved by < 1e-3 in the previous sweep
             int sweep = 0;
-            bool done = false;
-            while (!done) {
+            while (true) {
                 ++sweep;
-                double r0, r2, r3, r4, lam, dummy;
-                const double f0 = omega_rhs<true>(sh, w, d0, wg, r0, lam);
-                const Phi ph = phi123(0.5 * h * lam);
-                const Phi pf = phi_double(ph);
-                const double N0 = fma(-lam, wg, f0);
-                const double U2 = fma(ph.e, wg, 0.5 * h * ph.p1 * N0);
-                const double N2 = fma(-lam, U2, omega_rhs<false>(sh, w, dh, U2, r2, dummy));
-                const double U3 = fma(ph.e, wg, fma(0.5 * h * (ph.p1 - 2.0 * ph.p2), N0, h * ph.p2 * N2));
-                const double N3 = fma(-lam, U3, omega_rhs<false>(sh, w, dh, U3, r3, dummy));
-                const double U4 = fma(pf.e, wg, fma(h * (pf.p1 - 2.0 * pf.p2), N0, 2.0 * h * pf.p2 * N3));
-                const double N4 = fma(-lam, U4, omega_rhs<false>(sh, w, d1, U4, r4, dummy));
-                const double v = fma(pf.e, wg,
-                                     h * fma(pf.p1 - 3.0 * pf.p2 + 4.0 * pf.p3, N0,
-                                             fma(2.0 * pf.p2 - 4.0 * pf.p3, N2 + N3, (4.0 * pf.p3 - pf.p2) * N4)));
-                // linearised step map about the current guess: omega_end = e^{h lam} (omega_start - wg) + v
-                double aW = active ? pf.e : 1.0;
-                double bW = active ? fma(-pf.e, wg, v) : 0.0;
+                if (!(wg > 0.0) || !isfinite(wg)) wg = (wj > 0.0 && isfinite(wj)) ? wj : om_s;   // keep the iteration alive
+                double rot, lam;
+                f1 = omega_rhs<true>(sh, w, d1, wg, rot, lam);
+                // break-up reached by an iterate that is no longer a wild guess: the reference's 'flag'
+                flagged |= __ballot(active && settled && rot > 0.27);
+                double h1 = cf1, h2 = cf2, u1 = cw1, u2 = cw2;
+                if (tile == 0) {   // start-up: the two points before the grid continue points 0 and 1 linearly in the index
+                    const double fp1 = lane_bcast(f1, 0), wp1 = lane_bcast(wg, 0);
+                    h1 = 2.0 * cf0 - fp1; u1 = 2.0 * om_s - wp1;
+                    h2 = 3.0 * cf0 - 2.0 * fp1; u2 = 3.0 * om_s - 2.0 * wp1;
+                }
+                const double fj = lane_prev(f1, cf0), fj1 = lane_prev(fj, h1), fj2 = lane_prev(fj1, h2);
+                wj = lane_prev(wg, om_s);
+                const double wj1 = lane_prev(wj, u1), wj2 = lane_prev(wj1, u2);
+                const Phi pw_ = phi1234(h * lam);
+                double aW = active ? pw_.e : 1.0;
+                double bW = active ? eam4_increment(sh, pw_, h, fma(-lam, wg, f1), fma(-lam, wj, fj), fma(-lam, wj1, fj1),
+                                                    fma(-lam, wj2, fj2))
+                                   : 0.0;
                 scan_affine(aW, bW);
-                w1 = fma(aW, om_s, bW);
-                const double wn = lane_prev(w1, om_s);
-                const double delta = fabs(wn - wg);
-                const bool ok = delta <= kSweepTol * fabs(wn);   // false for NaN
-                rmax = fmax(fmax(r0, r2), fmax(r3, r4));        // fmax drops NaN like the oracle's `>` test
-                wg = wn;
-                done = (__ballot(active && !ok) == 0ull) || sweep >= kMaxSweeps;
+                const double w1 = fma(aW, om_s, bW);
+                const double dw = fabs(w1 - wg), aw = fabs(w1);
+                settled = dw <= 1.0e-3 * aw;                              // false for NaN
+                pending = __ballot(active && !(dw <= kSweepTol * aw));
+                wg = w1;
+                if (pending == 0ull || flagged != 0ull || sweep >= kMaxSweeps) break;
             }
             sweeps_total += sweep;
+            const double w1 = wg;
 
             // ---------------- failure detection in time order (oracle/mp_oracle.c)
             {
-                const bool bad = !(isfinite(M0) && isfinite(wg)) || M0 <= 0.0 || wg <= 0.0;
-                const bool flg = rmax > 0.27;
-                const unsigned long long mb = __ballot(active && bad), mf = __ballot(active && flg);
+                const bool bad = !(isfinite(M1) && isfinite(w1)) || M1 <= 0.0 || w1 <= 0.0;
+                const unsigned long long mb = __ballot(active && bad);
+                // a step whose sweeps never settle is chattering on the Nacc discontinuity: same verdict as a flag
+                const unsigned long long mf = flagged | __ballot(active && sh.crot * w1 * w1 > 0.27) | (flagged ? 0ull : pending);
                 if (mb | mf) {
                     const int first = __ffsll((unsigned long long)(mb | mf)) - 1;
-                    status = ((mb >> first) & 1ull) ? MP_STATUS_NONFINITE : MP_STATUS_FLAG;
+                    status = ((mf >> first) & 1ull) ? MP_STATUS_FLAG : MP_STATUS_NONFINITE;
                     break;
                 }
             }
@@ -515,21 +532,26 @@ __global__ __launch_bounds__(64) void lnprob_kernel(const DevShared sh, const La
                 }
             }
 
-            // ---------------- carry the tile end to the next tile
+            // ---------------- carry the tile end (and the history behind it) to the next tile
             const int nact = nsteps - tile * kTile;              // active steps in this tile (>= 1)
             const int last = nact >= kTile ? kTile - 1 : nact - 1;
-            om_m2 = last >= 2 ? lane_bcast(w1, last - 2) : (last == 1 ? om_s : om_m1);
-            om_m1 = last >= 1 ? lane_bcast(w1, last - 1) : om_s;
+            if (last >= 2) {
+                cS2 = lane_bcast(S1, last - 2); cf2 = lane_bcast(f1, last - 2); cw2 = lane_bcast(w1, last - 2);
+                cS1 = lane_bcast(S1, last - 1); cf1 = lane_bcast(f1, last - 1); cw1 = lane_bcast(w1, last - 1);
+            } else if (last == 1) {
+                cS2 = cS0; cf2 = cf0; cw2 = om_s;
+                cS1 = lane_bcast(S1, 0); cf1 = lane_bcast(f1, 0); cw1 = lane_bcast(w1, 0);
+            } else {
+                cS2 = cS1; cf2 = cf1; cw2 = cw1;
+                cS1 = cS0; cf1 = cf0; cw1 = om_s;
+            }
+            cS0 = lane_bcast(S1, last);
+            cf0 = lane_bcast(f1, last);
+            t_s = lane_bcast(tb, last);
             M_s = lane_bcast(M1, last);
             om_s = lane_bcast(w1, last);
-            S_s = lane_bcast(S2, last);
             d_s = disc_bcast(d1, last);
             L_s = lane_bcast(Lt, last);
-        }
-        if (status == MP_STATUS_OK) {
-            // state at the last grid point
-            if (!(isfinite(M_s) && isfinite(om_s)) || M_s <= 0.0 || om_s <= 0.0) status = MP_STATUS_NONFINITE;
-            else if (sh.crot * om_s * om_s > 0.27) status = MP_STATUS_FLAG;
         }
     }
 

@@ -58,6 +58,8 @@ def lib():
         ip = C.POINTER(C.c_int32)
         L.mpo_trajectory.restype = C.c_int
         L.mpo_trajectory.argtypes = [C.POINTER(Cfg), dp, C.c_int, dp, C.c_int, C.c_int, dp, dp]
+        L.mpo_trajectory_etd4rk.restype = C.c_int
+        L.mpo_trajectory_etd4rk.argtypes = L.mpo_trajectory.argtypes
         L.mpo_model_lc.restype = C.c_int
         L.mpo_model_lc.argtypes = [C.POINTER(Cfg), dp, C.c_int, dp, C.c_int, C.c_int, dp, dp]
         L.mpo_lnlike.restype = C.c_double
@@ -75,13 +77,16 @@ def _d(a):
     return a, a.ctypes.data_as(C.POINTER(C.c_double))
 
 
-def trajectory(cfg, pars, tgrid, nsub=1):
-    """(status, Mdisc[n], omega[n]) for PHYSICAL parameters."""
+def trajectory(cfg, pars, tgrid, nsub=1, scheme="eam4"):
+    """(status, Mdisc[n], omega[n]) for PHYSICAL parameters.  scheme "eam4" is the production scheme
+    (exponential Adams-Moulton, what the HIP kernel implements); "etd4rk" the independent one-step
+    cross-check (Krogstad exponential RK4 with an exponential Mdisc step)."""
     p, pp = _d(pars)
     t, tp = _d(tgrid)
     M = np.empty(t.size)
     W = np.empty(t.size)
-    st = lib().mpo_trajectory(C.byref(cfg), pp, p.size, tp, t.size, nsub,
+    fn = lib().mpo_trajectory if scheme == "eam4" else lib().mpo_trajectory_etd4rk
+    st = fn(C.byref(cfg), pp, p.size, tp, t.size, nsub,
                               M.ctypes.data_as(C.POINTER(C.c_double)), W.ctypes.data_as(C.POINTER(C.c_double)))
     return st, M, W
 

@@ -28,6 +28,7 @@
  *     code/synthetic_datasets/funcs.py:122-129): linear and omega-independent.  It is advanced
  *     with an exponential (integrating-factor) step whose source term is the quadratic interpolant
  *     of Mdotfb through t_i, t_i+h/2, t_i+h — unconditionally stable for h >> tvisc.
+ *   [cross-check scheme, mpo_trajectory_etd4rk]
  *   - omega is advanced with the exponential fourth-order Runge-Kutta scheme of Krogstad
  *     (ETD4RK, J. Comput. Phys. 203 (2005) 72) around the per-step frozen Jacobian
  *     lambda_i = d(omega_dot)/d(omega) at (t_i, omega_i), one step per grid interval, fed Mdisc at
@@ -184,8 +185,8 @@ static void etd_weights(double Z, double *I0, double *I1, double *I2) {
  * production scheme; larger values are for convergence studies in the tests).
  * Mout/Wout (may be NULL) receive the state at the grid points.  Returns a status.
  */
-int mpo_trajectory(const mpo_cfg *c, const double *pars, int ndim, const double *tgrid, int n,
-                   int nsub, double *Mout, double *Wout) {
+int mpo_trajectory_etd4rk(const mpo_cfg *c, const double *pars, int ndim, const double *tgrid, int n,
+                          int nsub, double *Mout, double *Wout) {
     wk w;
     walker_setup(c, pars, ndim, &w);
     /* code/synthetic_datasets/funcs.py:66-69 */
@@ -247,6 +248,127 @@ int mpo_trajectory(const mpo_cfg *c, const double *pars, int ndim, const double 
             break;
         }
     }
+    return status;
+}
+
+/* phi_1..4(z): Taylor below |z| = 0.5, closed forms above */
+static void phi1234(double z, double *ez, double ph[4]) {
+    if (fabs(z) < 0.5) {
+        double s = 0.0, term = 1.0 / 24.0;
+        for (int k = 0; k < 22; ++k) { s += term; term *= z / (double)(k + 5); }
+        ph[3] = s; ph[2] = z * s + 1.0 / 6.0; ph[1] = z * ph[2] + 0.5; ph[0] = z * ph[1] + 1.0; *ez = z * ph[0] + 1.0;
+    } else {
+        *ez = exp(z);
+        ph[0] = expm1(z) / z;
+        ph[1] = (ph[0] - 1.0) / z;
+        ph[2] = (ph[1] - 0.5) / z;
+        ph[3] = (ph[2] - 1.0 / 6.0) / z;
+    }
+}
+
+/*
+ * Quadrature matrix of the exponential Adams-Moulton step on a geometric grid of ratio q.
+ * Nodes (in units of the step h_j, origin t_j): t_{j+1}, t_j, t_{j-1}, t_{j-2}  ->  1, 0, -1/q, -(1/q + 1/q^2).
+ * With N(theta) = sum_k N_k l_k(theta) the cubic through the node values,
+ *   int_0^1 exp(z (1 - theta)) N(theta) dtheta = sum_m phi_{m+1}(z) sum_k Wm[k][m] N_k ,  Wm[k][m] = m! [theta^m] l_k.
+ */
+void mpo_eam4_weights(double q, double Wm[4][4]) {
+    const double x[4] = {1.0, 0.0, -1.0 / q, -(1.0 / q + 1.0 / (q * q))};
+    const double fact[4] = {1.0, 1.0, 2.0, 6.0};
+    for (int k = 0; k < 4; ++k) {
+        double c[4] = {1.0, 0.0, 0.0, 0.0}; /* polynomial coefficients, ascending */
+        int deg = 0;
+        double denom = 1.0;
+        for (int j = 0; j < 4; ++j) {
+            if (j == k) continue;
+            /* c(theta) *= (theta - x_j) */
+            for (int m = deg + 1; m >= 1; --m) c[m] = c[m - 1] - x[j] * c[m];
+            c[0] = -x[j] * c[0];
+            ++deg;
+            denom *= x[k] - x[j];
+        }
+        for (int m = 0; m < 4; ++m) Wm[k][m] = fact[m] * c[m] / denom;
+    }
+}
+
+/*
+ * PRODUCTION SCHEME (the one the HIP kernel implements): exponential Adams-Moulton of order 4 on the
+ * geometric output grid, one step per grid interval.
+ *   Mdisc_{j+1} = e^{-z} Mdisc_j + h sum_m phi_{m+1}(-z) sum_k Wm[k][m] Mdotfb(t_{j+1-k}),        z = h/tvisc
+ *   omega_{j+1} = e^{h lam} omega_j + h sum_m phi_{m+1}(h lam) sum_k Wm[k][m] (f_{j+1-k} - lam omega_{j+1-k})
+ * with f_p = omega_dot(Mdisc_p, omega_p) and lam = d(omega_dot)/d(omega) frozen at the NEW point
+ * (t_{j+1}, omega_{j+1}): implicit in omega_{j+1}, solved by fixed-point iteration (contraction ~ h*|d lam|).
+ * History before the first grid point: Mdotfb is analytic (the grid is continued geometrically backwards);
+ * for (f, omega) the two missing points are the linear continuation in the step index through points 0 and 1.
+ * Failure ('flag'): the rotation parameter of any iterate at a grid point exceeds 0.27.
+ * nsub > 1 refines the grid geometrically (convergence studies only).
+ */
+int mpo_trajectory(const mpo_cfg *c, const double *pars, int ndim, const double *tgrid, int n,
+                   int nsub, double *Mout, double *Wout) {
+    wk w;
+    walker_setup(c, pars, ndim, &w);
+    if (nsub < 1) nsub = 1;
+    const int nf = (n - 1) * nsub + 1;
+    const double q = exp(log(tgrid[n - 1] / tgrid[0]) / (double)(nf - 1));
+    double Wm[4][4];
+    mpo_eam4_weights(q, Wm);
+    double *tf = (double *)malloc(sizeof(double) * (size_t)nf);
+    if (nsub == 1) memcpy(tf, tgrid, sizeof(double) * (size_t)n);
+    else for (int i = 0; i < nf; ++i) tf[i] = (i % nsub == 0) ? tgrid[i / nsub] : tgrid[0] * pow(q, (double)i);
+    int status = MPO_OK;
+    for (int j = 0; j < n; ++j) { if (Mout) Mout[j] = NAN; if (Wout) Wout[j] = NAN; } /* undefined after a failure */
+    double M = pars[2] * MSOL_;                        /* code/synthetic_datasets/funcs.py:66-69 */
+    double om = (2.0 * M_PI) / (1.0e-3 * pars[1]);
+    /* history: index 0 = point j, 1 = j-1, 2 = j-2 */
+    double Sh[3] = {mdot_fb(&w, tf[0]), mdot_fb(&w, tf[0] / q), mdot_fb(&w, tf[0] / (q * q))};
+    double fh[3] = {0.0, 0.0, 0.0}, wh[3] = {0.0, 0.0, 0.0}, rot;
+    fh[0] = omega_dot(c, &w, M, om, &rot, NULL);
+    wh[0] = om;
+    double f0 = fh[0], w0 = om, f1 = 0.0, w1 = 0.0; /* points 0 and 1, for the start-up ghosts */
+    for (int i = 0; i < nf; ++i) {
+        if (i % nsub == 0) { if (Mout) Mout[i / nsub] = M; if (Wout) Wout[i / nsub] = om; }
+        if (!(isfinite(M) && isfinite(om)) || M <= 0.0 || om <= 0.0) status = MPO_NONFINITE;
+        else if ((0.5 * w.I * om * om) / w.modW > 0.27) status = MPO_FLAG;
+        if (status != MPO_OK || i == nf - 1) break;
+        const double h = tf[i + 1] - tf[i];
+        /* ---- Mdisc */
+        const double S1 = mdot_fb(&w, tf[i + 1]);
+        double ez, ph[4];
+        phi1234(-h / w.tvisc, &ez, ph);
+        double acc = 0.0;
+        for (int m = 0; m < 4; ++m)
+            acc += ph[m] * (Wm[0][m] * S1 + Wm[1][m] * Sh[0] + Wm[2][m] * Sh[1] + Wm[3][m] * Sh[2]);
+        const double M1 = ez * M + h * acc;
+        /* ---- omega: fixed-point iteration on the implicit step */
+        double wn = om + h * fh[0], fnew = 0.0;
+        int flagged = 0;
+        for (int it = 0; it < 200; ++it) {
+            double lam, r1;
+            fnew = omega_dot(c, &w, M1, wn, &r1, &lam);
+            if (r1 > 0.27) { flagged = 1; break; }
+            double hf[2], hw[2]; /* points j-1, j-2 (ghosts during start-up) */
+            if (i == 0) { hf[0] = 2.0 * f0 - fnew; hw[0] = 2.0 * w0 - wn; hf[1] = 3.0 * f0 - 2.0 * fnew; hw[1] = 3.0 * w0 - 2.0 * wn; }
+            else if (i == 1) { hf[0] = fh[1]; hw[0] = wh[1]; hf[1] = 2.0 * f0 - f1; hw[1] = 2.0 * w0 - w1; }
+            else { hf[0] = fh[1]; hw[0] = wh[1]; hf[1] = fh[2]; hw[1] = wh[2]; }
+            const double N0 = fnew - lam * wn, N1 = fh[0] - lam * wh[0], N2 = hf[0] - lam * hw[0], N3 = hf[1] - lam * hw[1];
+            phi1234(h * lam, &ez, ph);
+            acc = 0.0;
+            for (int m = 0; m < 4; ++m) acc += ph[m] * (Wm[0][m] * N0 + Wm[1][m] * N1 + Wm[2][m] * N2 + Wm[3][m] * N3);
+            const double wnew = ez * om + h * acc;
+            const double d = fabs(wnew - wn);
+            wn = wnew;
+            if (!(d > 1e-15 * fabs(wn))) break; /* converged, or NaN */
+        }
+        if (flagged) { status = MPO_FLAG; break; }
+        fnew = omega_dot(c, &w, M1, wn, &rot, NULL);
+        if (i == 0) { f1 = fnew; w1 = wn; }
+        Sh[2] = Sh[1]; Sh[1] = Sh[0]; Sh[0] = S1;
+        fh[2] = fh[1]; fh[1] = fh[0]; fh[0] = fnew;
+        wh[2] = wh[1]; wh[1] = wh[0]; wh[0] = wn;
+        M = M1;
+        om = wn;
+    }
+    free(tf);
     return status;
 }
 

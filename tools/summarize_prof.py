@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Condense a tools/profile.sh output directory into a short markdown + JSON summary (per-launch numbers
+for the dominant kernel mp::lnprob_kernel)."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+out, tag = sys.argv[1], sys.argv[2]
+KERN = "lnprob_kernel"
+
+
+def find(sub, pat):
+    r = glob.glob(os.path.join(out, sub, "**", pat), recursive=True)
+    return r[0] if r else None
+
+
+summary = {"tag": tag}
+f = find("trace", "*kernel_stats.csv")
+lines = ["# rocprofv3 summary `%s`" % tag, ""]
+if f:
+    lines += ["## kernel-trace --stats (top kernels)", "", "| kernel | calls | avg us | min us | max us | % |", "|---|---|---|---|---|---|"]
+    for row in list(csv.DictReader(open(f)))[:5]:
+        name = row["Name"]
+        short = name.split("(")[0][-60:] if len(name) > 70 else name
+        lines.append(f"| `{short}` | {row['Calls']} | {float(row['AverageNs'])/1e3:.1f} | {float(row['MinNs'])/1e3:.1f} | "
+                     f"{float(row['MaxNs'])/1e3:.1f} | {float(row['Percentage']):.2f} |")
+        if KERN in name and "kernel_avg_us" not in summary:
+            summary.update(kernel=name.split("(")[0], calls=int(row["Calls"]), kernel_avg_us=float(row["AverageNs"]) / 1e3,
+                           kernel_min_us=float(row["MinNs"]) / 1e3)
+    lines.append("")
+counters = defaultdict(list)
+meta = {}
+for sub in ("pmc_sq", "pmc_fetch", "pmc_write"):
+    f = find(sub, "*counter_collection.csv")
+    if not f:
+        continue
+    per_dispatch = defaultdict(dict)
+    for row in csv.DictReader(open(f)):
+        if KERN not in row.get("Kernel_Name", ""):
+            continue
+        per_dispatch[row["Dispatch_Id"]][row["Counter_Name"]] = float(row["Counter_Value"])
+        meta = {k: row.get(k) for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Grid_Size",
+                                        "Workgroup_Size", "Scratch_Size") if k in row}
+    for d in per_dispatch.values():
+        for k, v in d.items():
+            counters[k].append(v)
+avg = {k: sum(v) / len(v) for k, v in counters.items()}
+summary["counters_per_launch"] = avg
+summary["dispatch"] = meta
+if avg:
+    lines += ["## PMC counters, average per launch of `mp::lnprob_kernel`", "", "| counter | value |", "|---|---|"]
+    for k in sorted(avg):
+        lines.append(f"| {k} | {avg[k]:.6g} |")
+    lines.append("")
+    d = {}
+    if "SQ_WAVES" in avg and avg["SQ_WAVES"]:
+        w = avg["SQ_WAVES"]
+        d["valu_insts_per_wave"] = avg.get("SQ_INSTS_VALU", 0) / w
+        d["salu_insts_per_wave"] = avg.get("SQ_INSTS_SALU", 0) / w
+        if avg.get("SQ_WAVE_CYCLES"):
+            # SQ_WAVE_CYCLES / SQ_ACTIVE_INST_* / SQ_WAIT_* count quad-cycles (MI355X_MICROARCH.md cycle constants)
+            d["wave_cycles_per_wave"] = 4.0 * avg["SQ_WAVE_CYCLES"] / w
+            d["cycles_per_valu_inst"] = 4.0 * avg["SQ_WAVE_CYCLES"] / max(avg.get("SQ_INSTS_VALU", 1), 1)
+            d["valu_active_frac_of_wave_cycles"] = avg.get("SQ_ACTIVE_INST_VALU", 0) / avg["SQ_WAVE_CYCLES"]
+            d["wait_inst_any_frac"] = avg.get("SQ_WAIT_INST_ANY", 0) / avg["SQ_WAVE_CYCLES"]
+            d["wait_any_frac"] = avg.get("SQ_WAIT_ANY", 0) / avg["SQ_WAVE_CYCLES"]
+    if "FETCH_SIZE" in avg:
+        d["hbm_read_bytes_raw"] = avg["FETCH_SIZE"] * 1024.0          # FETCH_SIZE is in KiB
+        d["hbm_read_bytes_x2_gfx950"] = 2.0 * avg["FETCH_SIZE"] * 1024.0  # guide: gfx950 tallies 128-B requests at 64 B
+    if "WRITE_SIZE" in avg:
+        d["hbm_write_bytes"] = avg["WRITE_SIZE"] * 1024.0
+    if "hbm_read_bytes_raw" in d and "hbm_write_bytes" in d:
+        d["traffic_bytes_per_launch"] = d["hbm_read_bytes_x2_gfx950"] + d["hbm_write_bytes"]
+    summary["derived"] = d
+    lines += ["## derived", "", "| quantity | value |", "|---|---|"]
+    for k, v in d.items():
+        lines.append(f"| {k} | {v:.6g} |")
+    if meta:
+        lines += ["", "dispatch: " + ", ".join(f"{k}={v}" for k, v in meta.items())]
+for b in ("bench_trace.json",):
+    p = os.path.join(out, b)
+    if os.path.exists(p):
+        try:
+            j = json.loads(open(p).read().strip().splitlines()[-1])
+            summary["bench_under_profiler"] = {"value": j["value"], "kernel_ms_avg": j["roofline"]["kernel_ms_avg"],
+                                               "workload": j["config"]["workload"]}
+            lines += ["", f"bench.py under the profiler: {j['value']:.0f} evals/s, HIP-event kernel time "
+                          f"{j['roofline']['kernel_ms_avg']*1e3:.1f} us ({j['config']['workload']})"]
+        except Exception as e:  # noqa: BLE001
+            lines += ["", f"(bench json unreadable: {e})"]
+json.dump(summary, open(os.path.join(out, "summary.json"), "w"), indent=1)
+print("\n".join(lines))
