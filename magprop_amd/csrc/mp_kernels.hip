@@ -86,6 +86,15 @@ MP_DEV double wave_sum(double v) {
 }
 
 // ---------------------------------------------------------------- fp64 elementary functions
+// Three-address FMA for Horner chains.  hipcc selects the two-address v_fmac_f64 there and then has to
+// copy every polynomial coefficient into the accumulator first (one v_mov_b64 per term); the explicit
+// v_fma_f64 reads the coefficient in place.  Only plain VALU results feed it (no transcendental-op hazard).
+MP_DEV double fma3(double a, double b, double c) {
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
 // Hand-rolled for this kernel's argument ranges (positive, normal, far from overflow): hardware
 // seed (v_rcp_f64 / v_rsq_f64, ~2^-23) + two Newton steps, without the scaling / fix-up code the
 // general-purpose library versions carry.  All are accurate to ~1-2 ulp.
@@ -110,19 +119,44 @@ MP_DEV double exp_fast(double x) {
     double r = fma(k, -6.93147180369123816490e-01, x);
     r = fma(k, -1.90821492927058770002e-10, r);
     double p = 1.0 / 479001600.0;                 // Taylor degree 12 on |r| <= ln2/2: 1.7e-16
-    p = fma(p, r, 1.0 / 39916800.0);
-    p = fma(p, r, 1.0 / 3628800.0);
-    p = fma(p, r, 1.0 / 362880.0);
-    p = fma(p, r, 1.0 / 40320.0);
-    p = fma(p, r, 1.0 / 5040.0);
-    p = fma(p, r, 1.0 / 720.0);
-    p = fma(p, r, 1.0 / 120.0);
-    p = fma(p, r, 1.0 / 24.0);
-    p = fma(p, r, 1.0 / 6.0);
-    p = fma(p, r, 0.5);
-    p = fma(p, r, 1.0);
-    p = fma(p, r, 1.0);
+    p = fma3(p, r, 1.0 / 39916800.0);
+    p = fma3(p, r, 1.0 / 3628800.0);
+    p = fma3(p, r, 1.0 / 362880.0);
+    p = fma3(p, r, 1.0 / 40320.0);
+    p = fma3(p, r, 1.0 / 5040.0);
+    p = fma3(p, r, 1.0 / 720.0);
+    p = fma3(p, r, 1.0 / 120.0);
+    p = fma3(p, r, 1.0 / 24.0);
+    p = fma3(p, r, 1.0 / 6.0);
+    p = fma3(p, r, 0.5);
+    p = fma3(p, r, 1.0);
+    p = fma3(p, r, 1.0);
     return ldexp(p, (int)k);
+}
+
+// x^(-1/3) for positive normal x within float range: v_log_f32/v_exp_f32 seed (~1e-6) + two Newton steps
+// y <- y (4 - x y^3)/3 (error -> 2 e^2): ~1 ulp.
+MP_DEV double rcbrt_fast(double x) {
+    double y = (double)__builtin_amdgcn_exp2f(-0.33333333f * __builtin_amdgcn_logf((float)x));
+    const double x3 = x * (1.0 / 3.0);
+    double y3 = y * y * y;
+    y = y * fma(-x3, y3, 4.0 / 3.0);
+    y3 = y * y * y;
+    y = y * fma(-x3, y3, 4.0 / 3.0);
+    return y;
+}
+
+// x^(-2/7) for positive normal x within float range: y = (x^2)^(-1/7), Newton y <- y (8 - x^2 y^7)/7 (error -> 4 e^2)
+MP_DEV double pow_m2_7_fast(double x) {
+    double y = (double)__builtin_amdgcn_exp2f(-0.28571429f * __builtin_amdgcn_logf((float)x));
+    const double z7 = (x * x) * (1.0 / 7.0);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const double y2 = y * y, y4 = y2 * y2;
+        const double y7 = (y4 * y2) * y;
+        y = y * fma(-z7, y7, 8.0 / 7.0);
+    }
+    return y;
 }
 
 // natural log of a positive normal number
@@ -136,16 +170,16 @@ MP_DEV double log_fast(double x) {
     const double s = f * rcp_fast(2.0 + f);       // |s| <= 0.1716
     const double z = s * s;
     double p = 1.0 / 21.0;                        // atanh series: log(m) = 2s(1 + z/3 + z^2/5 + ...)
-    p = fma(p, z, 1.0 / 19.0);
-    p = fma(p, z, 1.0 / 17.0);
-    p = fma(p, z, 1.0 / 15.0);
-    p = fma(p, z, 1.0 / 13.0);
-    p = fma(p, z, 1.0 / 11.0);
-    p = fma(p, z, 1.0 / 9.0);
-    p = fma(p, z, 1.0 / 7.0);
-    p = fma(p, z, 1.0 / 5.0);
-    p = fma(p, z, 1.0 / 3.0);
-    p = fma(p, z, 1.0);
+    p = fma3(p, z, 1.0 / 19.0);
+    p = fma3(p, z, 1.0 / 17.0);
+    p = fma3(p, z, 1.0 / 15.0);
+    p = fma3(p, z, 1.0 / 13.0);
+    p = fma3(p, z, 1.0 / 11.0);
+    p = fma3(p, z, 1.0 / 9.0);
+    p = fma3(p, z, 1.0 / 7.0);
+    p = fma3(p, z, 1.0 / 5.0);
+    p = fma3(p, z, 1.0 / 3.0);
+    p = fma3(p, z, 1.0);
     return fma((double)e, 6.93147180559945309417e-01, 2.0 * s * p);
 }
 
@@ -158,18 +192,18 @@ struct Phi {
 MP_DEV Phi phi1234(double z) {
     // Taylor series of phi_4 for |z| < 1/2 (13 terms: < 2e-17 relative), closed forms elsewhere
     double s = 1.0 / 20922789888000.0;            // 1/16!
-    s = fma(s, z, 1.0 / 1307674368000.0);         // 1/15!
-    s = fma(s, z, 1.0 / 87178291200.0);           // 1/14!
-    s = fma(s, z, 1.0 / 6227020800.0);            // 1/13!
-    s = fma(s, z, 1.0 / 479001600.0);             // 1/12!
-    s = fma(s, z, 1.0 / 39916800.0);              // 1/11!
-    s = fma(s, z, 1.0 / 3628800.0);               // 1/10!
-    s = fma(s, z, 1.0 / 362880.0);                // 1/9!
-    s = fma(s, z, 1.0 / 40320.0);                 // 1/8!
-    s = fma(s, z, 1.0 / 5040.0);                  // 1/7!
-    s = fma(s, z, 1.0 / 720.0);                   // 1/6!
-    s = fma(s, z, 1.0 / 120.0);                   // 1/5!
-    s = fma(s, z, 1.0 / 24.0);                    // 1/4!
+    s = fma3(s, z, 1.0 / 1307674368000.0);         // 1/15!
+    s = fma3(s, z, 1.0 / 87178291200.0);           // 1/14!
+    s = fma3(s, z, 1.0 / 6227020800.0);            // 1/13!
+    s = fma3(s, z, 1.0 / 479001600.0);             // 1/12!
+    s = fma3(s, z, 1.0 / 39916800.0);              // 1/11!
+    s = fma3(s, z, 1.0 / 3628800.0);               // 1/10!
+    s = fma3(s, z, 1.0 / 362880.0);                // 1/9!
+    s = fma3(s, z, 1.0 / 40320.0);                 // 1/8!
+    s = fma3(s, z, 1.0 / 5040.0);                  // 1/7!
+    s = fma3(s, z, 1.0 / 720.0);                   // 1/6!
+    s = fma3(s, z, 1.0 / 120.0);                   // 1/5!
+    s = fma3(s, z, 1.0 / 24.0);                    // 1/4!
     Phi r;
     r.p4 = s;
     r.p3 = fma(z, s, 1.0 / 6.0);
@@ -211,7 +245,7 @@ struct Walker {
     double inv_tau;   // 1/tvisc
     double S_amp;     // M0/tfb
     double inv_tfb;   // 1/tfb
-    double lnCrm;     // ln( mu^(4/7) GM^(-1/7) f_Rm^(-2/7) )
+    double Crm;       // mu^(4/7) GM^(-1/7) f_Rm^(-2/7)
     double DI;        // mu^2/(6 c^3 I)          dipole torque / I = -DI*omega^3
     double D;         // mu^2/(6 c^3)
     double armI;      // sqrt(GM)/I
@@ -233,7 +267,7 @@ struct DiscPt {
 MP_DEV DiscPt disc_point(const DevShared &sh, const Walker &w, double Mdisc) {
     DiscPt p;
     p.mdot = Mdisc * w.inv_tau;
-    p.rmu = exp_fast(fma(-2.0 / 7.0, log_fast(p.mdot), w.lnCrm));   // Crm * mdot^(-2/7)
+    p.rmu = w.Crm * pow_m2_7_fast(p.mdot);
     p.squ = p.rmu * rsqrt_fast(p.rmu);
     p.qu = p.rmu * p.squ * sh.inv_sqrtGM;
     return p;
@@ -260,7 +294,8 @@ MP_DEV DiscPt disc_bcast(const DiscPt &p, int src) {
 // fallback accretion rate Mdotfb(t), code/synthetic_datasets/funcs.py:128
 MP_DEV double mdot_fb(const Walker &w, double t) {
     const double u = fma(t, w.inv_tfb, 1.0);                        // (t + tfb)/tfb >= 1
-    return w.S_amp * exp_fast(-5.0 / 3.0 * log_fast(u));            // u^(-5/3)
+    const double r = rcbrt_fast(u), r2 = r * r;
+    return w.S_amp * (r2 * r2 * r);                                 // u^(-5/3)
 }
 
 // Radii / fastness / switch shared by the ODE right-hand side and the luminosity stage
@@ -335,7 +370,7 @@ constexpr double kSweepTol = 1e-9;  // relative change of the step-end values th
 
 // ---------------------------------------------------------------- the kernel
 template <bool CURVES>
-__global__ __launch_bounds__(64) void lnprob_kernel(const DevShared sh, const LaunchArgs a) {
+__global__ __launch_bounds__(64, 1) void lnprob_kernel(const DevShared sh, const LaunchArgs a) {
     const int walker = blockIdx.x;
     const int lane = threadIdx.x;
     __shared__ double Lbuf[kTile + 1];
@@ -373,7 +408,7 @@ __global__ __launch_bounds__(64) void lnprob_kernel(const DevShared sh, const La
         w.inv_tau = 1.0 / tau;
         w.S_amp = M0 / tfb;
         w.inv_tfb = 1.0 / tfb;
-        w.lnCrm = (4.0 / 7.0) * log(mu) - (1.0 / 7.0) * log(sh.GM) - (2.0 / 7.0) * log(sh.cfg.rm_massflow_factor);
+        w.Crm = pow(mu, 4.0 / 7.0) * pow(sh.GM, -1.0 / 7.0) * pow(sh.cfg.rm_massflow_factor, -2.0 / 7.0);
         w.D = (mu * mu) / (6.0 * kC * kC * kC);
         w.DI = w.D * sh.inv_inertia;
         w.armI = sh.sqrtGM * sh.inv_inertia;
@@ -413,6 +448,19 @@ __global__ __launch_bounds__(64) void lnprob_kernel(const DevShared sh, const La
     const int dsid = a.ds_id ? a.ds_id[walker] : 0;
     const DsDesc dsd = sh.ds ? sh.ds[(dsid >= 0 && dsid < sh.n_ds) ? dsid : 0] : DsDesc{0, 0, 0, 0};
     const int32_t *tptr = sh.tile_ptr + dsd.tile_off;
+    // The first 64 observations of the walker's light curve live in registers, one per lane (time-sorted;
+    // every synthetic set has 50).  Longer light curves take the tile-bucketed global-memory path for the rest.
+    int ob_g = -1;
+    double ob_dx = 0.0, ob_idt = 0.0, ob_y = 0.0, ob_ye = 1.0;
+    if (a.want_chi2 && lane < dsd.n_obs) {
+        const int jj = dsd.obs_off + lane;
+        ob_g = sh.obs_g[jj];
+        ob_dx = sh.obs_dx[jj];
+        ob_idt = sh.obs_idt[jj];
+        ob_y = sh.obs_y[jj];
+        ob_ye = sh.obs_yerr[jj];
+    }
+    const bool long_lc = a.want_chi2 && dsd.n_obs > kTile;
     double chi = 0.0;
     int sweeps_total = 0;
     const double fl1 = (double)(lane + 1);
@@ -459,7 +507,7 @@ __global__ __launch_bounds__(64) void lnprob_kernel(const DevShared sh, const La
             int sweep = 0;
             while (true) {
                 ++sweep;
-                if (!(wg > 0.0) || !isfinite(wg)) wg = (wj > 0.0 && isfinite(wj)) ? wj : om_s;   // keep the iteration alive
+                if (!(wg > 0.0)) wg = wj > 0.0 ? wj : om_s;   // keep the iteration alive after a wild or NaN guess
                 double rot, lam;
                 f1 = omega_rhs<true>(sh, w, d1, wg, rot, lam);
                 // break-up reached by an iterate that is no longer a wild guess: the reference's 'flag'
@@ -513,18 +561,26 @@ __global__ __launch_bounds__(64) void lnprob_kernel(const DevShared sh, const La
                 if (a.mdisc) a.mdisc[o] = M1;
                 if (a.omega) a.omega[o] = w1;
             }
-            if (a.want_chi2) {
-                const int j0 = tptr[tile], j1 = tptr[tile + 1];
-                if (j1 > j0) {
+            {
+                const bool mine = (ob_g >> 6) == tile && ob_g >= 0;      // kTile == 64
+                int j0 = 0, j1 = 0;
+                if (long_lc) { j0 = max(tptr[tile], kTile); j1 = tptr[tile + 1]; }
+                if (__any(mine) || j1 > j0) {
                     Lbuf[lane + 1] = Lt;
                     if (lane == 0) Lbuf[0] = L_s;
                     __syncthreads();
+                    if (mine) {
+                        const int g = ob_g - tile * kTile;
+                        const double La = Lbuf[g], Lb = Lbuf[g + 1];
+                        const double mod = fma((Lb - La) * ob_idt, ob_dx, La) / 1.0e50;   // np.interp, then /1e50
+                        const double res = (ob_y - mod) / ob_ye;
+                        chi = fma(res, res, chi);
+                    }
                     for (int j = j0 + lane; j < j1; j += kTile) {
                         const int jj = dsd.obs_off + j;
                         const int g = sh.obs_g[jj] - tile * kTile;
                         const double La = Lbuf[g], Lb = Lbuf[g + 1];
-                        const double slope = (Lb - La) * sh.obs_idt[jj];
-                        const double mod = fma(slope, sh.obs_dx[jj], La) / 1.0e50;
+                        const double mod = fma((Lb - La) * sh.obs_idt[jj], sh.obs_dx[jj], La) / 1.0e50;
                         const double res = (sh.obs_y[jj] - mod) / sh.obs_yerr[jj];
                         chi = fma(res, res, chi);
                     }
@@ -550,7 +606,6 @@ __global__ __launch_bounds__(64) void lnprob_kernel(const DevShared sh, const La
             t_s = lane_bcast(tb, last);
             M_s = lane_bcast(M1, last);
             om_s = lane_bcast(w1, last);
-            d_s = disc_bcast(d1, last);
             L_s = lane_bcast(Lt, last);
         }
     }
