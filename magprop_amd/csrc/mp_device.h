@@ -6,7 +6,8 @@
 
 namespace mp {
 
-constexpr int kTile = 64;  // time steps per tile = lanes per wavefront: one step per lane
+constexpr int kSPL = 2;            // consecutive time steps owned by one lane
+constexpr int kTile = 64 * kSPL;   // time steps per tile (one wavefront)
 
 // physical constants, magnetar/funcs.py:7-13 (cgs)
 constexpr double kG = 6.674e-8;

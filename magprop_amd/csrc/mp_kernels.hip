@@ -365,7 +365,7 @@ MP_DEV void luminosity(const DevShared &sh, const Walker &w, const DiscPt &p, do
     Ldip = ld;
 }
 
-constexpr int kMaxSweeps = 80;      // > 64 + Newton margin: the sweeps always terminate
+constexpr int kMaxSweeps = 64 * kSPL + 16;  // > tile length + Newton margin: the sweeps always terminate
 constexpr double kSweepTol = 1e-9;  // relative change of the step-end values that ends the sweeps
 
 // ---------------------------------------------------------------- the kernel
@@ -374,6 +374,7 @@ __global__ __launch_bounds__(64, 1) void lnprob_kernel(const DevShared sh, const
     const int walker = blockIdx.x;
     const int lane = threadIdx.x;
     __shared__ double Lbuf[kTile + 1];
+    static_assert(kTile == 64 * kSPL, "one wavefront, kSPL steps per lane");
 
     const int n_grid = sh.n_grid;
     const int nsteps = n_grid - 1;
@@ -431,9 +432,10 @@ __global__ __launch_bounds__(64, 1) void lnprob_kernel(const DevShared sh, const
     double M_s = par[2] * kMsol;                         // initial conditions, code/synthetic_datasets/funcs.py:66-69
     double om_s = (2.0 * M_PI) / (1.0e-3 * par[1]);
     double cS0 = mdot_fb(w, t0), cS1 = mdot_fb(w, t0 * sh.inv_q), cS2 = mdot_fb(w, t0 * sh.inv_q * sh.inv_q);
-    DiscPt d_s = disc_point(sh, w, M_s);
-    double cf0, cf1, cf2, cw1 = om_s, cw2 = om_s;        // (omega_dot, omega) history; cw0 == om_s
+    double cf0, cf1, cf2, cw1 = om_s, cw2 = om_s, cw3 = om_s;   // (omega_dot, omega) history; cw0 == om_s (cw3: predictor only)
+    double L_s, Lp_s, Ld_s;
     {
+        const DiscPt d_s = disc_point(sh, w, M_s);
         double rot0, dummy;
         cf0 = omega_rhs<false>(sh, w, d_s, om_s, rot0, dummy);
         cf1 = cf2 = cf0;
@@ -441,9 +443,8 @@ __global__ __launch_bounds__(64, 1) void lnprob_kernel(const DevShared sh, const
             if (!(isfinite(M_s) && isfinite(om_s)) || M_s <= 0.0 || om_s <= 0.0) status = MP_STATUS_NONFINITE;
             else if (rot0 > 0.27) status = MP_STATUS_FLAG;
         }
+        luminosity(sh, w, d_s, om_s, L_s, Lp_s, Ld_s);
     }
-    double L_s, Lp_s, Ld_s;
-    luminosity(sh, w, d_s, om_s, L_s, Lp_s, Ld_s);
 
     const int dsid = a.ds_id ? a.ds_id[walker] : 0;
     const DsDesc dsd = sh.ds ? sh.ds[(dsid >= 0 && dsid < sh.n_ds) ? dsid : 0] : DsDesc{0, 0, 0, 0};
@@ -460,10 +461,10 @@ __global__ __launch_bounds__(64, 1) void lnprob_kernel(const DevShared sh, const
         ob_y = sh.obs_y[jj];
         ob_ye = sh.obs_yerr[jj];
     }
-    const bool long_lc = a.want_chi2 && dsd.n_obs > kTile;
+    const int ob_tile = ob_g >= 0 ? ob_g / kTile : -1;
+    const bool long_lc = a.want_chi2 && dsd.n_obs > 64;
     double chi = 0.0;
     int sweeps_total = 0;
-    const double fl1 = (double)(lane + 1);
 
     if (status == MP_STATUS_OK) {
         if (CURVES && lane == 0) {
@@ -473,76 +474,143 @@ __global__ __launch_bounds__(64, 1) void lnprob_kernel(const DevShared sh, const
             if (a.mdisc) a.mdisc[row] = M_s;
             if (a.omega) a.omega[row] = om_s;
         }
-        // this lane's step end time, fetched one tile ahead of its use
-        double tb_next = sh.tgrid[min(lane + 1, nsteps)];
-        for (int tile = 0; tile < sh.n_tiles; ++tile) {
-            const int i = tile * kTile + lane;           // this lane's step: tgrid[i] -> tgrid[i+1]
-            const bool active = i < nsteps;
-            const double tb = tb_next;
-            tb_next = sh.tgrid[min(i + kTile + 1, nsteps)];
-            const double ta = lane_prev(tb, t_s);
-            const double h = active ? tb - ta : 1.0;
+        // Each lane owns kSPL consecutive steps of the tile: steps tile*kTile + lane*kSPL + s, s = 0..kSPL-1.
+        // Step end times are fetched one tile ahead of their use.
+        double tb_next[kSPL];
+#pragma unroll
+        for (int s = 0; s < kSPL; ++s) tb_next[s] = sh.tgrid[min(lane * kSPL + s + 1, nsteps)];
 
-            // ---------------- Mdisc: exponential Adams-Moulton step (explicit: the source is known) + affine scan
-            const double S1 = mdot_fb(w, tb);
-            const double Sj = lane_prev(S1, cS0), Sj1 = lane_prev(Sj, cS1), Sj2 = lane_prev(Sj1, cS2);
-            const Phi pm = phi1234(-h * w.inv_tau);
-            double aM = active ? pm.e : 1.0;
-            double bM = active ? eam4_increment(sh, pm, h, S1, Sj, Sj1, Sj2) : 0.0;
-            scan_affine(aM, bM);
-            const double M1 = fma(aM, M_s, bM);          // Mdisc at this lane's step end
-            const DiscPt d1 = disc_point(sh, w, M1);
+        for (int tile = 0; tile < sh.n_tiles; ++tile) {
+            const int i0 = tile * kTile + lane * kSPL;   // this lane's first step: tgrid[i0] -> tgrid[i0+1]
+            double tb[kSPL], h[kSPL];
+            bool active[kSPL];
+#pragma unroll
+            for (int s = 0; s < kSPL; ++s) {
+                tb[s] = tb_next[s];
+                tb_next[s] = sh.tgrid[min(i0 + kTile + s + 1, nsteps)];
+                active[s] = i0 + s < nsteps;
+            }
+            {
+                const double ta0 = lane_prev(tb[kSPL - 1], t_s);
+#pragma unroll
+                for (int s = 0; s < kSPL; ++s) h[s] = active[s] ? tb[s] - (s == 0 ? ta0 : tb[s - 1]) : 1.0;
+            }
+
+            // ---------------- Mdisc: exponential Adams-Moulton step (explicit: the source is known) + affine scan.
+            // E*[k]: values at the three grid points before this lane's first step (k = 0,1,2) and at its step ends (k = 3+s).
+            double M1[kSPL];
+            double ES[kSPL + 3];
+            {
+#pragma unroll
+                for (int s = 0; s < kSPL; ++s) ES[3 + s] = mdot_fb(w, tb[s]);
+                ES[2] = lane_prev(ES[kSPL + 2], cS0);
+                ES[1] = lane_prev(ES[kSPL + 1], cS1);
+                ES[0] = lane_prev(ES[kSPL + 0], cS2);
+                double am[kSPL], bm[kSPL];
+                double A = 1.0, B = 0.0;                  // composition of this lane's step maps
+#pragma unroll
+                for (int s = 0; s < kSPL; ++s) {
+                    const Phi pm = phi1234(-h[s] * w.inv_tau);
+                    am[s] = active[s] ? pm.e : 1.0;
+                    bm[s] = active[s] ? eam4_increment(sh, pm, h[s], ES[3 + s], ES[2 + s], ES[1 + s], ES[s]) : 0.0;
+                    B = fma(am[s], B, bm[s]);
+                    A = A * am[s];
+                }
+                scan_affine(A, B);
+                const double Ax = lane_prev(A, 1.0), Bx = lane_prev(B, 0.0);   // exclusive prefix
+                double Mc = fma(Ax, M_s, Bx);            // Mdisc at this lane's first step start
+#pragma unroll
+                for (int s = 0; s < kSPL; ++s) { Mc = fma(am[s], Mc, bm[s]); M1[s] = Mc; }
+            }
+            DiscPt d1[kSPL];
+#pragma unroll
+            for (int s = 0; s < kSPL; ++s) d1[s] = disc_point(sh, w, M1[s]);
 
             // ---------------- omega: predictor = quadratic extrapolation of the last three grid values in the
             // step index (the grid is logarithmic, so power laws are smooth in the index) ...
-            double wg;                                    // current guess of omega at this lane's step end
+            double wg[kSPL];                              // current guess of omega at this lane's step ends
             {
-                const double g1 = om_s - cw1, g2 = (om_s - cw1) - (cw1 - cw2);
-                wg = fma(fl1, g1, fma(0.5 * fl1 * (fl1 + 1.0), g2, om_s));
+                // Newton backward-difference extrapolation (cubic once four grid values exist)
+                const double g1 = om_s - cw1, g2 = g1 - (cw1 - cw2);
+                const double g3 = tile == 0 ? 0.0 : g2 - ((cw1 - cw2) - (cw2 - cw3));
+#pragma unroll
+                for (int s = 0; s < kSPL; ++s) {
+                    const double k = (double)(lane * kSPL + s + 1);
+                    const double c2 = 0.5 * k * (k + 1.0);
+                    wg[s] = fma(k, g1, fma(c2, g2, fma(c2 * (k + 2.0) * (1.0 / 3.0), g3, om_s)));
+                }
             }
             // ... then Newton-type sweeps of the linearised step maps
-            double f1 = 0.0, wj = om_s;
+            double Ef[kSPL + 3], Ew[kSPL + 3];
             unsigned long long flagged = 0ull, pending = ~0ull;
-            bool settled = false;    // this lane's guess moved by < 1e-3 in the previous sweep
+            bool settled = false;    // this lane's guesses moved by < 1e-3 in the previous sweep
             int sweep = 0;
+            Ew[2] = om_s;
             while (true) {
                 ++sweep;
-                if (!(wg > 0.0)) wg = wj > 0.0 ? wj : om_s;   // keep the iteration alive after a wild or NaN guess
-                double rot, lam;
-                f1 = omega_rhs<true>(sh, w, d1, wg, rot, lam);
+                double lam[kSPL];
+                bool flg = false;
+#pragma unroll
+                for (int s = 0; s < kSPL; ++s) {
+                    if (!(wg[s] > 0.0)) wg[s] = Ew[2] > 0.0 ? Ew[2] : om_s;   // keep the iteration alive after a wild or NaN guess
+                    double rot;
+                    Ef[3 + s] = omega_rhs<true>(sh, w, d1[s], wg[s], rot, lam[s]);
+                    Ew[3 + s] = wg[s];
+                    flg = flg || (active[s] && rot > 0.27);
+                }
                 // break-up reached by an iterate that is no longer a wild guess: the reference's 'flag'
-                flagged |= __ballot(active && settled && rot > 0.27);
+                flagged |= __ballot(settled && flg);
                 double h1 = cf1, h2 = cf2, u1 = cw1, u2 = cw2;
                 if (tile == 0) {   // start-up: the two points before the grid continue points 0 and 1 linearly in the index
-                    const double fp1 = lane_bcast(f1, 0), wp1 = lane_bcast(wg, 0);
+                    const double fp1 = lane_bcast(Ef[3], 0), wp1 = lane_bcast(Ew[3], 0);
                     h1 = 2.0 * cf0 - fp1; u1 = 2.0 * om_s - wp1;
                     h2 = 3.0 * cf0 - 2.0 * fp1; u2 = 3.0 * om_s - 2.0 * wp1;
                 }
-                const double fj = lane_prev(f1, cf0), fj1 = lane_prev(fj, h1), fj2 = lane_prev(fj1, h2);
-                wj = lane_prev(wg, om_s);
-                const double wj1 = lane_prev(wj, u1), wj2 = lane_prev(wj1, u2);
-                const Phi pw_ = phi1234(h * lam);
-                double aW = active ? pw_.e : 1.0;
-                double bW = active ? eam4_increment(sh, pw_, h, fma(-lam, wg, f1), fma(-lam, wj, fj), fma(-lam, wj1, fj1),
-                                                    fma(-lam, wj2, fj2))
-                                   : 0.0;
-                scan_affine(aW, bW);
-                const double w1 = fma(aW, om_s, bW);
-                const double dw = fabs(w1 - wg), aw = fabs(w1);
-                settled = dw <= 1.0e-3 * aw;                              // false for NaN
-                pending = __ballot(active && !(dw <= kSweepTol * aw));
-                wg = w1;
+                Ef[2] = lane_prev(Ef[kSPL + 2], cf0);  Ew[2] = lane_prev(Ew[kSPL + 2], om_s);
+                Ef[1] = lane_prev(Ef[kSPL + 1], h1);   Ew[1] = lane_prev(Ew[kSPL + 1], u1);
+                Ef[0] = lane_prev(Ef[kSPL + 0], h2);   Ew[0] = lane_prev(Ew[kSPL + 0], u2);
+                double aw[kSPL], bw[kSPL];
+                double A = 1.0, B = 0.0;
+#pragma unroll
+                for (int s = 0; s < kSPL; ++s) {
+                    const Phi pw_ = phi1234(h[s] * lam[s]);
+                    aw[s] = active[s] ? pw_.e : 1.0;
+                    bw[s] = active[s] ? eam4_increment(sh, pw_, h[s], fma(-lam[s], Ew[3 + s], Ef[3 + s]),
+                                                       fma(-lam[s], Ew[2 + s], Ef[2 + s]), fma(-lam[s], Ew[1 + s], Ef[1 + s]),
+                                                       fma(-lam[s], Ew[s], Ef[s]))
+                                      : 0.0;
+                    B = fma(aw[s], B, bw[s]);
+                    A = A * aw[s];
+                }
+                scan_affine(A, B);
+                const double Ax = lane_prev(A, 1.0), Bx = lane_prev(B, 0.0);
+                double wc = fma(Ax, om_s, Bx);           // omega at this lane's first step start
+                bool all_ok = true, all_settled = true;
+#pragma unroll
+                for (int s = 0; s < kSPL; ++s) {
+                    wc = fma(aw[s], wc, bw[s]);
+                    const double dw = fabs(wc - wg[s]), mag = fabs(wc);
+                    all_settled = all_settled && (dw <= 1.0e-3 * mag);               // false for NaN
+                    all_ok = all_ok && (!active[s] || dw <= kSweepTol * mag);
+                    wg[s] = wc;
+                }
+                settled = all_settled;
+                pending = __ballot(!all_ok);
                 if (pending == 0ull || flagged != 0ull || sweep >= kMaxSweeps) break;
             }
             sweeps_total += sweep;
-            const double w1 = wg;
 
             // ---------------- failure detection in time order (oracle/mp_oracle.c)
             {
-                const bool bad = !(isfinite(M1) && isfinite(w1)) || M1 <= 0.0 || w1 <= 0.0;
-                const unsigned long long mb = __ballot(active && bad);
+                bool bad = false, over = false;
+#pragma unroll
+                for (int s = 0; s < kSPL; ++s) {
+                    bad = bad || (active[s] && (!(isfinite(M1[s]) && isfinite(wg[s])) || M1[s] <= 0.0 || wg[s] <= 0.0));
+                    over = over || (active[s] && sh.crot * wg[s] * wg[s] > 0.27);
+                }
+                const unsigned long long mb = __ballot(bad);
                 // a step whose sweeps never settle is chattering on the Nacc discontinuity: same verdict as a flag
-                const unsigned long long mf = flagged | __ballot(active && sh.crot * w1 * w1 > 0.27) | (flagged ? 0ull : pending);
+                const unsigned long long mf = flagged | __ballot(over) | (flagged ? 0ull : pending);
                 if (mb | mf) {
                     const int first = __ffsll((unsigned long long)(mb | mf)) - 1;
                     status = ((mf >> first) & 1ull) ? MP_STATUS_FLAG : MP_STATUS_NONFINITE;
@@ -551,22 +619,27 @@ __global__ __launch_bounds__(64, 1) void lnprob_kernel(const DevShared sh, const
             }
 
             // ---------------- luminosity at the step ends, light curve through LDS, chi^2
-            double Lt, Lp, Ld;
-            luminosity(sh, w, d1, w1, Lt, Lp, Ld);
-            if (CURVES && active) {
-                const size_t o = row + (size_t)i + 1;
-                if (a.ltot) a.ltot[o] = Lt / 1.0e50;
-                if (a.lprop) a.lprop[o] = Lp / 1.0e50;
-                if (a.ldip) a.ldip[o] = Ld / 1.0e50;
-                if (a.mdisc) a.mdisc[o] = M1;
-                if (a.omega) a.omega[o] = w1;
+            double Lt[kSPL];
+#pragma unroll
+            for (int s = 0; s < kSPL; ++s) {
+                double Lp, Ld;
+                luminosity(sh, w, d1[s], wg[s], Lt[s], Lp, Ld);
+                if (CURVES && active[s]) {
+                    const size_t o = row + (size_t)(i0 + s) + 1;
+                    if (a.ltot) a.ltot[o] = Lt[s] / 1.0e50;
+                    if (a.lprop) a.lprop[o] = Lp / 1.0e50;
+                    if (a.ldip) a.ldip[o] = Ld / 1.0e50;
+                    if (a.mdisc) a.mdisc[o] = M1[s];
+                    if (a.omega) a.omega[o] = wg[s];
+                }
             }
             {
-                const bool mine = (ob_g >> 6) == tile && ob_g >= 0;      // kTile == 64
+                const bool mine = ob_tile == tile;
                 int j0 = 0, j1 = 0;
-                if (long_lc) { j0 = max(tptr[tile], kTile); j1 = tptr[tile + 1]; }
+                if (long_lc) { j0 = max(tptr[tile], 64); j1 = tptr[tile + 1]; }
                 if (__any(mine) || j1 > j0) {
-                    Lbuf[lane + 1] = Lt;
+#pragma unroll
+                    for (int s = 0; s < kSPL; ++s) Lbuf[lane * kSPL + s + 1] = Lt[s];
                     if (lane == 0) Lbuf[0] = L_s;
                     __syncthreads();
                     if (mine) {
@@ -576,7 +649,7 @@ __global__ __launch_bounds__(64, 1) void lnprob_kernel(const DevShared sh, const
                         const double res = (ob_y - mod) / ob_ye;
                         chi = fma(res, res, chi);
                     }
-                    for (int j = j0 + lane; j < j1; j += kTile) {
+                    for (int j = j0 + lane; j < j1; j += 64) {
                         const int jj = dsd.obs_off + j;
                         const int g = sh.obs_g[jj] - tile * kTile;
                         const double La = Lbuf[g], Lb = Lbuf[g + 1];
@@ -588,25 +661,22 @@ __global__ __launch_bounds__(64, 1) void lnprob_kernel(const DevShared sh, const
                 }
             }
 
-            // ---------------- carry the tile end (and the history behind it) to the next tile
-            const int nact = nsteps - tile * kTile;              // active steps in this tile (>= 1)
-            const int last = nact >= kTile ? kTile - 1 : nact - 1;
-            if (last >= 2) {
-                cS2 = lane_bcast(S1, last - 2); cf2 = lane_bcast(f1, last - 2); cw2 = lane_bcast(w1, last - 2);
-                cS1 = lane_bcast(S1, last - 1); cf1 = lane_bcast(f1, last - 1); cw1 = lane_bcast(w1, last - 1);
-            } else if (last == 1) {
-                cS2 = cS0; cf2 = cf0; cw2 = om_s;
-                cS1 = lane_bcast(S1, 0); cf1 = lane_bcast(f1, 0); cw1 = lane_bcast(w1, 0);
-            } else {
-                cS2 = cS1; cf2 = cf1; cw2 = cw1;
-                cS1 = cS0; cf1 = cf0; cw1 = om_s;
+            // ---------------- carry the tile end (and the history behind it) to the next tile: only full tiles
+            // have a successor, so the sources are the last three step ends of lane 63
+            if (tile + 1 < sh.n_tiles) {
+                // step end number e of the tile (0-based) lives in lane e / kSPL, slot e % kSPL
+                constexpr int e1 = kTile - 2, e2 = kTile - 3, e3 = kTile - 4;
+                cS0 = lane_bcast(ES[3 + kSPL - 1], 63);            cf0 = lane_bcast(Ef[3 + kSPL - 1], 63);
+                cS1 = lane_bcast(ES[3 + e1 % kSPL], e1 / kSPL);    cf1 = lane_bcast(Ef[3 + e1 % kSPL], e1 / kSPL);
+                cS2 = lane_bcast(ES[3 + e2 % kSPL], e2 / kSPL);    cf2 = lane_bcast(Ef[3 + e2 % kSPL], e2 / kSPL);
+                cw1 = lane_bcast(wg[e1 % kSPL], e1 / kSPL);
+                cw2 = lane_bcast(wg[e2 % kSPL], e2 / kSPL);
+                cw3 = lane_bcast(wg[e3 % kSPL], e3 / kSPL);
+                t_s = lane_bcast(tb[kSPL - 1], 63);
+                M_s = lane_bcast(M1[kSPL - 1], 63);
+                om_s = lane_bcast(wg[kSPL - 1], 63);
+                L_s = lane_bcast(Lt[kSPL - 1], 63);
             }
-            cS0 = lane_bcast(S1, last);
-            cf0 = lane_bcast(f1, last);
-            t_s = lane_bcast(tb, last);
-            M_s = lane_bcast(M1, last);
-            om_s = lane_bcast(w1, last);
-            L_s = lane_bcast(Lt, last);
         }
     }
 
