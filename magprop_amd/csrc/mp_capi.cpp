@@ -396,7 +396,9 @@ int mp_lnprob_batch(mp_handle *h, const double *pars, const int32_t *ds_id, int 
     int cnt = 0;
     for (int i = 0; i < n; ++i)
         if (status[i] == MP_STATUS_OK) { tot += sweeps[i]; ++cnt; }
-    h->last_mean_sweeps = cnt ? tot / ((double)cnt * h->n_tiles) : 0.0;
+    const int ktile = mp::kTile * mp::kernel_spl(n);
+    const int kernel_tiles = ((int)h->tgrid.size() - 1 + ktile - 1) / ktile;
+    h->last_mean_sweeps = cnt ? tot / ((double)cnt * kernel_tiles) : 0.0;
     return MP_OK;
 }
 

@@ -6,8 +6,7 @@
 
 namespace mp {
 
-constexpr int kSPL = 2;            // consecutive time steps owned by one lane
-constexpr int kTile = 64 * kSPL;   // time steps per tile (one wavefront)
+constexpr int kTile = 64;  // observation bucket size in time steps (the kernels' tiles are 64*SPL steps)
 
 // physical constants, magnetar/funcs.py:7-13 (cgs)
 constexpr double kG = 6.674e-8;
@@ -28,7 +27,7 @@ struct DsDesc {
 struct DevShared {
     const double *tgrid;  // [n_grid]
     int32_t n_grid;
-    int32_t n_tiles;      // ceil((n_grid - 1) / 64)
+    int32_t n_tiles;      // ceil((n_grid - 1) / 64): number of 64-step observation buckets
     const DsDesc *ds;     // [n_ds]
     int32_t n_ds;
     int32_t pad0;
@@ -68,6 +67,9 @@ struct LaunchArgs {
     double *mdisc;          // [n][n_grid] or nullptr
     double *omega;          // [n][n_grid] or nullptr
 };
+
+// Steps per lane of the kernel variant used for a batch of n walkers (tiles are 64*spl steps): see launch_lnprob.
+inline int kernel_spl(int n) { return n <= 1536 ? 4 : 2; }
 
 // implemented in mp_kernels.hip; returns hipError_t as int
 int launch_lnprob(const DevShared &sh, const LaunchArgs &a, void *stream);

@@ -365,16 +365,18 @@ MP_DEV void luminosity(const DevShared &sh, const Walker &w, const DiscPt &p, do
     Ldip = ld;
 }
 
-constexpr int kMaxSweeps = 64 * kSPL + 16;  // > tile length + Newton margin: the sweeps always terminate
+constexpr int kMaxSweepsMargin = 16;  // sweeps allowed beyond the tile length (after which every step is exact)
 constexpr double kSweepTol = 1e-9;  // relative change of the step-end values that ends the sweeps
 
 // ---------------------------------------------------------------- the kernel
-template <bool CURVES>
+// SPL = consecutive steps owned by one lane; a tile is 64*SPL steps.
+template <bool CURVES, int SPL>
 __global__ __launch_bounds__(64, 1) void lnprob_kernel(const DevShared sh, const LaunchArgs a) {
+    constexpr int kSPL = SPL, kTile = 64 * SPL, kMaxSweeps = kTile + kMaxSweepsMargin;
+    const int n_tiles = (sh.n_grid - 1 + kTile - 1) / kTile;
     const int walker = blockIdx.x;
     const int lane = threadIdx.x;
     __shared__ double Lbuf[kTile + 1];
-    static_assert(kTile == 64 * kSPL, "one wavefront, kSPL steps per lane");
 
     const int n_grid = sh.n_grid;
     const int nsteps = n_grid - 1;
@@ -432,7 +434,7 @@ __global__ __launch_bounds__(64, 1) void lnprob_kernel(const DevShared sh, const
     double M_s = par[2] * kMsol;                         // initial conditions, code/synthetic_datasets/funcs.py:66-69
     double om_s = (2.0 * M_PI) / (1.0e-3 * par[1]);
     double cS0 = mdot_fb(w, t0), cS1 = mdot_fb(w, t0 * sh.inv_q), cS2 = mdot_fb(w, t0 * sh.inv_q * sh.inv_q);
-    double cf0, cf1, cf2, cw1 = om_s, cw2 = om_s, cw3 = om_s;   // (omega_dot, omega) history; cw0 == om_s (cw3: predictor only)
+    double cf0, cf1, cf2, cw1 = om_s, cw2 = om_s, cw3 = om_s, cw4 = om_s;   // (omega_dot, omega) history; cw0 == om_s (cw3, cw4: predictor only)
     double L_s, Lp_s, Ld_s;
     {
         const DiscPt d_s = disc_point(sh, w, M_s);
@@ -480,7 +482,7 @@ __global__ __launch_bounds__(64, 1) void lnprob_kernel(const DevShared sh, const
 #pragma unroll
         for (int s = 0; s < kSPL; ++s) tb_next[s] = sh.tgrid[min(lane * kSPL + s + 1, nsteps)];
 
-        for (int tile = 0; tile < sh.n_tiles; ++tile) {
+        for (int tile = 0; tile < n_tiles; ++tile) {
             const int i0 = tile * kTile + lane * kSPL;   // this lane's first step: tgrid[i0] -> tgrid[i0+1]
             double tb[kSPL], h[kSPL];
             bool active[kSPL];
@@ -532,12 +534,15 @@ __global__ __launch_bounds__(64, 1) void lnprob_kernel(const DevShared sh, const
             {
                 // Newton backward-difference extrapolation (cubic once four grid values exist)
                 const double g1 = om_s - cw1, g2 = g1 - (cw1 - cw2);
-                const double g3 = tile == 0 ? 0.0 : g2 - ((cw1 - cw2) - (cw2 - cw3));
+                const double d2b = (cw1 - cw2) - (cw2 - cw3);
+                const double g3 = tile == 0 ? 0.0 : g2 - d2b;
+                const double g4 = tile == 0 ? 0.0 : g3 - (d2b - ((cw2 - cw3) - (cw3 - cw4)));
 #pragma unroll
                 for (int s = 0; s < kSPL; ++s) {
                     const double k = (double)(lane * kSPL + s + 1);
                     const double c2 = 0.5 * k * (k + 1.0);
-                    wg[s] = fma(k, g1, fma(c2, g2, fma(c2 * (k + 2.0) * (1.0 / 3.0), g3, om_s)));
+                    const double c3 = c2 * (k + 2.0) * (1.0 / 3.0);
+                    wg[s] = fma(k, g1, fma(c2, g2, fma(c3, g3, fma(c3 * (k + 3.0) * 0.25, g4, om_s))));
                 }
             }
             // ... then Newton-type sweeps of the linearised step maps
@@ -636,7 +641,7 @@ __global__ __launch_bounds__(64, 1) void lnprob_kernel(const DevShared sh, const
             {
                 const bool mine = ob_tile == tile;
                 int j0 = 0, j1 = 0;
-                if (long_lc) { j0 = max(tptr[tile], 64); j1 = tptr[tile + 1]; }
+                if (long_lc) { j0 = max(tptr[tile * kSPL], 64); j1 = tptr[min((tile + 1) * kSPL, sh.n_tiles)]; }   // 64-step buckets
                 if (__any(mine) || j1 > j0) {
 #pragma unroll
                     for (int s = 0; s < kSPL; ++s) Lbuf[lane * kSPL + s + 1] = Lt[s];
@@ -663,15 +668,16 @@ __global__ __launch_bounds__(64, 1) void lnprob_kernel(const DevShared sh, const
 
             // ---------------- carry the tile end (and the history behind it) to the next tile: only full tiles
             // have a successor, so the sources are the last three step ends of lane 63
-            if (tile + 1 < sh.n_tiles) {
+            if (tile + 1 < n_tiles) {
                 // step end number e of the tile (0-based) lives in lane e / kSPL, slot e % kSPL
-                constexpr int e1 = kTile - 2, e2 = kTile - 3, e3 = kTile - 4;
+                constexpr int e1 = kTile - 2, e2 = kTile - 3, e3 = kTile - 4, e4 = kTile - 5;
                 cS0 = lane_bcast(ES[3 + kSPL - 1], 63);            cf0 = lane_bcast(Ef[3 + kSPL - 1], 63);
                 cS1 = lane_bcast(ES[3 + e1 % kSPL], e1 / kSPL);    cf1 = lane_bcast(Ef[3 + e1 % kSPL], e1 / kSPL);
                 cS2 = lane_bcast(ES[3 + e2 % kSPL], e2 / kSPL);    cf2 = lane_bcast(Ef[3 + e2 % kSPL], e2 / kSPL);
                 cw1 = lane_bcast(wg[e1 % kSPL], e1 / kSPL);
                 cw2 = lane_bcast(wg[e2 % kSPL], e2 / kSPL);
                 cw3 = lane_bcast(wg[e3 % kSPL], e3 / kSPL);
+                cw4 = lane_bcast(wg[e4 % kSPL], e4 / kSPL);
                 t_s = lane_bcast(tb[kSPL - 1], 63);
                 M_s = lane_bcast(M1[kSPL - 1], 63);
                 om_s = lane_bcast(wg[kSPL - 1], 63);
@@ -696,10 +702,18 @@ int launch_lnprob(const DevShared &sh, const LaunchArgs &a, void *stream) {
     if (a.n <= 0) return 0;
     const bool curves = a.ltot || a.lprop || a.ldip || a.mdisc || a.omega;
     dim3 grid((unsigned)a.n), block(64);
-    if (curves)
-        hipLaunchKernelGGL(lnprob_kernel<true>, grid, block, 0, (hipStream_t)stream, sh, a);
-    else
-        hipLaunchKernelGGL(lnprob_kernel<false>, grid, block, 0, (hipStream_t)stream, sh, a);
+    // Four steps per lane (256-step tiles) amortise the wavefront scans best and are the fastest variant while
+    // every walker can have a SIMD to itself (256 CUs x 4 SIMDs); it needs > 256 VGPRs-worth of state per two
+    // waves, so larger batches use two steps per lane, which keeps two waves resident per SIMD.
+    const bool wide = kernel_spl(a.n) == 4;
+    hipStream_t st = (hipStream_t)stream;
+    if (curves) {
+        if (wide) hipLaunchKernelGGL((lnprob_kernel<true, 4>), grid, block, 0, st, sh, a);
+        else hipLaunchKernelGGL((lnprob_kernel<true, 2>), grid, block, 0, st, sh, a);
+    } else {
+        if (wide) hipLaunchKernelGGL((lnprob_kernel<false, 4>), grid, block, 0, st, sh, a);
+        else hipLaunchKernelGGL((lnprob_kernel<false, 2>), grid, block, 0, st, sh, a);
+    }
     return (int)hipGetLastError();
 }
 
