@@ -14,5 +14,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $OUT/pmc_sq -- python3 $REPO/bench.py $ARGS > $OUT/bench_pmc_sq.json 2> $OUT/pmc_sq.log || exit 2
 rocprofv3 --kernel-trace --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_fetch -- python3 $REPO/bench.py $ARGS > $OUT/bench_pmc_fetch.json 2> $OUT/pmc_fetch.log || exit 3
 rocprofv3 --kernel-trace --pmc WRITE_SIZE SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $OUT/pmc_write -- python3 $REPO/bench.py $ARGS > $OUT/bench_pmc_write.json 2> $OUT/pmc_write.log || exit 4
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_FLOPS_FP64 --output-format csv -d $OUT/pmc_mix -- python3 $REPO/bench.py $ARGS > $OUT/bench_pmc_mix.json 2> $OUT/pmc_mix.log || exit 5
+rocprofv3 --kernel-trace --pmc SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_IFETCH SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_INSTS_VALU_FLOPS_FP64_TRANS SQ_INSTS_VALU_INT64 --output-format csv -d $OUT/pmc_misc -- python3 $REPO/bench.py $ARGS > $OUT/bench_pmc_misc.json 2> $OUT/pmc_misc.log || exit 6
 python3 $REPO/tools/summarize_prof.py $OUT $TAG > $OUT/summary.md
 cat $OUT/summary.md
