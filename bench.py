@@ -97,6 +97,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=20261003)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend; gloo is for rehearsing N>1 on a one-GPU box (ranks share the card, "
+                         "lnprob slices are gathered through host memory) and is never a reported configuration")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -115,17 +118,21 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count()           # == local_rank except in the gloo rehearsal
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)       # RCCL over xGMI
+        else:
+            dist.init_process_group("gloo")
 
     from magprop_amd import LogProb
     from magprop_amd.distributed import ShardedLnprob, shard_range
     g = np.load(os.path.join(ROOT, "tests", "golden", "golden_synth.npz"))
     x, y, yerr = g[a.grb + "_x"], g[a.grb + "_y"], g[a.grb + "_yerr"]
-    lp = LogProb(x, y, yerr, device=local_rank)
+    lp = LogProb(x, y, yerr, device=dev_index)
 
     n_global = a.nwalk * world
     total = a.warmup + a.steps
@@ -150,7 +157,7 @@ def main():
         ev1[i].record(stream)
         return out
 
-    sharded = ShardedLnprob(eval_local)
+    sharded = ShardedLnprob(eval_local, via_host=(a.backend == "gloo"))
     checksum = torch.zeros((), dtype=torch.float64, device=dev)
 
     def run(i):
@@ -204,7 +211,7 @@ def main():
                                    f"({n_global} walkers total), walkers at truth+1e-4*randn, 10001-point grid, "
                                    f"mode {'B (lnprob + model light curve written to HBM)' if a.curve else 'A (lnprob only)'}",
                        "n_walk_per_gpu": a.nwalk, "n_walk_total": n_global, "n_grid": 10001, "n_obs": int(x.size),
-                       "variant": "synth", "parallelism": f"walker-shard x{world} + RCCL all-gather(lnprob)"},
+                       "variant": "synth", "parallelism": f"walker-shard x{world} + {'RCCL' if a.backend == 'nccl' else 'gloo (rehearsal)'} all-gather(lnprob)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "mp::lnprob_kernel", "kernel_ms_avg": 1e3 * kavg, "kernel_ms_min": float(kern_ms.min()),

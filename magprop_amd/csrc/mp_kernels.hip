@@ -85,6 +85,25 @@ MP_DEV double wave_sum(double v) {
     return v;
 }
 
+// ---------------------------------------------------------------- N independent values per lane
+// Every lane owns N consecutive time steps.  All per-step mathematics below is written on N-vectors, one
+// statement at a time across the N steps, so that the N dependent chains (Horner polynomials, Newton
+// refinements) sit next to each other in the instruction stream and hide each other's latency: with one
+// wave per SIMD there is no other wave to do it.
+template <int N>
+struct Vd {
+    double v[N];
+    MP_DEV double &operator[](int i) { return v[i]; }
+    MP_DEV const double &operator[](int i) const { return v[i]; }
+};
+template <int N>
+struct Vb {
+    bool v[N];
+    MP_DEV bool &operator[](int i) { return v[i]; }
+    MP_DEV const bool &operator[](int i) const { return v[i]; }
+};
+#define FORN _Pragma("unroll") for (int i = 0; i < N; ++i)
+
 // ---------------------------------------------------------------- fp64 elementary functions
 // Three-address FMA for Horner chains.  hipcc selects the two-address v_fmac_f64 there and then has to
 // copy every polynomial coefficient into the accumulator first (one v_mov_b64 per term); the explicit
@@ -95,149 +114,171 @@ MP_DEV double fma3(double a, double b, double c) {
     return d;
 }
 
+// p <- p*x + c on all N chains
+template <int N>
+MP_DEV void horner(Vd<N> &p, const Vd<N> &x, double c) {
+    FORN p[i] = fma3(p[i], x[i], c);
+}
+
 // Hand-rolled for this kernel's argument ranges (positive, normal, far from overflow): hardware
 // seed (v_rcp_f64 / v_rsq_f64, ~2^-23) + two Newton steps, without the scaling / fix-up code the
 // general-purpose library versions carry.  All are accurate to ~1-2 ulp.
-MP_DEV double rcp_fast(double x) {
-    double r = __builtin_amdgcn_rcp(x);
-    r = fma(fma(-x, r, 1.0), r, r);
-    r = fma(fma(-x, r, 1.0), r, r);
+template <int N>
+MP_DEV Vd<N> rcp_fast(const Vd<N> &x) {
+    Vd<N> r, e;
+    FORN r[i] = __builtin_amdgcn_rcp(x[i]);
+    FORN e[i] = fma(-x[i], r[i], 1.0);
+    FORN r[i] = fma(e[i], r[i], r[i]);
+    FORN e[i] = fma(-x[i], r[i], 1.0);
+    FORN r[i] = fma(e[i], r[i], r[i]);
     return r;
 }
 
-MP_DEV double rsqrt_fast(double x) {
-    double y = __builtin_amdgcn_rsq(x);
-    const double hx = 0.5 * x;
-    y = fma(y, fma(-hx * y, y, 0.5), y);
-    y = fma(y, fma(-hx * y, y, 0.5), y);
+template <int N>
+MP_DEV Vd<N> rsqrt_fast(const Vd<N> &x) {
+    Vd<N> y, hx, t;
+    FORN y[i] = __builtin_amdgcn_rsq(x[i]);
+    FORN hx[i] = 0.5 * x[i];
+    FORN t[i] = hx[i] * y[i];
+    FORN t[i] = fma(-t[i], y[i], 0.5);
+    FORN y[i] = fma(y[i], t[i], y[i]);
+    FORN t[i] = hx[i] * y[i];
+    FORN t[i] = fma(-t[i], y[i], 0.5);
+    FORN y[i] = fma(y[i], t[i], y[i]);
     return y;
 }
 
 // e^x for x in [-750, 700]; underflows cleanly to 0 below
-MP_DEV double exp_fast(double x) {
-    const double k = __builtin_rint(x * 1.4426950408889634074);
-    double r = fma(k, -6.93147180369123816490e-01, x);
-    r = fma(k, -1.90821492927058770002e-10, r);
-    double p = 1.0 / 479001600.0;                 // Taylor degree 12 on |r| <= ln2/2: 1.7e-16
-    p = fma3(p, r, 1.0 / 39916800.0);
-    p = fma3(p, r, 1.0 / 3628800.0);
-    p = fma3(p, r, 1.0 / 362880.0);
-    p = fma3(p, r, 1.0 / 40320.0);
-    p = fma3(p, r, 1.0 / 5040.0);
-    p = fma3(p, r, 1.0 / 720.0);
-    p = fma3(p, r, 1.0 / 120.0);
-    p = fma3(p, r, 1.0 / 24.0);
-    p = fma3(p, r, 1.0 / 6.0);
-    p = fma3(p, r, 0.5);
-    p = fma3(p, r, 1.0);
-    p = fma3(p, r, 1.0);
-    return ldexp(p, (int)k);
+template <int N>
+MP_DEV Vd<N> exp_fast(const Vd<N> &x) {
+    Vd<N> k, r, p;
+    FORN k[i] = __builtin_rint(x[i] * 1.4426950408889634074);
+    FORN r[i] = fma(k[i], -6.93147180369123816490e-01, x[i]);
+    FORN r[i] = fma(k[i], -1.90821492927058770002e-10, r[i]);
+    FORN p[i] = 1.0 / 479001600.0;               // Taylor degree 12 on |r| <= ln2/2: 1.7e-16
+    horner(p, r, 1.0 / 39916800.0);
+    horner(p, r, 1.0 / 3628800.0);
+    horner(p, r, 1.0 / 362880.0);
+    horner(p, r, 1.0 / 40320.0);
+    horner(p, r, 1.0 / 5040.0);
+    horner(p, r, 1.0 / 720.0);
+    horner(p, r, 1.0 / 120.0);
+    horner(p, r, 1.0 / 24.0);
+    horner(p, r, 1.0 / 6.0);
+    horner(p, r, 0.5);
+    horner(p, r, 1.0);
+    horner(p, r, 1.0);
+    FORN p[i] = ldexp(p[i], (int)k[i]);
+    return p;
 }
 
 // x^(-1/3) for positive normal x within float range: v_log_f32/v_exp_f32 seed (~1e-6) + two Newton steps
 // y <- y (4 - x y^3)/3 (error -> 2 e^2): ~1 ulp.
-MP_DEV double rcbrt_fast(double x) {
-    double y = (double)__builtin_amdgcn_exp2f(-0.33333333f * __builtin_amdgcn_logf((float)x));
-    const double x3 = x * (1.0 / 3.0);
-    double y3 = y * y * y;
-    y = y * fma(-x3, y3, 4.0 / 3.0);
-    y3 = y * y * y;
-    y = y * fma(-x3, y3, 4.0 / 3.0);
-    return y;
-}
-
-// x^(-2/7) for positive normal x within float range: y = (x^2)^(-1/7), Newton y <- y (8 - x^2 y^7)/7 (error -> 4 e^2)
-MP_DEV double pow_m2_7_fast(double x) {
-    double y = (double)__builtin_amdgcn_exp2f(-0.28571429f * __builtin_amdgcn_logf((float)x));
-    const double z7 = (x * x) * (1.0 / 7.0);
+template <int N>
+MP_DEV Vd<N> rcbrt_fast(const Vd<N> &x) {
+    Vd<N> y, x3, y3;
+    FORN y[i] = (double)__builtin_amdgcn_exp2f(-0.33333333f * __builtin_amdgcn_logf((float)x[i]));
+    FORN x3[i] = x[i] * (1.0 / 3.0);
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
-        const double y2 = y * y, y4 = y2 * y2;
-        const double y7 = (y4 * y2) * y;
-        y = y * fma(-z7, y7, 8.0 / 7.0);
+        FORN y3[i] = y[i] * y[i];
+        FORN y3[i] = y3[i] * y[i];
+        FORN y3[i] = fma(-x3[i], y3[i], 4.0 / 3.0);
+        FORN y[i] = y[i] * y3[i];
     }
     return y;
 }
 
-// natural log of a positive normal number
-MP_DEV double log_fast(double x) {
-    int e = __builtin_amdgcn_frexp_exp(x);
-    double m = __builtin_amdgcn_frexp_mant(x);    // [0.5, 1)
-    const bool lt = m < 0.70710678118654752440;
-    m = lt ? 2.0 * m : m;                         // [sqrt(1/2), sqrt(2))
-    e = lt ? e - 1 : e;
-    const double f = m - 1.0;
-    const double s = f * rcp_fast(2.0 + f);       // |s| <= 0.1716
-    const double z = s * s;
-    double p = 1.0 / 21.0;                        // atanh series: log(m) = 2s(1 + z/3 + z^2/5 + ...)
-    p = fma3(p, z, 1.0 / 19.0);
-    p = fma3(p, z, 1.0 / 17.0);
-    p = fma3(p, z, 1.0 / 15.0);
-    p = fma3(p, z, 1.0 / 13.0);
-    p = fma3(p, z, 1.0 / 11.0);
-    p = fma3(p, z, 1.0 / 9.0);
-    p = fma3(p, z, 1.0 / 7.0);
-    p = fma3(p, z, 1.0 / 5.0);
-    p = fma3(p, z, 1.0 / 3.0);
-    p = fma3(p, z, 1.0);
-    return fma((double)e, 6.93147180559945309417e-01, 2.0 * s * p);
+// x^(-2/7) for positive normal x within float range: y = (x^2)^(-1/7), Newton y <- y (8 - x^2 y^7)/7 (error -> 4 e^2)
+template <int N>
+MP_DEV Vd<N> pow_m2_7_fast(const Vd<N> &x) {
+    Vd<N> y, z7, y2, y4, y7;
+    FORN y[i] = (double)__builtin_amdgcn_exp2f(-0.28571429f * __builtin_amdgcn_logf((float)x[i]));
+    FORN z7[i] = (x[i] * x[i]) * (1.0 / 7.0);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        FORN y2[i] = y[i] * y[i];
+        FORN y4[i] = y2[i] * y2[i];
+        FORN y7[i] = y4[i] * y2[i];
+        FORN y7[i] = y7[i] * y[i];
+        FORN y7[i] = fma(-z7[i], y7[i], 8.0 / 7.0);
+        FORN y[i] = y[i] * y7[i];
+    }
+    return y;
 }
 
 // ---------------------------------------------------------------- phi functions
 // phi_j(z) = sum_k z^k/(k+j)!  : phi_1 = (e^z-1)/z, phi_{j+1} = (phi_j - 1/j!)/z
+template <int N>
 struct Phi {
-    double e, p1, p2, p3, p4;
+    Vd<N> e, p1, p2, p3, p4;
 };
 
-MP_DEV Phi phi1234(double z) {
+template <int N>
+MP_DEV Phi<N> phi1234(const Vd<N> &z) {
     // Taylor series of phi_4 for |z| < 1/2 (13 terms: < 2e-17 relative), closed forms elsewhere
-    double s = 1.0 / 20922789888000.0;            // 1/16!
-    s = fma3(s, z, 1.0 / 1307674368000.0);         // 1/15!
-    s = fma3(s, z, 1.0 / 87178291200.0);           // 1/14!
-    s = fma3(s, z, 1.0 / 6227020800.0);            // 1/13!
-    s = fma3(s, z, 1.0 / 479001600.0);             // 1/12!
-    s = fma3(s, z, 1.0 / 39916800.0);              // 1/11!
-    s = fma3(s, z, 1.0 / 3628800.0);               // 1/10!
-    s = fma3(s, z, 1.0 / 362880.0);                // 1/9!
-    s = fma3(s, z, 1.0 / 40320.0);                 // 1/8!
-    s = fma3(s, z, 1.0 / 5040.0);                  // 1/7!
-    s = fma3(s, z, 1.0 / 720.0);                   // 1/6!
-    s = fma3(s, z, 1.0 / 120.0);                   // 1/5!
-    s = fma3(s, z, 1.0 / 24.0);                    // 1/4!
-    Phi r;
+    Vd<N> s;
+    FORN s[i] = 1.0 / 20922789888000.0;           // 1/16!
+    horner(s, z, 1.0 / 1307674368000.0);          // 1/15!
+    horner(s, z, 1.0 / 87178291200.0);            // 1/14!
+    horner(s, z, 1.0 / 6227020800.0);             // 1/13!
+    horner(s, z, 1.0 / 479001600.0);              // 1/12!
+    horner(s, z, 1.0 / 39916800.0);               // 1/11!
+    horner(s, z, 1.0 / 3628800.0);                // 1/10!
+    horner(s, z, 1.0 / 362880.0);                 // 1/9!
+    horner(s, z, 1.0 / 40320.0);                  // 1/8!
+    horner(s, z, 1.0 / 5040.0);                   // 1/7!
+    horner(s, z, 1.0 / 720.0);                    // 1/6!
+    horner(s, z, 1.0 / 120.0);                    // 1/5!
+    horner(s, z, 1.0 / 24.0);                     // 1/4!
+    Phi<N> r;
     r.p4 = s;
-    r.p3 = fma(z, s, 1.0 / 6.0);
-    r.p2 = fma(z, r.p3, 0.5);
-    r.p1 = fma(z, r.p2, 1.0);
-    r.e = fma(z, r.p1, 1.0);
-    const bool big = !(fabs(z) < 0.5);
-    if (__any(big)) {                              // wave-uniform: only stiff / late-time tiles pay for this
-        const double ce = exp_fast(fmax(z, -750.0));
-        const double rz = rcp_fast(big ? z : 1.0);
-        const double c1 = (ce - 1.0) * rz;
-        const double c2 = (c1 - 1.0) * rz;
-        const double c3 = (c2 - 0.5) * rz;
-        const double c4 = (c3 - 1.0 / 6.0) * rz;
-        r.e = big ? ce : r.e;
-        r.p1 = big ? c1 : r.p1;
-        r.p2 = big ? c2 : r.p2;
-        r.p3 = big ? c3 : r.p3;
-        r.p4 = big ? c4 : r.p4;
+    FORN r.p3[i] = fma(z[i], s[i], 1.0 / 6.0);
+    FORN r.p2[i] = fma(z[i], r.p3[i], 0.5);
+    FORN r.p1[i] = fma(z[i], r.p2[i], 1.0);
+    FORN r.e[i] = fma(z[i], r.p1[i], 1.0);
+    Vb<N> big;
+    bool any_big = false;
+    FORN { big[i] = !(fabs(z[i]) < 0.5); any_big = any_big || big[i]; }
+    if (__any(any_big)) {                          // wave-uniform: only stiff / late-time tiles pay for this
+        Vd<N> zc, zs;
+        FORN zc[i] = fmax(z[i], -750.0);
+        FORN zs[i] = big[i] ? z[i] : 1.0;
+        const Vd<N> ce = exp_fast(zc);
+        const Vd<N> rz = rcp_fast(zs);
+        FORN {
+            const double c1 = (ce[i] - 1.0) * rz[i];
+            const double c2 = (c1 - 1.0) * rz[i];
+            const double c3 = (c2 - 0.5) * rz[i];
+            const double c4 = (c3 - 1.0 / 6.0) * rz[i];
+            r.e[i] = big[i] ? ce[i] : r.e[i];
+            r.p1[i] = big[i] ? c1 : r.p1[i];
+            r.p2[i] = big[i] ? c2 : r.p2[i];
+            r.p3[i] = big[i] ? c3 : r.p3[i];
+            r.p4[i] = big[i] ? c4 : r.p4[i];
+        }
     }
     return r;
 }
 
 // h * int_0^1 e^{z(1-theta)} P(theta) dtheta for the cubic P through the node values v0..v3 at
 // t_{j+1}, t_j, t_{j-1}, t_{j-2} (quadrature matrix W of the geometric grid, DevShared::eamW)
-MP_DEV double eam4_increment(const DevShared &sh, const Phi &p, double h, double v0, double v1, double v2, double v3) {
-    double acc = 0.0;
-    const double ph[4] = {p.p1, p.p2, p.p3, p.p4};
+template <int N>
+MP_DEV Vd<N> eam4_increment(const DevShared &sh, const Phi<N> &p, const Vd<N> &h, const Vd<N> &v0, const Vd<N> &v1,
+                            const Vd<N> &v2, const Vd<N> &v3) {
+    Vd<N> acc, g;
+    FORN acc[i] = 0.0;
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-        const double g = fma(sh.eamW[0][m], v0, fma(sh.eamW[1][m], v1, fma(sh.eamW[2][m], v2, sh.eamW[3][m] * v3)));
-        acc = fma(ph[m], g, acc);
+        const Vd<N> &ph = m == 0 ? p.p1 : m == 1 ? p.p2 : m == 2 ? p.p3 : p.p4;
+        FORN g[i] = sh.eamW[3][m] * v3[i];
+        FORN g[i] = fma(sh.eamW[2][m], v2[i], g[i]);
+        FORN g[i] = fma(sh.eamW[1][m], v1[i], g[i]);
+        FORN g[i] = fma(sh.eamW[0][m], v0[i], g[i]);
+        FORN acc[i] = fma(ph[i], g[i], acc[i]);
     }
-    return h * acc;
+    FORN acc[i] = h[i] * acc[i];
+    return acc;
 }
 
 // ---------------------------------------------------------------- per-walker constants
@@ -255,114 +296,121 @@ struct Walker {
     double dipeff, propeff, f_beam;
 };
 
-// What the omega equation needs to know about the disc at one time point (all omega-independent,
+// What the omega equation needs to know about the disc at the N time points of a lane (all omega-independent,
 // computed once per tile in the time-parallel Mdisc phase).
+template <int N>
 struct DiscPt {
-    double mdot;  // Mdisc/tvisc
-    double rmu;   // uncapped Alfven radius, code/synthetic_datasets/funcs.py:105-106
-    double squ;   // sqrt(rmu)
-    double qu;    // rmu^1.5/sqrt(GM): uncapped fastness = omega*qu
+    Vd<N> mdot;  // Mdisc/tvisc
+    Vd<N> rmu;   // uncapped Alfven radius, code/synthetic_datasets/funcs.py:105-106
+    Vd<N> squ;   // sqrt(rmu)
+    Vd<N> qu;    // rmu^1.5/sqrt(GM): uncapped fastness = omega*qu
 };
 
-MP_DEV DiscPt disc_point(const DevShared &sh, const Walker &w, double Mdisc) {
-    DiscPt p;
-    p.mdot = Mdisc * w.inv_tau;
-    p.rmu = w.Crm * pow_m2_7_fast(p.mdot);
-    p.squ = p.rmu * rsqrt_fast(p.rmu);
-    p.qu = p.rmu * p.squ * sh.inv_sqrtGM;
+template <int N>
+MP_DEV DiscPt<N> disc_point(const DevShared &sh, const Walker &w, const Vd<N> &Mdisc) {
+    DiscPt<N> p;
+    FORN p.mdot[i] = Mdisc[i] * w.inv_tau;
+    const Vd<N> pw_ = pow_m2_7_fast(p.mdot);
+    FORN p.rmu[i] = w.Crm * pw_[i];                                 // Crm * mdot^(-2/7)
+    const Vd<N> rs = rsqrt_fast(p.rmu);
+    FORN p.squ[i] = p.rmu[i] * rs[i];
+    FORN p.qu[i] = p.rmu[i] * p.squ[i] * sh.inv_sqrtGM;
     return p;
 }
 
-MP_DEV DiscPt disc_prev(const DiscPt &p, const DiscPt &first) {  // the previous lane's point (lane 0: `first`)
-    DiscPt r;
-    r.mdot = lane_prev(p.mdot, first.mdot);
-    r.rmu = lane_prev(p.rmu, first.rmu);
-    r.squ = lane_prev(p.squ, first.squ);
-    r.qu = lane_prev(p.qu, first.qu);
-    return r;
-}
-
-MP_DEV DiscPt disc_bcast(const DiscPt &p, int src) {
-    DiscPt r;
-    r.mdot = lane_bcast(p.mdot, src);
-    r.rmu = lane_bcast(p.rmu, src);
-    r.squ = lane_bcast(p.squ, src);
-    r.qu = lane_bcast(p.qu, src);
-    return r;
-}
-
 // fallback accretion rate Mdotfb(t), code/synthetic_datasets/funcs.py:128
-MP_DEV double mdot_fb(const Walker &w, double t) {
-    const double u = fma(t, w.inv_tfb, 1.0);                        // (t + tfb)/tfb >= 1
-    const double r = rcbrt_fast(u), r2 = r * r;
-    return w.S_amp * (r2 * r2 * r);                                 // u^(-5/3)
+template <int N>
+MP_DEV Vd<N> mdot_fb(const Walker &w, const Vd<N> &t) {
+    Vd<N> u;
+    FORN u[i] = fma(t[i], w.inv_tfb, 1.0);                          // (t + tfb)/tfb >= 1
+    const Vd<N> r = rcbrt_fast(u);
+    Vd<N> out;
+    FORN { const double r2 = r[i] * r[i]; out[i] = w.S_amp * (r2 * r2 * r[i]); }   // u^(-5/3)
+    return out;
 }
 
 // Radii / fastness / switch shared by the ODE right-hand side and the luminosity stage
 // (code/synthetic_datasets/funcs.py:105-123 / magnetar/funcs.py:64-84 in simplified algebra):
 //   Rm = min(rmu, k c/omega);  fastness = (Rm/Rc)^1.5 = omega Rm^1.5/sqrt(GM);  tanh(n (fastness-1)).
+template <int N>
 struct Flow {
-    double inv_om, Rm, sq, fast, e, r, th;
-    bool capped, big;
+    Vd<N> inv_om, Rm, sq, fast, e, r, th;
+    Vb<N> capped, big;
 };
 
-MP_DEV Flow flow_state(const Walker &w, double n, const DiscPt &p, double om) {
-    Flow f;
-    const double y = rsqrt_fast(om);
-    f.inv_om = y * y;
-    const double rlc = w.kc * f.inv_om;
-    f.capped = p.rmu >= rlc;                                        // Rm >= k*Rlc -> Rm = k*Rlc
-    f.Rm = f.capped ? rlc : p.rmu;
-    f.sq = f.capped ? w.sqrt_kc * y : p.squ;                        // sqrt(Rm)
-    f.fast = f.capped ? w.Kc * y : om * p.qu;
-    const double x = fma(n, f.fast, -n);
-    f.e = exp_fast(fmax(-2.0 * fabs(x), -750.0));
-    f.r = rcp_fast(1.0 + f.e);
-    f.th = copysign((1.0 - f.e) * f.r, x);                          // tanh(x) = eta2 - eta1
-    f.big = f.Rm >= kR;
+template <int N>
+MP_DEV Flow<N> flow_state(const Walker &w, double n, const DiscPt<N> &p, const Vd<N> &om) {
+    Flow<N> f;
+    const Vd<N> y = rsqrt_fast(om);
+    Vd<N> x, ea, den;
+    FORN f.inv_om[i] = y[i] * y[i];
+    FORN {
+        const double rlc = w.kc * f.inv_om[i];
+        f.capped[i] = p.rmu[i] >= rlc;                              // Rm >= k*Rlc -> Rm = k*Rlc
+        f.Rm[i] = f.capped[i] ? rlc : p.rmu[i];
+    }
+    FORN f.sq[i] = f.capped[i] ? w.sqrt_kc * y[i] : p.squ[i];       // sqrt(Rm)
+    FORN f.fast[i] = f.capped[i] ? w.Kc * y[i] : om[i] * p.qu[i];
+    FORN x[i] = fma(n, f.fast[i], -n);
+    FORN ea[i] = fmax(-2.0 * fabs(x[i]), -750.0);
+    f.e = exp_fast(ea);
+    FORN den[i] = 1.0 + f.e[i];
+    f.r = rcp_fast(den);
+    FORN f.th[i] = copysign((1.0 - f.e[i]) * f.r[i], x[i]);        // tanh(x) = eta2 - eta1
+    FORN f.big[i] = f.Rm[i] >= kR;
     return f;
 }
 
 // d(omega)/dt, code/synthetic_datasets/funcs.py:119,131-140; lam = d(omega_dot)/d(omega)
-template <bool WANT_LAM>
-MP_DEV double omega_rhs(const DevShared &sh, const Walker &w, const DiscPt &p, double om, double &rot, double &lam) {
-    const Flow f = flow_state(w, sh.cfg.n_ode, p, om);
-    const double om2 = om * om;
-    rot = sh.crot * om2;
-    const bool brk = rot > 0.27;                                    // break-up: Nacc = 0
-    const double arm = w.armI * (f.big ? f.sq : sh.sqrtR);          // sqrt(GM*max(Rm,R))/I
-    const double nacc = brk ? 0.0 : -arm * p.mdot * f.th;           // Nacc/I ; Macc - Mprop = -tanh * mdot
-    if (WANT_LAM) {
-        const double dfast = (f.capped ? -0.5 : 1.0) * f.fast * f.inv_om;
-        const double dth = sh.cfg.n_ode * (4.0 * f.e * f.r * f.r) * dfast;   // n sech^2 dfast
-        const double darm = (f.capped && f.big) ? -0.5 * arm * f.inv_om : 0.0;
-        const double dn = brk ? 0.0 : -p.mdot * fma(darm, f.th, arm * dth);
-        lam = fma(-3.0 * w.DI, om2, dn);
+template <bool WANT_LAM, int N>
+MP_DEV Vd<N> omega_rhs(const DevShared &sh, const Walker &w, const DiscPt<N> &p, const Vd<N> &om, Vd<N> &rot,
+                       Vd<N> &lam) {
+    const Flow<N> f = flow_state(w, sh.cfg.n_ode, p, om);
+    Vd<N> out;
+    FORN {
+        const double om2 = om[i] * om[i];
+        rot[i] = sh.crot * om2;
+        const bool brk = rot[i] > 0.27;                                    // break-up: Nacc = 0
+        const double arm = w.armI * (f.big[i] ? f.sq[i] : sh.sqrtR);       // sqrt(GM*max(Rm,R))/I
+        const double nacc = brk ? 0.0 : -arm * p.mdot[i] * f.th[i];        // Nacc/I ; Macc - Mprop = -tanh * mdot
+        if (WANT_LAM) {
+            const double dfast = (f.capped[i] ? -0.5 : 1.0) * f.fast[i] * f.inv_om[i];
+            const double dth = sh.cfg.n_ode * (4.0 * f.e[i] * f.r[i] * f.r[i]) * dfast;   // n sech^2 dfast
+            const double darm = (f.capped[i] && f.big[i]) ? -0.5 * arm * f.inv_om[i] : 0.0;
+            const double dn = brk ? 0.0 : -p.mdot[i] * fma(darm, f.th[i], arm * dth);
+            lam[i] = fma(-3.0 * w.DI, om2, dn);
+        }
+        out[i] = fma(-w.DI * om2, om[i], nacc);
     }
-    return fma(-w.DI * om2, om, nacc);
+    return out;
 }
 
-// luminosities (erg/s) at one grid point, reference luminosity stage
+// luminosities (erg/s) at the lane's N grid points, reference luminosity stage
 // (code/synthetic_datasets/funcs.py:204-229, magnetar/funcs.py:191-210)
-MP_DEV void luminosity(const DevShared &sh, const Walker &w, const DiscPt &p, double om, double &Ltot,
-                       double &Lprop, double &Ldip) {
-    const Flow f = flow_state(w, sh.cfg.n_lum, p, om);
-    const double eta2 = f.th >= 0.0 ? f.r : f.e * f.r;              // 0.5*(1 + tanh x)
-    const double om2 = om * om;
-    const double rot = sh.crot * om2;
-    const double arm = sh.sqrtGM * (f.big ? f.sq : sh.sqrtR);
-    const double Nacc = rot > sh.cfg.nacc_lum_threshold ? 0.0 : -arm * p.mdot * f.th;
-    double ld = w.dipeff * (w.D * om2 * om2);
-    if (ld <= 0.0) ld = 0.0;
-    if (!isfinite(ld)) ld = 0.0;
-    double lp = -Nacc * om;
-    if (sh.cfg.lprop_gm_term) lp -= sh.GM * rcp_fast(f.Rm) * eta2 * p.mdot;
-    lp *= w.propeff;
-    if (lp <= 0.0) lp = 0.0;
-    if (!isfinite(lp)) lp = 0.0;
-    Ltot = w.f_beam * (ld + lp);
-    Lprop = lp;
-    Ldip = ld;
+template <int N>
+MP_DEV void luminosity(const DevShared &sh, const Walker &w, const DiscPt<N> &p, const Vd<N> &om, Vd<N> &Ltot,
+                       Vd<N> &Lprop, Vd<N> &Ldip) {
+    const Flow<N> f = flow_state(w, sh.cfg.n_lum, p, om);
+    Vd<N> irm;
+    if (sh.cfg.lprop_gm_term) irm = rcp_fast(f.Rm);
+    FORN {
+        const double eta2 = f.th[i] >= 0.0 ? f.r[i] : f.e[i] * f.r[i];     // 0.5*(1 + tanh x)
+        const double om2 = om[i] * om[i];
+        const double rot = sh.crot * om2;
+        const double arm = sh.sqrtGM * (f.big[i] ? f.sq[i] : sh.sqrtR);
+        const double Nacc = rot > sh.cfg.nacc_lum_threshold ? 0.0 : -arm * p.mdot[i] * f.th[i];
+        double ld = w.dipeff * (w.D * om2 * om2);
+        if (ld <= 0.0) ld = 0.0;
+        if (!isfinite(ld)) ld = 0.0;
+        double lp = -Nacc * om[i];
+        if (sh.cfg.lprop_gm_term) lp -= sh.GM * irm[i] * eta2 * p.mdot[i];
+        lp *= w.propeff;
+        if (lp <= 0.0) lp = 0.0;
+        if (!isfinite(lp)) lp = 0.0;
+        Ltot[i] = w.f_beam * (ld + lp);
+        Lprop[i] = lp;
+        Ldip[i] = ld;
+    }
 }
 
 constexpr int kMaxSweepsMargin = 16;  // sweeps allowed beyond the tile length (after which every step is exact)
@@ -371,7 +419,7 @@ constexpr double kSweepTol = 1e-9;  // relative change of the step-end values th
 // ---------------------------------------------------------------- the kernel
 // SPL = consecutive steps owned by one lane; a tile is 64*SPL steps.
 template <bool CURVES, int SPL>
-__global__ __launch_bounds__(64, 1) void lnprob_kernel(const DevShared sh, const LaunchArgs a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, SPL >= 4 ? 1 : 2))) void lnprob_kernel(const DevShared sh, const LaunchArgs a) {
     constexpr int kSPL = SPL, kTile = 64 * SPL, kMaxSweeps = kTile + kMaxSweepsMargin;
     const int n_tiles = (sh.n_grid - 1 + kTile - 1) / kTile;
     const int walker = blockIdx.x;
@@ -433,19 +481,26 @@ __global__ __launch_bounds__(64, 1) void lnprob_kernel(const DevShared sh, const
     double t_s = t0;
     double M_s = par[2] * kMsol;                         // initial conditions, code/synthetic_datasets/funcs.py:66-69
     double om_s = (2.0 * M_PI) / (1.0e-3 * par[1]);
-    double cS0 = mdot_fb(w, t0), cS1 = mdot_fb(w, t0 * sh.inv_q), cS2 = mdot_fb(w, t0 * sh.inv_q * sh.inv_q);
+    double cS0, cS1, cS2;
+    {
+        const Vd<3> tg{{t0, t0 * sh.inv_q, t0 * sh.inv_q * sh.inv_q}};     // the grid continued backwards
+        const Vd<3> Sg = mdot_fb(w, tg);
+        cS0 = Sg[0]; cS1 = Sg[1]; cS2 = Sg[2];
+    }
     double cf0, cf1, cf2, cw1 = om_s, cw2 = om_s, cw3 = om_s, cw4 = om_s;   // (omega_dot, omega) history; cw0 == om_s (cw3, cw4: predictor only)
     double L_s, Lp_s, Ld_s;
     {
-        const DiscPt d_s = disc_point(sh, w, M_s);
-        double rot0, dummy;
-        cf0 = omega_rhs<false>(sh, w, d_s, om_s, rot0, dummy);
+        const Vd<1> Mv{{M_s}}, ov{{om_s}};
+        const DiscPt<1> d_s = disc_point(sh, w, Mv);
+        Vd<1> rot0, dummy, Lt0, Lp0, Ld0;
+        cf0 = omega_rhs<false>(sh, w, d_s, ov, rot0, dummy)[0];
         cf1 = cf2 = cf0;
         if (status == MP_STATUS_OK) {
             if (!(isfinite(M_s) && isfinite(om_s)) || M_s <= 0.0 || om_s <= 0.0) status = MP_STATUS_NONFINITE;
-            else if (rot0 > 0.27) status = MP_STATUS_FLAG;
+            else if (rot0[0] > 0.27) status = MP_STATUS_FLAG;
         }
-        luminosity(sh, w, d_s, om_s, L_s, Lp_s, Ld_s);
+        luminosity(sh, w, d_s, ov, Lt0, Lp0, Ld0);
+        L_s = Lt0[0]; Lp_s = Lp0[0]; Ld_s = Ld0[0];
     }
 
     const int dsid = a.ds_id ? a.ds_id[walker] : 0;
@@ -484,8 +539,8 @@ __global__ __launch_bounds__(64, 1) void lnprob_kernel(const DevShared sh, const
 
         for (int tile = 0; tile < n_tiles; ++tile) {
             const int i0 = tile * kTile + lane * kSPL;   // this lane's first step: tgrid[i0] -> tgrid[i0+1]
-            double tb[kSPL], h[kSPL];
-            bool active[kSPL];
+            Vd<kSPL> tb, h;
+            Vb<kSPL> active;
 #pragma unroll
             for (int s = 0; s < kSPL; ++s) {
                 tb[s] = tb_next[s];
@@ -500,21 +555,29 @@ __global__ __launch_bounds__(64, 1) void lnprob_kernel(const DevShared sh, const
 
             // ---------------- Mdisc: exponential Adams-Moulton step (explicit: the source is known) + affine scan.
             // E*[k]: values at the three grid points before this lane's first step (k = 0,1,2) and at its step ends (k = 3+s).
-            double M1[kSPL];
+            Vd<kSPL> M1;
             double ES[kSPL + 3];
             {
+                const Vd<kSPL> S1 = mdot_fb(w, tb);
 #pragma unroll
-                for (int s = 0; s < kSPL; ++s) ES[3 + s] = mdot_fb(w, tb[s]);
+                for (int s = 0; s < kSPL; ++s) ES[3 + s] = S1[s];
                 ES[2] = lane_prev(ES[kSPL + 2], cS0);
                 ES[1] = lane_prev(ES[kSPL + 1], cS1);
                 ES[0] = lane_prev(ES[kSPL + 0], cS2);
-                double am[kSPL], bm[kSPL];
+                Vd<kSPL> zm, v0, v1, v2, v3;
+#pragma unroll
+                for (int s = 0; s < kSPL; ++s) {
+                    zm[s] = -h[s] * w.inv_tau;
+                    v0[s] = ES[3 + s]; v1[s] = ES[2 + s]; v2[s] = ES[1 + s]; v3[s] = ES[s];
+                }
+                const Phi<kSPL> pm = phi1234(zm);
+                const Vd<kSPL> inc = eam4_increment(sh, pm, h, v0, v1, v2, v3);
+                Vd<kSPL> am, bm;
                 double A = 1.0, B = 0.0;                  // composition of this lane's step maps
 #pragma unroll
                 for (int s = 0; s < kSPL; ++s) {
-                    const Phi pm = phi1234(-h[s] * w.inv_tau);
-                    am[s] = active[s] ? pm.e : 1.0;
-                    bm[s] = active[s] ? eam4_increment(sh, pm, h[s], ES[3 + s], ES[2 + s], ES[1 + s], ES[s]) : 0.0;
+                    am[s] = active[s] ? pm.e[s] : 1.0;
+                    bm[s] = active[s] ? inc[s] : 0.0;
                     B = fma(am[s], B, bm[s]);
                     A = A * am[s];
                 }
@@ -524,15 +587,13 @@ __global__ __launch_bounds__(64, 1) void lnprob_kernel(const DevShared sh, const
 #pragma unroll
                 for (int s = 0; s < kSPL; ++s) { Mc = fma(am[s], Mc, bm[s]); M1[s] = Mc; }
             }
-            DiscPt d1[kSPL];
-#pragma unroll
-            for (int s = 0; s < kSPL; ++s) d1[s] = disc_point(sh, w, M1[s]);
+            const DiscPt<kSPL> d1 = disc_point(sh, w, M1);
 
-            // ---------------- omega: predictor = quadratic extrapolation of the last three grid values in the
-            // step index (the grid is logarithmic, so power laws are smooth in the index) ...
-            double wg[kSPL];                              // current guess of omega at this lane's step ends
+            // ---------------- omega: predictor = extrapolation of the last five grid values in the step index
+            // (the grid is logarithmic, so power laws are smooth in the index) ...
+            Vd<kSPL> wg;                                  // current guess of omega at this lane's step ends
             {
-                // Newton backward-difference extrapolation (cubic once four grid values exist)
+                // Newton backward-difference extrapolation (quartic once five grid values exist)
                 const double g1 = om_s - cw1, g2 = g1 - (cw1 - cw2);
                 const double d2b = (cw1 - cw2) - (cw2 - cw3);
                 const double g3 = tile == 0 ? 0.0 : g2 - d2b;
@@ -553,15 +614,17 @@ __global__ __launch_bounds__(64, 1) void lnprob_kernel(const DevShared sh, const
             Ew[2] = om_s;
             while (true) {
                 ++sweep;
-                double lam[kSPL];
+#pragma unroll
+                for (int s = 0; s < kSPL; ++s)
+                    if (!(wg[s] > 0.0)) wg[s] = Ew[2] > 0.0 ? Ew[2] : om_s;   // keep the iteration alive after a wild or NaN guess
+                Vd<kSPL> rot, lam;
+                const Vd<kSPL> f1 = omega_rhs<true>(sh, w, d1, wg, rot, lam);
                 bool flg = false;
 #pragma unroll
                 for (int s = 0; s < kSPL; ++s) {
-                    if (!(wg[s] > 0.0)) wg[s] = Ew[2] > 0.0 ? Ew[2] : om_s;   // keep the iteration alive after a wild or NaN guess
-                    double rot;
-                    Ef[3 + s] = omega_rhs<true>(sh, w, d1[s], wg[s], rot, lam[s]);
+                    Ef[3 + s] = f1[s];
                     Ew[3 + s] = wg[s];
-                    flg = flg || (active[s] && rot > 0.27);
+                    flg = flg || (active[s] && rot[s] > 0.27);
                 }
                 // break-up reached by an iterate that is no longer a wild guess: the reference's 'flag'
                 flagged |= __ballot(settled && flg);
@@ -574,16 +637,23 @@ __global__ __launch_bounds__(64, 1) void lnprob_kernel(const DevShared sh, const
                 Ef[2] = lane_prev(Ef[kSPL + 2], cf0);  Ew[2] = lane_prev(Ew[kSPL + 2], om_s);
                 Ef[1] = lane_prev(Ef[kSPL + 1], h1);   Ew[1] = lane_prev(Ew[kSPL + 1], u1);
                 Ef[0] = lane_prev(Ef[kSPL + 0], h2);   Ew[0] = lane_prev(Ew[kSPL + 0], u2);
-                double aw[kSPL], bw[kSPL];
+                Vd<kSPL> zw, n0, n1, n2, n3;
+#pragma unroll
+                for (int s = 0; s < kSPL; ++s) {
+                    zw[s] = h[s] * lam[s];
+                    n0[s] = fma(-lam[s], Ew[3 + s], Ef[3 + s]);
+                    n1[s] = fma(-lam[s], Ew[2 + s], Ef[2 + s]);
+                    n2[s] = fma(-lam[s], Ew[1 + s], Ef[1 + s]);
+                    n3[s] = fma(-lam[s], Ew[s], Ef[s]);
+                }
+                const Phi<kSPL> pw_ = phi1234(zw);
+                const Vd<kSPL> inc = eam4_increment(sh, pw_, h, n0, n1, n2, n3);
+                Vd<kSPL> aw, bw;
                 double A = 1.0, B = 0.0;
 #pragma unroll
                 for (int s = 0; s < kSPL; ++s) {
-                    const Phi pw_ = phi1234(h[s] * lam[s]);
-                    aw[s] = active[s] ? pw_.e : 1.0;
-                    bw[s] = active[s] ? eam4_increment(sh, pw_, h[s], fma(-lam[s], Ew[3 + s], Ef[3 + s]),
-                                                       fma(-lam[s], Ew[2 + s], Ef[2 + s]), fma(-lam[s], Ew[1 + s], Ef[1 + s]),
-                                                       fma(-lam[s], Ew[s], Ef[s]))
-                                      : 0.0;
+                    aw[s] = active[s] ? pw_.e[s] : 1.0;
+                    bw[s] = active[s] ? inc[s] : 0.0;
                     B = fma(aw[s], B, bw[s]);
                     A = A * aw[s];
                 }
@@ -624,16 +694,15 @@ __global__ __launch_bounds__(64, 1) void lnprob_kernel(const DevShared sh, const
             }
 
             // ---------------- luminosity at the step ends, light curve through LDS, chi^2
-            double Lt[kSPL];
+            Vd<kSPL> Lt, Lp, Ld;
+            luminosity(sh, w, d1, wg, Lt, Lp, Ld);
 #pragma unroll
             for (int s = 0; s < kSPL; ++s) {
-                double Lp, Ld;
-                luminosity(sh, w, d1[s], wg[s], Lt[s], Lp, Ld);
                 if (CURVES && active[s]) {
                     const size_t o = row + (size_t)(i0 + s) + 1;
                     if (a.ltot) a.ltot[o] = Lt[s] / 1.0e50;
-                    if (a.lprop) a.lprop[o] = Lp / 1.0e50;
-                    if (a.ldip) a.ldip[o] = Ld / 1.0e50;
+                    if (a.lprop) a.lprop[o] = Lp[s] / 1.0e50;
+                    if (a.ldip) a.ldip[o] = Ld[s] / 1.0e50;
                     if (a.mdisc) a.mdisc[o] = M1[s];
                     if (a.omega) a.omega[o] = wg[s];
                 }

@@ -24,9 +24,10 @@ class ShardedLnprob:
     the same full `pars` (replicated proposals: no scatter needed) and gets the full lnprob vector.
     """
 
-    def __init__(self, eval_local, group=None):
+    def __init__(self, eval_local, group=None, via_host=False):
         self.eval_local = eval_local
         self.group = group
+        self.via_host = via_host      # gather through host memory (gloo rehearsal of the multi-GPU path)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self._buf = None
@@ -41,5 +42,10 @@ class ShardedLnprob:
             local[: hi - lo] = self.eval_local(pars[lo:hi])
         if self._buf is None or self._buf.numel() != per * self.world or self._buf.device != pars.device:
             self._buf = torch.empty(per * self.world, dtype=torch.float64, device=pars.device)
-        dist.all_gather_into_tensor(self._buf, local, group=self.group)
+        if self.via_host:
+            hbuf = torch.empty(per * self.world, dtype=torch.float64)
+            dist.all_gather_into_tensor(hbuf, local.cpu(), group=self.group)
+            self._buf.copy_(hbuf)
+        else:
+            dist.all_gather_into_tensor(self._buf, local, group=self.group)
         return self._buf[:n]
