@@ -97,6 +97,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=20261003)
+    ap.add_argument("--no-mcmc", action="store_true", help="skip the ensemble-sampler leg (N=1 only)")
+    ap.add_argument("--mcmc-steps", type=int, default=100)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend; gloo is for rehearsing N>1 on a one-GPU box (ranks share the card, "
                          "lnprob slices are gathered through host memory) and is never a reported configuration")
@@ -187,6 +189,21 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
+    mcmc = None
+    if world == 1 and not a.no_mcmc:
+        # the same metric through the device-resident ensemble sampler (fused stretch-move half-steps): walkers x steps / s
+        from magprop_amd import EnsembleSampler
+        es = EnsembleSampler(a.nwalk, 6, x, y, yerr, seed=a.seed, device=dev_index)
+        p0 = (truth + 1.0e-4 * torch.randn(a.nwalk, 6, dtype=torch.float64, device=dev, generator=gen)).cpu().numpy()
+        es.run_mcmc(p0, 5, store=False)
+        tm = time.perf_counter()
+        es.run_mcmc(None, a.mcmc_steps, store=False)
+        tm = time.perf_counter() - tm
+        mcmc = {"walkers": a.nwalk, "steps": a.mcmc_steps, "walker_steps_per_sec": a.nwalk * a.mcmc_steps / tm,
+                "ms_per_step": 1e3 * tm / a.mcmc_steps, "acceptance_fraction": float(es.acceptance_fraction.mean()),
+                "note": "emcee-style stretch move, 2 fused kernel launches per step (propose+lnprob+accept+store)"}
+        es.close()
+
     kern_ms = np.array([ev0[i].elapsed_time(ev1[i]) for i in range(a.warmup, total)])
     n_flag = int((status != 0).sum().item())
     first = float(full[0].item())
@@ -224,6 +241,8 @@ def main():
             "host_enqueue_ms_per_step": 1e3 * t_host / a.steps,
             "check": {"lnprob0": first, "n_not_ok": n_flag, "checksum": float(checksum.item())},
         }
+        if mcmc is not None:
+            out["ensemble_sampler"] = mcmc
         if cpu is not None:
             out["cpu_baseline"] = cpu
             out["speedup_vs_cpu_baseline"] = value / cpu["value"]

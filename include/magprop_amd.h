@@ -140,6 +140,31 @@ int mp_lnprob_batch_dev(mp_handle *h, const double *d_pars, const int32_t *d_ds_
  */
 int mp_model_lc(mp_handle *h, const double *pars, int ndim, double *out, double *traj, int32_t *status);
 
+/*
+ * Ensemble sampler: emcee's affine-invariant stretch move (Goodman & Weare 2010) with a random red/blue
+ * split per step, as driven by code/synthetic_datasets/synth_mcmc.py:175-185
+ * (em.EnsembleSampler(Nwalk, Npars, lnprob, ...).run_mcmc(pos, Nstep)).  Positions, log-posteriors,
+ * acceptance counters and the chain stay resident on the device; every half-step is ONE kernel launch that
+ * proposes, evaluates the log-posterior, accepts/rejects and stores the chain row.
+ *   n_walkers   walkers per ensemble (even, >= 2*ndim recommended as in emcee)
+ *   n_ensembles independent ensembles advanced together (e.g. one per GRB dataset); ens_ds_id[e] is the
+ *               dataset of ensemble e (NULL: dataset 0 for all)
+ *   a           stretch scale (emcee default 2.0)
+ *   target      0: the magnetar log-posterior of this handle; 1: isotropic unit Gaussian (tests of the move)
+ * Random numbers: Philox4x32-10 keyed by (seed; step, half, walker) for partner / stretch factor / accept;
+ * the split permutations are Fisher-Yates shuffles driven by the same generator on the host.  Same seed => same chain.
+ */
+typedef struct mp_sampler mp_sampler;
+mp_sampler *mp_sampler_create(mp_handle *h, int n_walkers, int n_ensembles, int ndim, const int32_t *ens_ds_id,
+                              uint64_t seed, double a, int target);
+int mp_sampler_destroy(mp_sampler *s);
+/* pos[n_ensembles*n_walkers][ndim] (host): sets the state and evaluates its log-posterior */
+int mp_sampler_set_positions(mp_sampler *s, const double *pos);
+/* n_steps full steps; chain[n_steps][n_total][ndim] and chain_lnprob[n_steps][n_total] (host, both or neither) */
+int mp_sampler_run(mp_sampler *s, int n_steps, double *chain, double *chain_lnprob);
+/* any of the outputs may be NULL */
+int mp_sampler_get_state(mp_sampler *s, double *pos, double *lnprob, int64_t *n_accepted, int64_t *steps_done);
+
 /* wait for everything enqueued on the handle's own stream */
 int mp_synchronize(mp_handle *h);
 

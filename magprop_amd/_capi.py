@@ -22,6 +22,7 @@ EXPORTS = (
     "mp_abi_version", "mp_last_error", "mp_cfg_synth", "mp_cfg_lib", "mp_create", "mp_destroy",
     "mp_set_dataset", "mp_set_prior", "mp_lnprob_batch", "mp_lnprob_batch_dev", "mp_model_lc",
     "mp_synchronize", "mp_device", "mp_stream", "mp_n_grid", "mp_last_mean_sweeps",
+    "mp_sampler_create", "mp_sampler_destroy", "mp_sampler_set_positions", "mp_sampler_run", "mp_sampler_get_state",
 )
 
 
@@ -84,10 +85,18 @@ def lib():
     L.mp_stream.argtypes = [vp]
     L.mp_stream.restype = vp
     L.mp_n_grid.argtypes = [vp]
+    i64p = C.POINTER(C.c_int64)
+    L.mp_sampler_create.restype = vp
+    L.mp_sampler_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, ip, C.c_uint64, C.c_double, C.c_int]
+    L.mp_sampler_destroy.argtypes = [vp]
+    L.mp_sampler_set_positions.argtypes = [vp, dp]
+    L.mp_sampler_run.argtypes = [vp, C.c_int, dp, dp]
+    L.mp_sampler_get_state.argtypes = [vp, dp, dp, i64p, i64p]
     L.mp_last_mean_sweeps.argtypes = [vp]
     L.mp_last_mean_sweeps.restype = C.c_double
     for name in ("mp_destroy", "mp_set_dataset", "mp_set_prior", "mp_lnprob_batch", "mp_lnprob_batch_dev",
-                 "mp_model_lc", "mp_synchronize", "mp_device", "mp_n_grid"):
+                 "mp_model_lc", "mp_synchronize", "mp_device", "mp_n_grid", "mp_sampler_destroy",
+                 "mp_sampler_set_positions", "mp_sampler_run", "mp_sampler_get_state"):
         getattr(L, name).restype = C.c_int
     _lib = L
     return L

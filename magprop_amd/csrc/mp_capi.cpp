@@ -446,6 +446,176 @@ int mp_synchronize(mp_handle *h) {
     return MP_OK;
 }
 
+// ---------------------------------------------------------------- ensemble sampler (stretch move)
+// Philox4x32-10 (same function as in mp_kernels.hip); the host uses it for the random red/blue split.
+static void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t out[4]) {
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+struct mp_sampler {
+    mp_handle *h = nullptr;
+    int n_walkers = 0, n_ensembles = 0, n_total = 0, ndim = 0, target = 0;
+    uint64_t seed = 0;
+    double a = 2.0;
+    uint64_t steps_done = 0;
+    bool have_state = false;
+    DevBuf<double> d_pos, d_lnprob, d_chain, d_chain_lnp;
+    DevBuf<int64_t> d_acc;
+    DevBuf<int32_t> d_perm, d_dsid, d_status;
+};
+
+mp_sampler *mp_sampler_create(mp_handle *h, int n_walkers, int n_ensembles, int ndim, const int32_t *ens_ds_id,
+                              uint64_t seed, double a, int target) {
+    if (!h) { fail(MP_EINVAL, "mp_sampler_create: NULL handle"); return nullptr; }
+    if (n_walkers < 2 || (n_walkers & 1)) { fail(MP_EINVAL, "mp_sampler_create: n_walkers must be even and >= 2"); return nullptr; }
+    if (n_ensembles < 1 || ndim < 1 || ndim > MP_MAX_NDIM || (target == 0 && ndim < 6)) {
+        fail(MP_EINVAL, "mp_sampler_create: bad n_ensembles / ndim");
+        return nullptr;
+    }
+    if (!(a > 1.0)) { fail(MP_EINVAL, "mp_sampler_create: stretch scale a must exceed 1"); return nullptr; }
+    if (target == 0) {
+        for (int e = 0; e < n_ensembles; ++e) {
+            const int d = ens_ds_id ? ens_ds_id[e] : 0;
+            if (d < 0 || d >= MP_MAX_DATASETS || !h->ds[d].set) {
+                fail(MP_ESTATE, "mp_sampler_create: ensemble %d refers to unset dataset %d", e, d);
+                return nullptr;
+            }
+        }
+    }
+    mp_sampler *s = new mp_sampler();
+    s->h = h; s->n_walkers = n_walkers; s->n_ensembles = n_ensembles; s->n_total = n_walkers * n_ensembles;
+    s->ndim = ndim; s->target = target; s->seed = seed; s->a = a;
+    DeviceScope scope(h->device);
+    const size_t nt = (size_t)s->n_total;
+    std::vector<int32_t> ds(nt, 0);
+    for (int e = 0; e < n_ensembles; ++e)
+        for (int k = 0; k < n_walkers; ++k) ds[(size_t)e * n_walkers + k] = ens_ds_id ? ens_ds_id[e] : 0;
+    if (s->d_pos.ensure(nt * ndim) || s->d_lnprob.ensure(nt) || s->d_acc.ensure(nt) || s->d_dsid.ensure(nt) ||
+        s->d_status.ensure(nt) ||
+        hipMemcpy(s->d_dsid.p, ds.data(), nt * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemset(s->d_acc.p, 0, nt * sizeof(int64_t)) != hipSuccess) {
+        fail(MP_EHIP, "mp_sampler_create: device allocation failed");
+        mp_sampler_destroy(s);
+        return nullptr;
+    }
+    return s;
+}
+
+int mp_sampler_destroy(mp_sampler *s) {
+    if (!s) return MP_OK;
+    DeviceScope scope(s->h->device);
+    (void)hipStreamSynchronize(s->h->stream);
+    s->d_pos.release(); s->d_lnprob.release(); s->d_chain.release(); s->d_chain_lnp.release();
+    s->d_acc.release(); s->d_perm.release(); s->d_dsid.release(); s->d_status.release();
+    delete s;
+    return MP_OK;
+}
+
+int mp_sampler_set_positions(mp_sampler *s, const double *pos) {
+    if (!s || !pos) return fail(MP_EINVAL, "mp_sampler_set_positions: NULL argument");
+    mp_handle *h = s->h;
+    DeviceScope scope(h->device);
+    const size_t nt = (size_t)s->n_total;
+    for (size_t i = 0; i < nt * s->ndim; ++i)
+        if (!std::isfinite(pos[i])) return fail(MP_EINVAL, "mp_sampler_set_positions: non-finite coordinate");
+    HIP_TRY(hipMemcpyAsync(s->d_pos.p, pos, nt * s->ndim * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (s->target == 1) {
+        std::vector<double> lp(nt, 0.0);
+        for (size_t k = 0; k < nt; ++k)
+            for (int i = 0; i < s->ndim; ++i) lp[k] -= 0.5 * pos[k * s->ndim + i] * pos[k * s->ndim + i];
+        HIP_TRY(hipMemcpyAsync(s->d_lnprob.p, lp.data(), nt * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    } else {
+        mp::LaunchArgs a{};
+        a.pars = s->d_pos.p; a.ds_id = s->d_dsid.p; a.n = s->n_total; a.ndim = s->ndim; a.want_chi2 = 1;
+        a.lnprob = s->d_lnprob.p; a.status = s->d_status.p;
+        const int e = mp::launch_lnprob(h->sh, a, h->stream);
+        if (e) return fail(MP_EHIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    s->have_state = true;
+    return MP_OK;
+}
+
+int mp_sampler_run(mp_sampler *s, int n_steps, double *chain, double *chain_lnprob) {
+    if (!s || n_steps < 0) return fail(MP_EINVAL, "mp_sampler_run: bad argument");
+    if (!s->have_state) return fail(MP_ESTATE, "mp_sampler_run: call mp_sampler_set_positions first");
+    if ((chain == nullptr) != (chain_lnprob == nullptr)) return fail(MP_EINVAL, "mp_sampler_run: chain and chain_lnprob go together");
+    mp_handle *h = s->h;
+    DeviceScope scope(h->device);
+    const size_t nt = (size_t)s->n_total, row = nt * s->ndim;
+    // chunks of steps so that the device-resident chain slab stays below ~256 MB
+    const int chunk_max = chain ? std::max<int>(1, (int)std::min<size_t>((size_t)n_steps, (256u << 20) / (row * sizeof(double)))) : n_steps;
+    std::vector<int32_t> perm;
+    int rc;
+    for (int done = 0; done < n_steps;) {
+        const int chunk = std::min(chunk_max, n_steps - done);
+        // random split of every ensemble for every step of the chunk (emcee's randomize_split)
+        perm.resize((size_t)chunk * nt);
+        for (int st = 0; st < chunk; ++st)
+            for (int e = 0; e < s->n_ensembles; ++e) {
+                int32_t *p = perm.data() + (size_t)st * nt + (size_t)e * s->n_walkers;
+                std::iota(p, p + s->n_walkers, 0);
+                const uint32_t step = (uint32_t)(s->steps_done + (uint64_t)st);
+                for (int i = s->n_walkers - 1; i > 0; --i) {   // Fisher-Yates, counter (step, ensemble, i, 'split')
+                    uint32_t r[4];
+                    philox4x32_10((uint32_t)s->seed, (uint32_t)(s->seed >> 32), step, (uint32_t)e, (uint32_t)i, 0x5117u, r);
+                    const uint64_t r64 = ((uint64_t)r[0] << 32) | r[1];
+                    std::swap(p[i], p[(size_t)(r64 % (uint64_t)(i + 1))]);
+                }
+            }
+        if ((rc = s->d_perm.ensure(perm.size()))) return rc;
+        HIP_TRY(hipMemcpyAsync(s->d_perm.p, perm.data(), perm.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+        if (chain) {
+            if ((rc = s->d_chain.ensure((size_t)chunk * row)) || (rc = s->d_chain_lnp.ensure((size_t)chunk * nt))) return rc;
+        }
+        for (int st = 0; st < chunk; ++st) {
+            for (int half = 0; half < 2; ++half) {
+                mp::StretchArgs g{};
+                g.pos = s->d_pos.p; g.lnprob = s->d_lnprob.p; g.n_accepted = s->d_acc.p;
+                g.perm = s->d_perm.p + (size_t)st * nt;
+                g.ds_id = s->d_dsid.p;
+                g.chain = chain ? s->d_chain.p : nullptr;
+                g.chain_lnp = chain ? s->d_chain_lnp.p : nullptr;
+                g.chain_row = st;
+                g.n_walkers = s->n_walkers; g.n_half = s->n_walkers / 2; g.n_ensembles = s->n_ensembles;
+                g.n_total = s->n_total; g.ndim = s->ndim; g.half = half; g.target = s->target;
+                g.step = (uint32_t)(s->steps_done + (uint64_t)st); g.seed = s->seed; g.a = s->a;
+                const int e = mp::launch_stretch(h->sh, g, h->stream);
+                if (e) return fail(MP_EHIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+            }
+        }
+        if (chain) {
+            HIP_TRY(hipMemcpyAsync(chain + (size_t)done * row, s->d_chain.p, (size_t)chunk * row * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(hipMemcpyAsync(chain_lnprob + (size_t)done * nt, s->d_chain_lnp.p, (size_t)chunk * nt * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        }
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        s->steps_done += (uint64_t)chunk;
+        done += chunk;
+    }
+    return MP_OK;
+}
+
+int mp_sampler_get_state(mp_sampler *s, double *pos, double *lnprob, int64_t *n_accepted, int64_t *steps_done) {
+    if (!s) return fail(MP_EINVAL, "mp_sampler_get_state: NULL sampler");
+    mp_handle *h = s->h;
+    DeviceScope scope(h->device);
+    const size_t nt = (size_t)s->n_total;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (pos) HIP_TRY(hipMemcpy(pos, s->d_pos.p, nt * s->ndim * sizeof(double), hipMemcpyDeviceToHost));
+    if (lnprob) HIP_TRY(hipMemcpy(lnprob, s->d_lnprob.p, nt * sizeof(double), hipMemcpyDeviceToHost));
+    if (n_accepted) HIP_TRY(hipMemcpy(n_accepted, s->d_acc.p, nt * sizeof(int64_t), hipMemcpyDeviceToHost));
+    if (steps_done) *steps_done = (int64_t)s->steps_done;
+    return MP_OK;
+}
+
 int mp_device(const mp_handle *h) { return h ? h->device : -1; }
 void *mp_stream(const mp_handle *h) { return h ? (void *)h->stream : nullptr; }
 int mp_n_grid(const mp_handle *h) { return h ? (int)h->tgrid.size() : 0; }

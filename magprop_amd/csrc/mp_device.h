@@ -68,10 +68,34 @@ struct LaunchArgs {
     double *omega;          // [n][n_grid] or nullptr
 };
 
+// Arguments of one fused stretch-move half-step (mp_kernels.hip: stretch_kernel).
+struct StretchArgs {
+    double *pos;            // [n_total][ndim] current positions, updated in place
+    double *lnprob;         // [n_total]
+    int64_t *n_accepted;    // [n_total]
+    const int32_t *perm;    // [n_ensembles][n_walkers]: this step's random split (first n_half entries = half 0)
+    const int32_t *ds_id;   // [n_total] or nullptr (dataset 0)
+    double *chain;          // [n_rows][n_total][ndim] or nullptr
+    double *chain_lnp;      // [n_rows][n_total]
+    int32_t chain_row;
+    int32_t n_walkers;      // walkers per ensemble (even)
+    int32_t n_half;         // n_walkers / 2
+    int32_t n_ensembles;
+    int32_t n_total;        // n_walkers * n_ensembles
+    int32_t ndim;
+    int32_t half;           // 0 or 1: which half moves
+    int32_t target;         // 0: magnetar posterior, 1: isotropic unit Gaussian (move tests)
+    uint32_t step;
+    uint32_t pad;
+    uint64_t seed;
+    double a;               // stretch scale (emcee default 2)
+};
+
 // Steps per lane of the kernel variant used for a batch of n walkers (tiles are 64*spl steps): see launch_lnprob.
 inline int kernel_spl(int n) { return n <= 1536 ? 4 : 2; }
 
 // implemented in mp_kernels.hip; returns hipError_t as int
 int launch_lnprob(const DevShared &sh, const LaunchArgs &a, void *stream);
+int launch_stretch(const DevShared &sh, const StretchArgs &g, void *stream);
 
 }  // namespace mp

@@ -417,25 +417,22 @@ constexpr int kMaxSweepsMargin = 16;  // sweeps allowed beyond the tile length (
 constexpr double kSweepTol = 1e-9;  // relative change of the step-end values that ends the sweeps
 
 // ---------------------------------------------------------------- the kernel
-// SPL = consecutive steps owned by one lane; a tile is 64*SPL steps.
+// Evaluate ONE walker on the calling wavefront (all 64 lanes enter with identical arguments).
+// SPL = consecutive steps owned by one lane; a tile is 64*SPL steps.  par[] holds the sampler coordinates
+// (prior checked and log-masked coordinates un-logged here unless a.physical); walker indexes ds_id and the
+// optional curve outputs; Lbuf is the wave's LDS tile [64*SPL + 1].
 template <bool CURVES, int SPL>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, SPL >= 4 ? 1 : 2))) void lnprob_kernel(const DevShared sh, const LaunchArgs a) {
+MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, double (&par)[MP_MAX_NDIM], double *Lbuf,
+                        double &lnp_out, int &status_out, int &sweeps_out) {
     constexpr int kSPL = SPL, kTile = 64 * SPL, kMaxSweeps = kTile + kMaxSweepsMargin;
     const int n_tiles = (sh.n_grid - 1 + kTile - 1) / kTile;
-    const int walker = blockIdx.x;
-    const int lane = threadIdx.x;
-    __shared__ double Lbuf[kTile + 1];
+    const int lane = threadIdx.x & 63;
 
     const int n_grid = sh.n_grid;
     const int nsteps = n_grid - 1;
     const size_t row = (size_t)walker * (size_t)n_grid;
 
-    // ---- parameters, prior, un-logging (code/synthetic_datasets/mcmc_eqns.py:16-17,28-49)
-    double par[MP_MAX_NDIM];
-    const double *pw = a.pars + (size_t)walker * a.ndim;
-#pragma unroll
-    for (int i = 0; i < MP_MAX_NDIM; ++i) par[i] = i < a.ndim ? pw[i] : 0.0;
-
+    // ---- prior, un-logging (code/synthetic_datasets/mcmc_eqns.py:16-17,28-49)
     int status = MP_STATUS_OK;
     if (!a.physical) {
         bool outside = false;
@@ -760,11 +757,134 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, SPL >= 4 
         lnp = -0.5 * wave_sum(chi);
         if (!isfinite(lnp)) { lnp = -INFINITY; status = MP_STATUS_NONFINITE; }
     }
-    if (lane == 0) {
+    lnp_out = lnp;
+    status_out = status;
+    sweeps_out = sweeps_total;
+}
+
+// ---------------------------------------------------------------- batched log-posterior kernel
+template <bool CURVES, int SPL>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, SPL >= 4 ? 1 : 2))) void lnprob_kernel(const DevShared sh, const LaunchArgs a) {
+    __shared__ double Lbuf[64 * SPL + 1];
+    const int walker = blockIdx.x;
+    double par[MP_MAX_NDIM];
+    const double *pw = a.pars + (size_t)walker * a.ndim;
+#pragma unroll
+    for (int i = 0; i < MP_MAX_NDIM; ++i) par[i] = i < a.ndim ? pw[i] : 0.0;
+    double lnp;
+    int status, sweeps;
+    walker_eval<CURVES, SPL>(sh, a, walker, par, Lbuf, lnp, status, sweeps);
+    if (threadIdx.x == 0) {
         a.lnprob[walker] = lnp;
         if (a.status) a.status[walker] = status;
-        if (a.sweeps) a.sweeps[walker] = sweeps_total;
+        if (a.sweeps) a.sweeps[walker] = sweeps;
     }
+}
+
+// ---------------------------------------------------------------- fused stretch-move half-step kernel
+// Counter-based RNG (Philox4x32-10, Salmon et al. 2011): one independent stream per (seed, step, walker).
+MP_DEV void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// Unfused double arithmetic (hipcc contracts a*b+c into an FMA by default, also through __dmul_rn/__dadd_rn):
+// the proposal and the test target are computed with separately rounded operations so that a numpy
+// restatement of the move reproduces the chain bit for bit.
+MP_DEV double mul_rn(double a, double b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+MP_DEV double add_rn(double a, double b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
+MP_DEV double sub_rn(double a, double b) {
+#pragma clang fp contract(off)
+    return a - b;
+}
+
+MP_DEV double u01(uint32_t hi, uint32_t lo) {   // 53-bit uniform in [0, 1)
+    return (double)((((uint64_t)hi << 32) | lo) >> 11) * (1.0 / 9007199254740992.0);
+}
+
+// One wavefront = one walker of the active half: draw the partner and the stretch factor, form the
+// proposal (emcee's StretchMove.get_proposal), evaluate its log-posterior with walker_eval, accept or
+// reject against the walker's current value, update position / lnprob / counters in place and write the
+// step's row of the chain.  Walkers of the complementary half are only read, so the update is race-free.
+template <int SPL>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, SPL >= 4 ? 1 : 2))) void stretch_kernel(const DevShared sh, const StretchArgs g) {
+    __shared__ double Lbuf[64 * SPL + 1];
+    const int w_ens = blockIdx.x / g.n_half;                       // which ensemble
+    const int slot = blockIdx.x - w_ens * g.n_half;                // which walker of the active half
+    const int32_t *perm = g.perm + (size_t)w_ens * g.n_walkers;    // this step's random split of the ensemble
+    const int base = w_ens * g.n_walkers;
+    const int k = base + perm[g.half * g.n_half + slot];           // active walker (global index)
+    uint32_t r[4], r2[4];
+    philox4x32_10((uint32_t)g.seed, (uint32_t)(g.seed >> 32), (uint32_t)g.step, (uint32_t)g.half, (uint32_t)k, 0u, r);
+    philox4x32_10((uint32_t)g.seed, (uint32_t)(g.seed >> 32), (uint32_t)g.step, (uint32_t)g.half, (uint32_t)k, 1u, r2);
+    const int n_comp = g.n_walkers - g.n_half;
+    const int jc = (int)(u01(r[0], r[1]) * n_comp);                // partner from the complementary half
+    const int j = base + perm[(1 - g.half) * g.n_half + min(jc, n_comp - 1)];
+    // (unfused arithmetic below, so that a numpy restatement of the move reproduces the chain bit for bit)
+    const double zr = add_rn(mul_rn(g.a - 1.0, u01(r[2], r[3])), 1.0);
+    const double zz = mul_rn(zr, zr) / g.a;                      // g(z) ~ 1/sqrt(z) on [1/a, a]
+    double par[MP_MAX_NDIM];
+#pragma unroll
+    for (int i = 0; i < MP_MAX_NDIM; ++i) {
+        const double xk = i < g.ndim ? g.pos[(size_t)k * g.ndim + i] : 0.0;
+        const double xj = i < g.ndim ? g.pos[(size_t)j * g.ndim + i] : 0.0;
+        par[i] = sub_rn(xj, mul_rn(sub_rn(xj, xk), zz));
+    }
+    double prop[MP_MAX_NDIM];
+#pragma unroll
+    for (int i = 0; i < MP_MAX_NDIM; ++i) prop[i] = par[i];
+    LaunchArgs a{};
+    a.ds_id = g.ds_id;
+    a.ndim = g.ndim;
+    a.physical = 0;
+    a.want_chi2 = 1;
+    double lnp;
+    int status, sweeps;
+    if (g.target == 1) {   // isotropic unit Gaussian: exercises the move itself (tests)
+        lnp = 0.0;
+#pragma unroll
+        for (int i = 0; i < MP_MAX_NDIM; ++i) lnp = i < g.ndim ? sub_rn(lnp, mul_rn(mul_rn(0.5, prop[i]), prop[i])) : lnp;
+        status = MP_STATUS_OK;
+    } else {
+        walker_eval<false, SPL>(sh, a, k, par, Lbuf, lnp, status, sweeps);
+    }
+    if (threadIdx.x == 0) {
+        const double lnp_old = g.lnprob[k];
+        const double lnpdiff = sub_rn(add_rn(mul_rn(g.ndim - 1.0, log(zz)), lnp), lnp_old);
+        const bool accept = lnpdiff > log(u01(r2[0], r2[1]));      // false for NaN / -inf proposals
+        if (accept) {
+            for (int i = 0; i < g.ndim; ++i) g.pos[(size_t)k * g.ndim + i] = prop[i];
+            g.lnprob[k] = lnp;
+            g.n_accepted[k] += 1;
+        }
+        if (g.chain) {
+            double *c = g.chain + ((size_t)g.chain_row * g.n_total + k) * g.ndim;
+            for (int i = 0; i < g.ndim; ++i) c[i] = accept ? prop[i] : g.pos[(size_t)k * g.ndim + i];
+            g.chain_lnp[(size_t)g.chain_row * g.n_total + k] = accept ? lnp : lnp_old;
+        }
+    }
+}
+
+int launch_stretch(const DevShared &sh, const StretchArgs &g, void *stream) {
+    const int n_blocks = g.n_half * g.n_ensembles;
+    if (n_blocks <= 0) return 0;
+    dim3 grid((unsigned)n_blocks), block(64);
+    if (kernel_spl(n_blocks) == 4) hipLaunchKernelGGL((stretch_kernel<4>), grid, block, 0, (hipStream_t)stream, sh, g);
+    else hipLaunchKernelGGL((stretch_kernel<2>), grid, block, 0, (hipStream_t)stream, sh, g);
+    return (int)hipGetLastError();
 }
 
 int launch_lnprob(const DevShared &sh, const LaunchArgs &a, void *stream) {

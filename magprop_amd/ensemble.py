@@ -1,0 +1,133 @@
+"""Device-resident ensemble sampler with the slice of emcee's API that the reference driver uses.
+
+`code/synthetic_datasets/synth_mcmc.py:175-226` does
+
+    sampler = em.EnsembleSampler(Nwalk, Npars, lnprob, args=(x, y, yerr, fbad), pool=pool)
+    sampler.run_mcmc(pos, Nstep, progress=True)
+    sampler.chain[i, j, k]; sampler.lnprobability[i, j]; sampler.acceptance_fraction; sampler.get_autocorr_time()
+
+`EnsembleSampler` here keeps positions, log-posteriors, acceptance counters and the chain in HBM and runs every
+stretch-move half-step as one fused kernel (propose -> lnprob -> accept -> store), so there is no host round
+trip per half-step.  Several independent ensembles (e.g. one per GRB dataset) can be advanced together.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi, engine, synth
+
+
+class EnsembleSampler:
+    def __init__(self, nwalkers, ndim=6, x=None, y=None, yerr=None, variant="synth", GRBtype=None, seed=0, a=2.0,
+                 datasets=None, lower="default", upper="default", log_mask=None, device=-1, target="posterior"):
+        """One ensemble on dataset (x, y, yerr), or one ensemble per entry of `datasets` = [(x, y, yerr), ...]."""
+        if nwalkers % 2 or nwalkers < 2:
+            raise ValueError("nwalkers must be even")            # emcee requires an even number too
+        self.nwalkers, self.ndim = int(nwalkers), int(ndim)
+        self._L = _capi.lib()
+        if variant == "synth":
+            cfg, lo, hi, mask = _capi.cfg_synth(), synth.PRIOR_LOWER, synth.PRIOR_UPPER, synth.LOG_MASK
+        elif variant == "lib":
+            from . import mcmc_eqns
+            cfg = _capi.cfg_lib()
+            lo, hi = mcmc_eqns._bounds(ndim)
+            mask = mcmc_eqns.LIB_LOG_MASK
+        else:
+            raise ValueError("variant must be 'synth' or 'lib'")
+        if not isinstance(lower, str):
+            lo, hi = lower, upper
+        if log_mask is not None:
+            mask = log_mask
+        self.handle = _capi.Handle(cfg, engine.grid(GRBtype), device)
+        self.handle.set_prior(lo, hi, mask)
+        self._target = {"posterior": 0, "gaussian": 1}[target]
+        if datasets is None:
+            datasets = [(x, y, yerr)] if x is not None else []
+        if self._target == 0 and not datasets:
+            raise ValueError("a dataset is required")
+        for k, (dx, dy, de) in enumerate(datasets):
+            self.handle.set_dataset(k, dx, dy, de)
+        self.nensembles = max(1, len(datasets))
+        ids = np.arange(self.nensembles, dtype=np.int32)
+        self._s = self._L.mp_sampler_create(self.handle._h, self.nwalkers, self.nensembles, self.ndim,
+                                            ids.ctypes.data_as(C.POINTER(C.c_int32)), C.c_uint64(int(seed)),
+                                            C.c_double(a), self._target)
+        if not self._s:
+            raise _capi.MagpropAmdError("mp_sampler_create failed: " + _capi.last_error())
+        self.seed = int(seed)
+        self._chain = None
+        self._lnp = None
+        self.iteration = 0
+
+    def close(self):
+        if getattr(self, "_s", None):
+            self._L.mp_sampler_destroy(self._s)
+            self._s = None
+        if getattr(self, "handle", None):
+            self.handle.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    @property
+    def ntotal(self):
+        return self.nwalkers * self.nensembles
+
+    def run_mcmc(self, pos, nsteps, store=True, progress=False):
+        """pos: (nwalkers, ndim) [or (nensembles*nwalkers, ndim)], or None to continue.  Returns the final positions."""
+        if pos is not None:
+            p = np.ascontiguousarray(pos, dtype=np.float64)
+            if p.shape != (self.ntotal, self.ndim):
+                raise ValueError(f"pos must have shape {(self.ntotal, self.ndim)}")
+            _capi.check(self._L.mp_sampler_set_positions(self._s, p.ctypes.data_as(C.POINTER(C.c_double))),
+                        "mp_sampler_set_positions")
+        chain = lnp = None
+        cp = lp = None
+        if store and nsteps > 0:
+            chain = np.empty((nsteps, self.ntotal, self.ndim))
+            lnp = np.empty((nsteps, self.ntotal))
+            cp, lp = chain.ctypes.data_as(C.POINTER(C.c_double)), lnp.ctypes.data_as(C.POINTER(C.c_double))
+        _capi.check(self._L.mp_sampler_run(self._s, int(nsteps), cp, lp), "mp_sampler_run")
+        if store and nsteps > 0:
+            self._chain = chain if self._chain is None else np.concatenate([self._chain, chain])
+            self._lnp = lnp if self._lnp is None else np.concatenate([self._lnp, lnp])
+        self.iteration += int(nsteps)
+        return self.get_last_sample()[0]
+
+    def get_last_sample(self):
+        pos = np.empty((self.ntotal, self.ndim))
+        lnp = np.empty(self.ntotal)
+        acc = np.empty(self.ntotal, dtype=np.int64)
+        done = C.c_int64(0)
+        _capi.check(self._L.mp_sampler_get_state(self._s, pos.ctypes.data_as(C.POINTER(C.c_double)),
+                                                 lnp.ctypes.data_as(C.POINTER(C.c_double)),
+                                                 acc.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(done)),
+                    "mp_sampler_get_state")
+        return pos, lnp, acc
+
+    # ---- emcee-shaped views (synth_mcmc.py:188-226 indexes chain[i, j, k], lnprobability[i, j])
+    def get_chain(self):
+        """(nsteps, nwalkers_total, ndim)"""
+        return self._chain
+
+    def get_log_prob(self):
+        return self._lnp
+
+    @property
+    def chain(self):
+        return None if self._chain is None else np.swapaxes(self._chain, 0, 1)
+
+    @property
+    def lnprobability(self):
+        return None if self._lnp is None else self._lnp.T
+
+    @property
+    def acceptance_fraction(self):
+        return self.get_last_sample()[2] / max(self.iteration, 1)
+
+    def get_autocorr_time(self, c=5.0, tol=50, quiet=True):
+        from .mcmc_io import integrated_time
+        return integrated_time(self._chain, c=c, tol=tol, quiet=quiet)
