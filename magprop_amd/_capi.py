@@ -11,7 +11,7 @@ import subprocess
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libmagprop_amd.so")
+LIB_PATH = os.environ.get("MAGPROP_AMD_LIB") or os.path.join(_PKG, "libmagprop_amd.so")  # override: A/B builds
 
 MP_OK, MP_EINVAL, MP_EHIP, MP_ERANGE, MP_ENODEV, MP_ESTATE = 0, -1, -2, -3, -4, -5
 STATUS_OK, STATUS_FLAG, STATUS_NONFINITE, STATUS_PRIOR = 0, 1, 2, 3

@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <string>
@@ -234,6 +235,11 @@ mp_handle *mp_create(const mp_model_cfg *cfg, const double *tgrid, int n_grid, i
     s.inv_sqrtGM = 1.0 / s.sqrtGM;
     s.sqrtR = std::sqrt(mp::kR);
     s.q = q;
+    s.sweep_tol = 1.0e-9;
+    if (const char *e = std::getenv("MAGPROP_AMD_SWEEP_TOL")) {   // experiments only
+        const double v = std::atof(e);
+        if (v > 0.0 && v < 1.0) s.sweep_tol = v;
+    }
     s.inv_q = 1.0 / q;
     {   // exponential Adams-Moulton quadrature matrix for nodes t_{j+1}, t_j, t_{j-1}, t_{j-2}:
         // W[k][m] = m! * [theta^m] l_k(theta), l_k the Lagrange basis on theta = 1, 0, -1/q, -(1/q + 1/q^2)

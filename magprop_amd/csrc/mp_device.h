@@ -46,6 +46,7 @@ struct DevShared {
     double GM, inertia, inv_inertia, crot /* 0.5*I/|W| */, sqrtGM, inv_sqrtGM, sqrtR;
     // geometric grid: ratio q = t_{j+1}/t_j and the exponential Adams-Moulton quadrature matrix for it
     double q, inv_q;
+    double sweep_tol;     // relative change of the step-end values that ends the Newton sweeps of a tile
     double eamW[4][4];
     mp_model_cfg cfg;
 };

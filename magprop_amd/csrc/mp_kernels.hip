@@ -216,21 +216,34 @@ struct Phi {
 
 template <int N>
 MP_DEV Phi<N> phi1234(const Vd<N> &z) {
-    // Taylor series of phi_4 for |z| < 1/2 (13 terms: < 2e-17 relative), closed forms elsewhere
+    // Taylor series of phi_4: 7 terms when every |z| of the wavefront is below 1/32 (< 2e-17 relative), 13 terms
+    // for |z| < 1/2, closed forms elsewhere
     Vd<N> s;
-    FORN s[i] = 1.0 / 20922789888000.0;           // 1/16!
-    horner(s, z, 1.0 / 1307674368000.0);          // 1/15!
-    horner(s, z, 1.0 / 87178291200.0);            // 1/14!
-    horner(s, z, 1.0 / 6227020800.0);             // 1/13!
-    horner(s, z, 1.0 / 479001600.0);              // 1/12!
-    horner(s, z, 1.0 / 39916800.0);               // 1/11!
-    horner(s, z, 1.0 / 3628800.0);                // 1/10!
-    horner(s, z, 1.0 / 362880.0);                 // 1/9!
-    horner(s, z, 1.0 / 40320.0);                  // 1/8!
-    horner(s, z, 1.0 / 5040.0);                   // 1/7!
-    horner(s, z, 1.0 / 720.0);                    // 1/6!
-    horner(s, z, 1.0 / 120.0);                    // 1/5!
-    horner(s, z, 1.0 / 24.0);                     // 1/4!
+    bool all_tiny = true;
+    FORN all_tiny = all_tiny && fabs(z[i]) < 0.03125;
+    if (__all(all_tiny)) {
+        FORN s[i] = 1.0 / 3628800.0;              // 1/10!
+        horner(s, z, 1.0 / 362880.0);             // 1/9!
+        horner(s, z, 1.0 / 40320.0);              // 1/8!
+        horner(s, z, 1.0 / 5040.0);               // 1/7!
+        horner(s, z, 1.0 / 720.0);                // 1/6!
+        horner(s, z, 1.0 / 120.0);                // 1/5!
+        horner(s, z, 1.0 / 24.0);                 // 1/4!
+    } else {
+        FORN s[i] = 1.0 / 20922789888000.0;       // 1/16!
+        horner(s, z, 1.0 / 1307674368000.0);      // 1/15!
+        horner(s, z, 1.0 / 87178291200.0);        // 1/14!
+        horner(s, z, 1.0 / 6227020800.0);         // 1/13!
+        horner(s, z, 1.0 / 479001600.0);          // 1/12!
+        horner(s, z, 1.0 / 39916800.0);           // 1/11!
+        horner(s, z, 1.0 / 3628800.0);            // 1/10!
+        horner(s, z, 1.0 / 362880.0);             // 1/9!
+        horner(s, z, 1.0 / 40320.0);              // 1/8!
+        horner(s, z, 1.0 / 5040.0);               // 1/7!
+        horner(s, z, 1.0 / 720.0);                // 1/6!
+        horner(s, z, 1.0 / 120.0);                // 1/5!
+        horner(s, z, 1.0 / 24.0);                 // 1/4!
+    }
     Phi<N> r;
     r.p4 = s;
     FORN r.p3[i] = fma(z[i], s[i], 1.0 / 6.0);
@@ -370,14 +383,17 @@ MP_DEV Vd<N> omega_rhs(const DevShared &sh, const Walker &w, const DiscPt<N> &p,
     FORN {
         const double om2 = om[i] * om[i];
         rot[i] = sh.crot * om2;
-        const bool brk = rot[i] > 0.27;                                    // break-up: Nacc = 0
-        const double arm = w.armI * (f.big[i] ? f.sq[i] : sh.sqrtR);       // sqrt(GM*max(Rm,R))/I
-        const double nacc = brk ? 0.0 : -arm * p.mdot[i] * f.th[i];        // Nacc/I ; Macc - Mprop = -tanh * mdot
+        // break-up (Nacc = 0) as a 0/1 factor: only the high dword of the double differs
+        const double live = __hiloint2double(rot[i] > 0.27 ? 0 : 0x3FF00000, 0);
+        const double arm = live * (w.armI * fmax(f.sq[i], sh.sqrtR));      // sqrt(GM*max(Rm,R))/I, or 0 beyond break-up
+        const double nacc = -arm * p.mdot[i] * f.th[i];                    // Nacc/I ; Macc - Mprop = -tanh * mdot
         if (WANT_LAM) {
-            const double dfast = (f.capped[i] ? -0.5 : 1.0) * f.fast[i] * f.inv_om[i];
+            const double cf = __hiloint2double(f.capped[i] ? (int)0xBFE00000 : 0x3FF00000, 0);   // -0.5 : 1.0
+            const double dfast = cf * f.fast[i] * f.inv_om[i];
             const double dth = sh.cfg.n_ode * (4.0 * f.e[i] * f.r[i] * f.r[i]) * dfast;   // n sech^2 dfast
-            const double darm = (f.capped[i] && f.big[i]) ? -0.5 * arm * f.inv_om[i] : 0.0;
-            const double dn = brk ? 0.0 : -p.mdot[i] * fma(darm, f.th[i], arm * dth);
+            const double cd = __hiloint2double((f.capped[i] && f.sq[i] >= sh.sqrtR) ? (int)0xBFE00000 : 0, 0);   // -0.5 : 0
+            const double darm = cd * arm * f.inv_om[i];
+            const double dn = -p.mdot[i] * fma(darm, f.th[i], arm * dth);
             lam[i] = fma(-3.0 * w.DI, om2, dn);
         }
         out[i] = fma(-w.DI * om2, om[i], nacc);
@@ -414,7 +430,6 @@ MP_DEV void luminosity(const DevShared &sh, const Walker &w, const DiscPt<N> &p,
 }
 
 constexpr int kMaxSweepsMargin = 16;  // sweeps allowed beyond the tile length (after which every step is exact)
-constexpr double kSweepTol = 1e-9;  // relative change of the step-end values that ends the sweeps
 
 // ---------------------------------------------------------------- the kernel
 // Evaluate ONE walker on the calling wavefront (all 64 lanes enter with identical arguments).
@@ -663,7 +678,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                     wc = fma(aw[s], wc, bw[s]);
                     const double dw = fabs(wc - wg[s]), mag = fabs(wc);
                     all_settled = all_settled && (dw <= 1.0e-3 * mag);               // false for NaN
-                    all_ok = all_ok && (!active[s] || dw <= kSweepTol * mag);
+                    all_ok = all_ok && (!active[s] || dw <= sh.sweep_tol * mag);
                     wg[s] = wc;
                 }
                 settled = all_settled;
