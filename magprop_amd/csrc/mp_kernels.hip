@@ -501,6 +501,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
     }
     double cf0, cf1, cf2, cw1 = om_s, cw2 = om_s, cw3 = om_s, cw4 = om_s;   // (omega_dot, omega) history; cw0 == om_s (cw3, cw4: predictor only)
     double L_s, Lp_s, Ld_s;
+    bool L_valid = true;          // L_s holds the luminosity at the current tile start
     {
         const Vd<1> Mv{{M_s}}, ov{{om_s}};
         const DiscPt<1> d_s = disc_point(sh, w, Mv);
@@ -562,7 +563,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
             {
                 const double ta0 = lane_prev(tb[kSPL - 1], t_s);
 #pragma unroll
-                for (int s = 0; s < kSPL; ++s) h[s] = active[s] ? tb[s] - (s == 0 ? ta0 : tb[s - 1]) : 1.0;
+                for (int s = 0; s < kSPL; ++s) h[s] = tb[s] - (s == 0 ? ta0 : tb[s - 1]);   // 0 for the padding steps of the last tile
             }
 
             // ---------------- Mdisc: exponential Adams-Moulton step (explicit: the source is known) + affine scan.
@@ -588,8 +589,8 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 double A = 1.0, B = 0.0;                  // composition of this lane's step maps
 #pragma unroll
                 for (int s = 0; s < kSPL; ++s) {
-                    am[s] = active[s] ? pm.e[s] : 1.0;
-                    bm[s] = active[s] ? inc[s] : 0.0;
+                    am[s] = pm.e[s];      // padding steps: h = 0 -> e = 1, inc = 0
+                    bm[s] = inc[s];
                     B = fma(am[s], B, bm[s]);
                     A = A * am[s];
                 }
@@ -626,9 +627,16 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
             Ew[2] = om_s;
             while (true) {
                 ++sweep;
+                {
+                    bool wild = false;
 #pragma unroll
-                for (int s = 0; s < kSPL; ++s)
-                    if (!(wg[s] > 0.0)) wg[s] = Ew[2] > 0.0 ? Ew[2] : om_s;   // keep the iteration alive after a wild or NaN guess
+                    for (int s = 0; s < kSPL; ++s) wild = wild || !(wg[s] > 0.0);
+                    if (__any(wild)) {   // keep the iteration alive after a wild or NaN guess (rare)
+#pragma unroll
+                        for (int s = 0; s < kSPL; ++s)
+                            if (!(wg[s] > 0.0)) wg[s] = Ew[2] > 0.0 ? Ew[2] : om_s;
+                    }
+                }
                 Vd<kSPL> rot, lam;
                 const Vd<kSPL> f1 = omega_rhs<true>(sh, w, d1, wg, rot, lam);
                 bool flg = false;
@@ -664,8 +672,8 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 double A = 1.0, B = 0.0;
 #pragma unroll
                 for (int s = 0; s < kSPL; ++s) {
-                    aw[s] = active[s] ? pw_.e[s] : 1.0;
-                    bw[s] = active[s] ? inc[s] : 0.0;
+                    aw[s] = pw_.e[s];
+                    bw[s] = inc[s];
                     B = fma(aw[s], B, bw[s]);
                     A = A * aw[s];
                 }
@@ -678,7 +686,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                     wc = fma(aw[s], wc, bw[s]);
                     const double dw = fabs(wc - wg[s]), mag = fabs(wc);
                     all_settled = all_settled && (dw <= 1.0e-3 * mag);               // false for NaN
-                    all_ok = all_ok && (!active[s] || dw <= sh.sweep_tol * mag);
+                    all_ok = all_ok && dw <= sh.sweep_tol * mag;
                     wg[s] = wc;
                 }
                 settled = all_settled;
@@ -706,8 +714,13 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
             }
 
             // ---------------- luminosity at the step ends, light curve through LDS, chi^2
+            // (tiles that hold no observation and are not written out skip the luminosity stage altogether)
+            const bool mine = ob_tile == tile;
+            int j0 = 0, j1 = 0;
+            if (long_lc) { j0 = max(tptr[tile * kSPL], 64); j1 = tptr[min((tile + 1) * kSPL, sh.n_tiles)]; }   // 64-step buckets
+            const bool tile_has_obs = __any(mine) || j1 > j0;
             Vd<kSPL> Lt, Lp, Ld;
-            luminosity(sh, w, d1, wg, Lt, Lp, Ld);
+            if (CURVES || tile_has_obs) luminosity(sh, w, d1, wg, Lt, Lp, Ld);
 #pragma unroll
             for (int s = 0; s < kSPL; ++s) {
                 if (CURVES && active[s]) {
@@ -720,12 +733,17 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 }
             }
             {
-                const bool mine = ob_tile == tile;
-                int j0 = 0, j1 = 0;
-                if (long_lc) { j0 = max(tptr[tile * kSPL], 64); j1 = tptr[min((tile + 1) * kSPL, sh.n_tiles)]; }   // 64-step buckets
-                if (__any(mine) || j1 > j0) {
+                if (tile_has_obs) {
 #pragma unroll
                     for (int s = 0; s < kSPL; ++s) Lbuf[lane * kSPL + s + 1] = Lt[s];
+                    if (!L_valid) {   // the previous tile skipped its luminosity stage: evaluate its end point now
+                        const Vd<1> Mv{{M_s}}, ov{{om_s}};
+                        const DiscPt<1> dps = disc_point(sh, w, Mv);
+                        Vd<1> l0, l1, l2;
+                        luminosity(sh, w, dps, ov, l0, l1, l2);
+                        L_s = l0[0];
+                        L_valid = true;
+                    }
                     if (lane == 0) Lbuf[0] = L_s;
                     __syncthreads();
                     if (mine) {
@@ -762,7 +780,8 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 t_s = lane_bcast(tb[kSPL - 1], 63);
                 M_s = lane_bcast(M1[kSPL - 1], 63);
                 om_s = lane_bcast(wg[kSPL - 1], 63);
-                L_s = lane_bcast(Lt[kSPL - 1], 63);
+                L_valid = CURVES || tile_has_obs;
+                if (L_valid) L_s = lane_bcast(Lt[kSPL - 1], 63);
             }
         }
     }
