@@ -37,7 +37,6 @@ TRUTH = {"Humped": [1.0, 5.0, -3.0, 2.0, -1.0, 0.0], "Classic": [1.0, 5.0, -3.0,
          "Sloped": [1.0, 1.0, -3.0, 2.0, 1.0, 1.0], "Stuttering": [1.0, 5.0, -5.0, 2.0, -1.0, 2.0]}
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X fp64 vector peak (spec)
-FLOP_EQ_PER_EVAL = 1.3e7       # SURVEY.md 8(d) flop-equivalent convention for ONE serial evaluation
 BYTES_PER_EVAL_A = 48 + 8 + 4  # mode A: 6 fp64 parameters in, lnprob + status out
 BYTES_LTOT = 10001 * 8         # mode B adds the model light curve
 
@@ -213,13 +212,14 @@ def main():
         kavg = float(kern_ms.mean()) * 1e-3
         bytes_eval = BYTES_PER_EVAL_A + (BYTES_LTOT if a.curve else 0)
         achieved = bytes_eval * n_local / kavg / 1e9
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        traffic = flops_launch = None
+        tf = os.path.join(ROOT, "profiles", "pmc_figures.json")     # from the committed rocprofv3 PMC summary
         if os.path.exists(tf):
             try:
-                traffic = json.load(open(tf)).get("curve" if a.curve else "lnprob", {}).get(str(n_local))
+                fig = json.load(open(tf)).get("curve" if a.curve else "lnprob", {}).get(str(n_local), {})
+                traffic, flops_launch = fig.get("traffic_bytes"), fig.get("fp64_flops")
             except Exception:  # noqa: BLE001
-                traffic = None
+                traffic = flops_launch = None
         out = {
             "metric": "walker_lnprob_evals_per_sec", "value": value, "unit": "evals/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
@@ -234,9 +234,13 @@ def main():
                          "kernel": "mp::lnprob_kernel", "kernel_ms_avg": 1e3 * kavg, "kernel_ms_min": float(kern_ms.min()),
                          "algorithmic_bytes_per_eval": bytes_eval, "evals_per_launch": n_local,
                          "note": "latency-bound fp64 VALU recurrence: neither HBM nor MFMA binds; see valu"},
-            "valu": {"flop_eq_per_eval": FLOP_EQ_PER_EVAL, "achieved_tflop_eq": FLOP_EQ_PER_EVAL * n_local / kavg / 1e12,
-                     "peak_tflops_fp64_vector": FP64_VALU_PEAK_TFLOPS,
-                     "frac": FLOP_EQ_PER_EVAL * n_local / kavg / 1e12 / FP64_VALU_PEAK_TFLOPS},
+            "valu": {"bound": "fp64 VALU issue, one wave per SIMD", "unit": "TFLOP/s",
+                     "fp64_flops_per_launch_pmc": flops_launch,
+                     "achieved": None if flops_launch is None else flops_launch / kavg / 1e12,
+                     "peak": FP64_VALU_PEAK_TFLOPS,
+                     "frac": None if flops_launch is None else flops_launch / kavg / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                     "note": "flops executed = 64 x (2 FMA + MUL + ADD) fp64 instructions counted by rocprofv3 PMC for this "
+                             "launch size (profiles/pmc_figures.json) / kernel time measured here"},
             "kernel_evals_per_sec_per_gpu": n_local / kavg,
             "host_enqueue_ms_per_step": 1e3 * t_host / a.steps,
             "check": {"lnprob0": first, "n_not_ok": n_flag, "checksum": float(checksum.item())},

@@ -6,12 +6,13 @@
 Everything is evaluated by hand-written HIP kernels behind the C ABI of include/magprop_amd.h; there
 is no CPU fallback.
 """
-from . import _capi, engine, funcs, mcmc_eqns, synth  # noqa: F401
+from . import _capi, engine, fit_stats, funcs, mcmc_eqns, synth  # noqa: F401
 from .ensemble import EnsembleSampler  # noqa: F401
 from .logprob import LogProb  # noqa: F401
 from ._capi import MagpropAmdError  # noqa: F401
+from .fit_stats import aicc, redchisq  # noqa: F401
 from .funcs import init_conds, model_lc, model_lum  # noqa: F401
 from .mcmc_eqns import lnlike, lnprior, lnprob  # noqa: F401
 
 __version__ = "0.1.0"
-__all__ = ["init_conds", "model_lc", "model_lum", "lnlike", "lnprior", "lnprob", "synth", "LogProb", "EnsembleSampler", "MagpropAmdError"]
+__all__ = ["init_conds", "model_lc", "model_lum", "redchisq", "aicc", "lnlike", "lnprior", "lnprob", "synth", "LogProb", "EnsembleSampler", "MagpropAmdError"]

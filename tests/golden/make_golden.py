@@ -256,6 +256,15 @@ def make_lib():
         rows.append(row); vals.append(lib.lnprior(np.array(p)))
     g["lnprior_pars"] = np.array(rows)
     g["lnprior"] = np.array(vals)
+    # fit statistics (magnetar/fit_stats.py:6-62) on the reference's own fixture (tests/test_funcs.py:167-182)
+    ng = pd.read_csv(os.path.join(REF, "tests/test_data/noisy_gaussian.csv"))
+    yd, ye, ym = ng["ydata"].values, ng["yerr"].values, ng["ymod"].values
+    g["fit_ydata"], g["fit_yerr"], g["fit_ymod"] = yd, ye, ym
+    g["fit_redchisq_sd"] = np.array(lib.redchisq(yd, ym, sd=ye))
+    g["fit_redchisq_sd_deg6"] = np.array(lib.redchisq(yd, ym, deg=6, sd=ye))
+    g["fit_redchisq_plain"] = np.array(lib.redchisq(yd, ym))
+    g["fit_aicc_2"] = np.array(lib.aicc(yd, ym, ye, 2))
+    g["fit_aicc_6"] = np.array(lib.aicc(yd, ym, ye, 6))
     np.savez_compressed(os.path.join(HERE, "golden_lib.npz"), **g)
     print("lib lnlike L:", g["lnlike_L"][:4])
 
@@ -263,10 +272,12 @@ def make_lib():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--flag-scan", type=int, default=1500)
+    ap.add_argument("--only", choices=["all", "lib"], default="all", help="regenerate only golden_lib.npz")
     a = ap.parse_args()
     import scipy, pandas
-    make_synth()
-    make_flagscan(a.flag_scan)
+    if a.only == "all":
+        make_synth()
+        make_flagscan(a.flag_scan)
     make_lib()
     manifest = {
         "generator": "tests/golden/make_golden.py",

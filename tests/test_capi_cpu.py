@@ -99,3 +99,16 @@ def test_lib_lnprior_custom_limits(tmp_path):
     assert mcmc_eqns.lnprior([0.5] * 6 + [0.5], custom_lims=str(p)) == -np.inf
     with pytest.raises(ValueError, match="valid file path"):
         mcmc_eqns.lnprior([0.5] * 6, custom_lims=str(tmp_path / "missing.csv"))
+
+
+def test_fit_stats_match_reference(glib):
+    """magnetar/fit_stats.py on the reference's own noisy_gaussian fixture (tests/test_funcs.py:153-182)."""
+    import magprop_amd as mpa
+    yd, ye, ym = glib["fit_ydata"], glib["fit_yerr"], glib["fit_ymod"]
+    assert mpa.redchisq(yd, ym, sd=ye) == float(glib["fit_redchisq_sd"])
+    assert mpa.redchisq(yd, ym, deg=6, sd=ye) == float(glib["fit_redchisq_sd_deg6"])
+    assert mpa.redchisq(yd, ym) == float(glib["fit_redchisq_plain"])
+    assert mpa.aicc(yd, ym, ye, 2) == float(glib["fit_aicc_2"])
+    assert mpa.aicc(yd, ym, ye, 6) == float(glib["fit_aicc_6"])
+    with pytest.raises(ValueError, match="same length"):
+        mpa.aicc(yd, ym[:-1], ye, 2)

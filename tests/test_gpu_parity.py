@@ -312,3 +312,18 @@ def test_device_pointer_entry_matches_host_entry(gsynth):
     torch.cuda.synchronize()
     assert np.array_equal(dev.cpu().numpy(), host)
     assert int(st.sum()) == 0
+
+
+def test_fit_statistics_epilogue(mpa, gsynth):
+    """redchisq / aicc from the kernel's chi-square equal the reference formulas applied to the model at x."""
+    from magprop_amd.fit_stats import fit_statistics
+    x, y, yerr = gsynth["Humped_x"], gsynth["Humped_y"], gsynth["Humped_yerr"]
+    p = np.array(TRUTHS["Humped"])
+    st = fit_statistics(p, x, y, yerr)
+    phys = p.copy()
+    phys[2:] = 10.0 ** phys[2:]
+    ymod = mpa.model_lum(phys, xdata=x)
+    assert st["redchisq"] == pytest.approx(mpa.redchisq(y, ymod, deg=6, sd=yerr), rel=1e-10)
+    assert st["aicc"] == pytest.approx(mpa.aicc(y, ymod, yerr, 6), rel=1e-10)
+    many = fit_statistics(np.tile(p, (3, 1)), x, y, yerr)
+    assert many["chisq"].shape == (3,) and np.allclose(many["chisq"], st["chisq"], rtol=1e-12)
