@@ -50,6 +50,11 @@ def gflag():
 
 
 @pytest.fixture(scope="session")
+def gcorners():
+    return np.load(os.path.join(GOLDEN, "golden_corners.npz"))
+
+
+@pytest.fixture(scope="session")
 def tarr():
     return np.logspace(0.0, 6.0, num=10001, base=10.0)
 

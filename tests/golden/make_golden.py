@@ -19,7 +19,7 @@ What is called (paths relative to /root/reference):
                   tests/test_data/model_light_curve.csv — decimated (every 20th row) copies.
 `*_tight` arrays: the same reference code with its odeint call given rtol=atol=1e-12 (integrator noise
 removed; see tight_lsoda).
-Outputs: golden_synth.npz, golden_lib.npz, golden_flagscan.npz, MANIFEST.json.
+Outputs: golden_synth.npz, golden_lib.npz, golden_flagscan.npz, golden_corners.npz, MANIFEST.json.
 """
 import argparse
 import contextlib
@@ -190,6 +190,25 @@ def make_flagscan(n):
     print("flag rate", (st == 1).mean())
 
 
+def make_corners():
+    """All 64 corners of the synth prior box on the Humped dataset, plus the largest rotation parameter the
+    reference's own trajectory reaches (so tests can tell 'rode the break-up limit but LSODA survived')."""
+    import itertools
+    _, x, y, yerr = synth_dataset("Humped", SEED0)
+    P = np.array([[UPPER[i] if b else LOWER[i] for i, b in enumerate(bits)] for bits in itertools.product([0, 1], repeat=6)])
+    lnp = np.empty(len(P)); st = np.empty(len(P), dtype=np.int32); rot = np.full(len(P), np.nan)
+    inertia = sf.I
+    modW = (0.6 * sf.M * sf.c ** 2.0 * ((sf.GM / (sf.R * sf.c ** 2.0)) / (1.0 - 0.5 * (sf.GM / (sf.R * sf.c ** 2.0)))))
+    for i, p in enumerate(P):
+        lnp[i], st[i] = synth_lnprob(p, x, y, yerr)
+        arr = p.copy(); arr[2:] = 10.0 ** arr[2:]
+        y0 = sf.init_conds(arr[2], arr[1])
+        soln = quiet(odeint, sf.ODEs, y0, sf.tarr, args=(arr[0], arr[2], arr[3], arr[4], arr[5], 10.0, 0.1, 1.0, 0.9))
+        rot[i] = np.nanmax(0.5 * inertia * soln[:, 1] ** 2.0 / modW)
+    np.savez_compressed(os.path.join(HERE, "golden_corners.npz"), pars=P, lnprob=lnp, status=st, max_rot=rot)
+    print("corners: flags", int((st == 1).sum()), "rode break-up but survived", int(((st == 0) & (rot >= 0.27)).sum()))
+
+
 def make_lib():
     os.chdir(REF)  # magnetar/mcmc_eqns.py:55 reads a cwd-relative CSV
     import pandas as pd
@@ -272,13 +291,16 @@ def make_lib():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--flag-scan", type=int, default=1500)
-    ap.add_argument("--only", choices=["all", "lib"], default="all", help="regenerate only golden_lib.npz")
+    ap.add_argument("--only", choices=["all", "lib", "corners"], default="all", help="regenerate only one file")
     a = ap.parse_args()
     import scipy, pandas
     if a.only == "all":
         make_synth()
         make_flagscan(a.flag_scan)
-    make_lib()
+    if a.only in ("all", "corners"):
+        make_corners()
+    if a.only in ("all", "lib"):
+        make_lib()
     manifest = {
         "generator": "tests/golden/make_golden.py",
         "reference": "sgibson91/magprop mounted at /root/reference (magnetar v%s)" % lib.__version__

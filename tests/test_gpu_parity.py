@@ -89,6 +89,22 @@ def test_flag_scan(synth_handle, gflag):
     assert 2.0 <= synth_handle.last_mean_sweeps <= 6.0
 
 
+def test_prior_box_corners(synth_handle, co, gsynth, gcorners, tarr):
+    """The 64 prior-box corners: identical verdicts and values to the C oracle; see tests/test_oracle.py for how
+    the four corners where the reference's LSODA survives on the break-up limit are treated."""
+    x, y, yerr = gsynth["Humped_x"], gsynth["Humped_y"], gsynth["Humped_yerr"]
+    out, st = synth_handle.lnprob_batch(gcorners["pars"], ds_id=0, want_status=True)
+    ref_c, st_c = co.lnprob_batch(co.cfg_synth(), gcorners["pars"], tarr, x, y, yerr, gsynth["prior_lower"],
+                                  gsynth["prior_upper"], LOG_MASK)
+    assert np.array_equal(st, st_c)
+    ok = np.isfinite(ref_c)
+    assert np.all(np.abs(out[ok] - ref_c[ok]) <= GPU_VS_C_RTOL * np.abs(ref_c[ok]) + 1e-9)
+    rst, at_limit = gcorners["status"], gcorners["max_rot"] >= 0.27
+    assert np.array_equal(st[~at_limit], rst[~at_limit]) and np.all(st[at_limit] == 1)
+    good = (rst == 0) & ~at_limit
+    assert np.all(np.abs(out[good] - gcorners["lnprob"][good]) <= REF_ATOL + REF_RTOL * np.abs(gcorners["lnprob"][good]))
+
+
 @pytest.mark.parametrize("name", TYPES)
 def test_model_lum_curves(mpa, co, gsynth, tarr, name):
     out = mpa.model_lum(CANON[name])

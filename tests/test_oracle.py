@@ -100,6 +100,24 @@ def test_flag_rule_confusion_matrix(gsynth, gflag, tarr, cfg):
     assert np.all(np.abs(out[m] - tight[m]) <= TIGHT_ATOL + TIGHT_RTOL * np.abs(tight[m]))
 
 
+def test_prior_box_corners(gsynth, gcorners, tarr, cfg):
+    """All 64 corners of the prior box.  Where the reference's trajectory reaches the break-up limit
+    (rotation parameter >= 0.27) LSODA either gives up ('flag') or, at default tolerances, survives riding the
+    limit -- the same model fails when integrated at tight tolerances, i.e. the reference's verdict there is an
+    artefact of its step-size history.  The deterministic rule calls all of them 'flag'; everywhere else status
+    and value agree.  (Documented in DESIGN.md section 5.)"""
+    x, y, yerr = gsynth["Humped_x"], gsynth["Humped_y"], gsynth["Humped_yerr"]
+    out, st = co.lnprob_batch(cfg, gcorners["pars"], tarr, x, y, yerr, gsynth["prior_lower"], gsynth["prior_upper"],
+                              LOG_MASK)
+    rst, rot, ref = gcorners["status"], gcorners["max_rot"], gcorners["lnprob"]
+    at_limit = rot >= 0.27
+    assert np.array_equal(st[~at_limit], rst[~at_limit])
+    assert np.all(st[at_limit] == co.STATUS_FLAG)
+    assert int(((rst == 0) & at_limit).sum()) == 4 and int((rst == 1).sum()) == 4     # what the reference did
+    ok = (rst == 0) & ~at_limit
+    assert np.all(np.abs(out[ok] - ref[ok]) <= REF_ATOL + REF_RTOL * np.abs(ref[ok]))
+
+
 def test_scheme_converges_with_substeps(tarr, cfg, gsynth):
     """A stiff prior-wide case (plain RK4 on the grid is 24 % off there): 1 vs 8 sub-steps agree."""
     p = gsynth["Classic_pars"][55].copy()
