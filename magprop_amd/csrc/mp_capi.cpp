@@ -236,6 +236,11 @@ mp_handle *mp_create(const mp_model_cfg *cfg, const double *tgrid, int n_grid, i
     s.sqrtR = std::sqrt(mp::kR);
     s.q = q;
     s.sweep_tol = 1.0e-9;
+    s.force_wpw = 0;
+    if (const char *e = std::getenv("MAGPROP_AMD_WPW")) {          // experiments only
+        const int v = std::atoi(e);
+        if (v == 1 || v == 2 || v == 4) s.force_wpw = v;
+    }
     if (const char *e = std::getenv("MAGPROP_AMD_SWEEP_TOL")) {   // experiments only
         const double v = std::atof(e);
         if (v > 0.0 && v < 1.0) s.sweep_tol = v;

@@ -47,6 +47,8 @@ struct DevShared {
     // geometric grid: ratio q = t_{j+1}/t_j and the exponential Adams-Moulton quadrature matrix for it
     double q, inv_q;
     double sweep_tol;     // relative change of the step-end values that ends the Newton sweeps of a tile
+    int32_t force_wpw;    // experiments: 0 = automatic, else wavefronts per walker (1, 2, 4)
+    int32_t pad1;
     double eamW[4][4];
     mp_model_cfg cfg;
 };
@@ -94,6 +96,8 @@ struct StretchArgs {
 
 // Steps per lane of the kernel variant used for a batch of n walkers (tiles are 64*spl steps): see launch_lnprob.
 inline int kernel_spl(int n) { return n <= 1536 ? 4 : 2; }
+// Wavefronts that cooperate on one walker: small batches cannot give every SIMD (256 CUs x 4) a walker of its own.
+inline int waves_per_walker(int n) { return n <= 256 ? 4 : 1; }
 
 // implemented in mp_kernels.hip; returns hipError_t as int
 int launch_lnprob(const DevShared &sh, const LaunchArgs &a, void *stream);

@@ -31,6 +31,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <type_traits>
 
 #include "mp_device.h"
 
@@ -429,24 +430,9 @@ MP_DEV void luminosity(const DevShared &sh, const Walker &w, const DiscPt<N> &p,
     }
 }
 
-constexpr int kMaxSweepsMargin = 16;  // sweeps allowed beyond the tile length (after which every step is exact)
-
-// ---------------------------------------------------------------- the kernel
-// Evaluate ONE walker on the calling wavefront (all 64 lanes enter with identical arguments).
-// SPL = consecutive steps owned by one lane; a tile is 64*SPL steps.  par[] holds the sampler coordinates
-// (prior checked and log-masked coordinates un-logged here unless a.physical); walker indexes ds_id and the
-// optional curve outputs; Lbuf is the wave's LDS tile [64*SPL + 1].
-template <bool CURVES, int SPL>
-MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, double (&par)[MP_MAX_NDIM], double *Lbuf,
-                        double &lnp_out, int &status_out, int &sweeps_out) {
-    constexpr int kSPL = SPL, kTile = 64 * SPL, kMaxSweeps = kTile + kMaxSweepsMargin;
-    const int n_tiles = (sh.n_grid - 1 + kTile - 1) / kTile;
-    const int lane = threadIdx.x & 63;
-
-    const int n_grid = sh.n_grid;
-    const int nsteps = n_grid - 1;
-    const size_t row = (size_t)walker * (size_t)n_grid;
-
+// Prior box, un-logging of the log-masked coordinates and the per-walker constants
+// (code/synthetic_datasets/mcmc_eqns.py:16-17,28-49; funcs.py:98-102).  Returns MP_STATUS_OK or MP_STATUS_PRIOR.
+MP_DEV int walker_setup(const DevShared &sh, const LaunchArgs &a, double (&par)[MP_MAX_NDIM], Walker &w) {
     // ---- prior, un-logging (code/synthetic_datasets/mcmc_eqns.py:16-17,28-49)
     int status = MP_STATUS_OK;
     if (!a.physical) {
@@ -461,7 +447,6 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
     }
 
     // ---- walker constants (code/synthetic_datasets/funcs.py:98-102)
-    Walker w;
     {
         const double B = par[0], MdiscI = par[2], RdiscI = par[3], epsilon = par[4], delta = par[5];
         const double tau = (RdiscI * 1.0e5) / (sh.cfg.alpha * sh.cfg.cs7 * 1.0e7);
@@ -486,6 +471,30 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
         if (a.ndim == 8) { w.dipeff = par[6]; w.propeff = par[7]; }
         if (a.ndim == 9) { w.dipeff = par[6]; w.propeff = par[7]; w.f_beam = par[8]; }
     }
+
+    return status;
+}
+
+constexpr int kMaxSweepsMargin = 16;  // sweeps allowed beyond the tile length (after which every step is exact)
+
+// ---------------------------------------------------------------- the kernel
+// Evaluate ONE walker on the calling wavefront (all 64 lanes enter with identical arguments).
+// SPL = consecutive steps owned by one lane; a tile is 64*SPL steps.  par[] holds the sampler coordinates
+// (prior checked and log-masked coordinates un-logged here unless a.physical); walker indexes ds_id and the
+// optional curve outputs; Lbuf is the wave's LDS tile [64*SPL + 1].
+template <bool CURVES, int SPL>
+MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, double (&par)[MP_MAX_NDIM], double *Lbuf,
+                        double &lnp_out, int &status_out, int &sweeps_out) {
+    constexpr int kSPL = SPL, kTile = 64 * SPL, kMaxSweeps = kTile + kMaxSweepsMargin;
+    const int n_tiles = (sh.n_grid - 1 + kTile - 1) / kTile;
+    const int lane = threadIdx.x & 63;
+
+    const int n_grid = sh.n_grid;
+    const int nsteps = n_grid - 1;
+    const size_t row = (size_t)walker * (size_t)n_grid;
+
+    Walker w;
+    int status = walker_setup(sh, a, par, w);
 
     // ---- state carried from tile to tile (all wave-uniform).  Index 0 = the tile's start point P0,
     // 1 = P0-1, 2 = P0-2: the history the multistep formulas reach back to.
@@ -796,6 +805,334 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
     sweeps_out = sweeps_total;
 }
 
+// ---------------------------------------------------------------- W wavefronts per walker
+// Small batches cannot give every SIMD a walker (256 CUs x 4 SIMDs): the stretch move only ever has half an
+// ensemble in flight, and the reference's own configuration has 24 walkers.  walker_eval_mw spreads ONE walker
+// over the W wavefronts of a 64*W-thread workgroup: a tile is 64*W*SPL steps, every lane still owns SPL
+// consecutive steps, the wavefront scans stay in DPP, and what has to cross wavefronts goes through LDS:
+//   - the step history (Mdotfb, omega_dot, omega at the three previous grid points) is read from an LDS image
+//     of the tile instead of the neighbouring lane;
+//   - the affine scan is completed with the per-wavefront totals;
+//   - loop exits are agreed with __syncthreads_or.
+// Same scheme, same arithmetic per step as walker_eval; only the tile length differs (results agree to
+// rounding, like the SPL variants).  lds: [2*(kTile+3) + 2*W + (kTile+1) + 16] doubles, see MwLds.
+template <int SPL, int W>
+struct MwLds {
+    static constexpr int kTile = 64 * W * SPL;
+    double s[kTile + 3];        // Mdotfb at step ends e = -3..kTile-1, stored at [e + 3]
+    double f[kTile + 3];        // omega_dot
+    double w[kTile + 3];        // omega
+    double tot[2][2 * W];       // per-wavefront scan totals (a, b); double-buffered by use
+    int flags[2][W];            // per-wavefront (pending | flagged << 1); double-buffered by sweep
+    double L[2][kTile + 1];     // model light curve of the tile; double-buffered by tile
+    double carry[2][16];        // tile-end state for the next tile; double-buffered by tile
+    int fail[2][2 * W];         // per-wavefront first non-finite / first over-limit lane; double-buffered by tile
+};
+
+// Complete a wavefront-level affine scan across the W wavefronts of the workgroup: x_wave = value at this
+// wavefront's first step start, given the tile's start value x0.  One barrier.
+template <int W>
+MP_DEV void scan_affine_block(double &A, double &B, double (&tot)[2 * W], int wave, int lane, double x0, double &x_wave) {
+    scan_affine(A, B);
+    if (lane == 63) { tot[2 * wave] = A; tot[2 * wave + 1] = B; }
+    __syncthreads();
+    double xw = x0;
+#pragma unroll
+    for (int v = 0; v < W; ++v)
+        if (v < wave) xw = fma(tot[2 * v], xw, tot[2 * v + 1]);
+    x_wave = xw;
+}
+
+template <int SPL, int W>
+MP_DEV void walker_eval_mw(const DevShared &sh, const LaunchArgs &a, int walker, double (&par)[MP_MAX_NDIM], MwLds<SPL, W> &lds,
+                           double &lnp_out, int &status_out, int &sweeps_out) {
+    constexpr int kSPL = SPL, kTile = 64 * W * SPL, kMaxSweeps = kTile + kMaxSweepsMargin;
+    const int n_tiles = (sh.n_grid - 1 + kTile - 1) / kTile;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, gl = threadIdx.x;
+    const int nsteps = sh.n_grid - 1;
+
+    Walker w;
+    int status = walker_setup(sh, a, par, w);
+
+    const double t0 = sh.tgrid[0];
+    double M_s = par[2] * kMsol;
+    double om_s = (2.0 * M_PI) / (1.0e-3 * par[1]);
+    double cS0, cS1, cS2;
+    {
+        const Vd<3> tg{{t0, t0 * sh.inv_q, t0 * sh.inv_q * sh.inv_q}};
+        const Vd<3> Sg = mdot_fb(w, tg);
+        cS0 = Sg[0]; cS1 = Sg[1]; cS2 = Sg[2];
+    }
+    double cf0, cf1, cf2, cw1 = om_s, cw2 = om_s, cw3 = om_s, cw4 = om_s;
+    double L_s;
+    {
+        const Vd<1> Mv{{M_s}}, ov{{om_s}};
+        const DiscPt<1> d_s = disc_point(sh, w, Mv);
+        Vd<1> rot0, dummy, Lt0, Lp0, Ld0;
+        cf0 = omega_rhs<false>(sh, w, d_s, ov, rot0, dummy)[0];
+        cf1 = cf2 = cf0;
+        if (status == MP_STATUS_OK) {
+            if (!(isfinite(M_s) && isfinite(om_s)) || M_s <= 0.0 || om_s <= 0.0) status = MP_STATUS_NONFINITE;
+            else if (rot0[0] > 0.27) status = MP_STATUS_FLAG;
+        }
+        luminosity(sh, w, d_s, ov, Lt0, Lp0, Ld0);
+        L_s = Lt0[0];
+    }
+
+    const int dsid = a.ds_id ? a.ds_id[walker] : 0;
+    const DsDesc dsd = sh.ds ? sh.ds[(dsid >= 0 && dsid < sh.n_ds) ? dsid : 0] : DsDesc{0, 0, 0, 0};
+    const int32_t *tptr = sh.tile_ptr + dsd.tile_off;
+    constexpr int kRes = 64 * W;                     // observations resident in registers (one per lane of the workgroup)
+    int ob_g = -1;
+    double ob_dx = 0.0, ob_idt = 0.0, ob_y = 0.0, ob_ye = 1.0;
+    if (a.want_chi2 && gl < dsd.n_obs) {
+        const int jj = dsd.obs_off + gl;
+        ob_g = sh.obs_g[jj]; ob_dx = sh.obs_dx[jj]; ob_idt = sh.obs_idt[jj]; ob_y = sh.obs_y[jj]; ob_ye = sh.obs_yerr[jj];
+    }
+    const int ob_tile = ob_g >= 0 ? ob_g / kTile : -1;
+    const bool long_lc = a.want_chi2 && dsd.n_obs > kRes;
+    double chi = 0.0;
+    int sweeps_total = 0;
+    int tp = 0;      // buffer parity of the scan totals
+    int fp = 0;      // buffer parity of the sweep flags
+
+    if (status == MP_STATUS_OK) {
+        double tb_next[kSPL];
+#pragma unroll
+        for (int s = 0; s < kSPL; ++s) tb_next[s] = sh.tgrid[min(gl * kSPL + s + 1, nsteps)];
+        double ta_next = sh.tgrid[min(gl * kSPL, nsteps)];
+
+        for (int tile = 0; tile < n_tiles; ++tile) {
+            const int i0 = tile * kTile + gl * kSPL;
+            const int e0 = gl * kSPL;                    // index of this lane's first step inside the tile
+            const int tq = tile & 1;                     // buffer parity of the per-tile LDS regions
+            Vd<kSPL> tb, h;
+#pragma unroll
+            for (int s = 0; s < kSPL; ++s) {
+                tb[s] = tb_next[s];
+                tb_next[s] = sh.tgrid[min(i0 + kTile + s + 1, nsteps)];
+            }
+            const double ta0 = ta_next;
+            ta_next = sh.tgrid[min(i0 + kTile, nsteps)];
+#pragma unroll
+            for (int s = 0; s < kSPL; ++s) h[s] = tb[s] - (s == 0 ? ta0 : tb[s - 1]);   // 0 for the padding steps
+
+            // ---------------- Mdisc (2 barriers)
+            Vd<kSPL> M1;
+            double ES[kSPL + 3];
+            {
+                const Vd<kSPL> S1 = mdot_fb(w, tb);
+#pragma unroll
+                for (int s = 0; s < kSPL; ++s) { ES[3 + s] = S1[s]; lds.s[e0 + s + 3] = S1[s]; }
+                if (gl == 0) { lds.s[2] = cS0; lds.s[1] = cS1; lds.s[0] = cS2; }
+                __syncthreads();
+                ES[2] = lds.s[e0 + 2]; ES[1] = lds.s[e0 + 1]; ES[0] = lds.s[e0];
+                Vd<kSPL> zm, v0, v1, v2, v3;
+#pragma unroll
+                for (int s = 0; s < kSPL; ++s) {
+                    zm[s] = -h[s] * w.inv_tau;
+                    v0[s] = ES[3 + s]; v1[s] = ES[2 + s]; v2[s] = ES[1 + s]; v3[s] = ES[s];
+                }
+                const Phi<kSPL> pm = phi1234(zm);
+                const Vd<kSPL> inc = eam4_increment(sh, pm, h, v0, v1, v2, v3);
+                double A = 1.0, B = 0.0;
+#pragma unroll
+                for (int s = 0; s < kSPL; ++s) { B = fma(pm.e[s], B, inc[s]); A = A * pm.e[s]; }
+                double M_wave;
+                scan_affine_block<W>(A, B, lds.tot[tp], wave, lane, M_s, M_wave);
+                tp ^= 1;
+                const double Ax = lane_prev(A, 1.0), Bx = lane_prev(B, 0.0);
+                double Mc = fma(Ax, M_wave, Bx);
+#pragma unroll
+                for (int s = 0; s < kSPL; ++s) { Mc = fma(pm.e[s], Mc, inc[s]); M1[s] = Mc; }
+            }
+            const DiscPt<kSPL> d1 = disc_point(sh, w, M1);
+
+            // ---------------- omega: predictor
+            Vd<kSPL> wg;
+            {
+                const double g1 = om_s - cw1, g2 = g1 - (cw1 - cw2);
+                const double d2b = (cw1 - cw2) - (cw2 - cw3);
+                const double g3 = tile == 0 ? 0.0 : g2 - d2b;
+                const double g4 = tile == 0 ? 0.0 : g3 - (d2b - ((cw2 - cw3) - (cw3 - cw4)));
+#pragma unroll
+                for (int s = 0; s < kSPL; ++s) {
+                    const double k = (double)(e0 + s + 1);
+                    const double c2 = 0.5 * k * (k + 1.0);
+                    const double c3 = c2 * (k + 2.0) * (1.0 / 3.0);
+                    wg[s] = fma(k, g1, fma(c2, g2, fma(c3, g3, fma(c3 * (k + 3.0) * 0.25, g4, om_s))));
+                }
+            }
+            // ---------------- Newton sweeps.  Each pass starts with the right-hand side at the current values and ONE
+            // barrier that publishes (omega_dot, omega) for the neighbours together with every wavefront's verdict on the
+            // previous pass; when nobody is pending those values are final (and omega_dot is exact at them).  A full pass
+            // adds a second barrier for the scan totals.
+            Vd<kSPL> f1;
+            bool flagged = false, pending = true, not_ok = false, settled = false;
+            int sweep = 0;
+            double w_guard = om_s;
+            while (true) {
+                {
+                    bool wild = false;
+#pragma unroll
+                    for (int s = 0; s < kSPL; ++s) wild = wild || !(wg[s] > 0.0);
+                    if (__any(wild)) {
+#pragma unroll
+                        for (int s = 0; s < kSPL; ++s)
+                            if (!(wg[s] > 0.0)) wg[s] = w_guard > 0.0 ? w_guard : om_s;
+                    }
+                }
+                Vd<kSPL> rot, lam;
+                f1 = omega_rhs<true>(sh, w, d1, wg, rot, lam);
+                bool flg = false;
+#pragma unroll
+                for (int s = 0; s < kSPL; ++s) {
+                    lds.f[e0 + s + 3] = f1[s];
+                    lds.w[e0 + s + 3] = wg[s];
+                    flg = flg || (i0 + s < nsteps && rot[s] > 0.27);
+                }
+                if (gl == 0) {
+                    double h1 = cf1, h2 = cf2, u1 = cw1, u2 = cw2;
+                    if (tile == 0) {   // start-up ghosts: linear continuation of points 0 and 1 in the index
+                        h1 = 2.0 * cf0 - f1[0]; u1 = 2.0 * om_s - wg[0];
+                        h2 = 3.0 * cf0 - 2.0 * f1[0]; u2 = 3.0 * om_s - 2.0 * wg[0];
+                    }
+                    lds.f[2] = cf0; lds.f[1] = h1; lds.f[0] = h2;
+                    lds.w[2] = om_s; lds.w[1] = u1; lds.w[0] = u2;
+                }
+                {
+                    const int word = (__any(not_ok) ? 1 : 0) | (__any(settled && flg) ? 2 : 0);
+                    if (lane == 0) lds.flags[fp][wave] = word;
+                }
+                __syncthreads();
+                {
+                    int all = 0;
+#pragma unroll
+                    for (int v = 0; v < W; ++v) all |= lds.flags[fp][v];
+                    fp ^= 1;
+                    pending = sweep == 0 || (all & 1);
+                    flagged = flagged || (all & 2);
+                }
+                if (!pending || flagged || sweep >= kMaxSweeps) break;
+                ++sweep;
+                double Ef[kSPL + 3], Ew[kSPL + 3];
+#pragma unroll
+                for (int s = 0; s < kSPL; ++s) { Ef[3 + s] = f1[s]; Ew[3 + s] = wg[s]; }
+                Ef[2] = lds.f[e0 + 2]; Ef[1] = lds.f[e0 + 1]; Ef[0] = lds.f[e0];
+                Ew[2] = lds.w[e0 + 2]; Ew[1] = lds.w[e0 + 1]; Ew[0] = lds.w[e0];
+                w_guard = Ew[2];
+                Vd<kSPL> zw, n0, n1, n2, n3;
+#pragma unroll
+                for (int s = 0; s < kSPL; ++s) {
+                    zw[s] = h[s] * lam[s];
+                    n0[s] = fma(-lam[s], Ew[3 + s], Ef[3 + s]);
+                    n1[s] = fma(-lam[s], Ew[2 + s], Ef[2 + s]);
+                    n2[s] = fma(-lam[s], Ew[1 + s], Ef[1 + s]);
+                    n3[s] = fma(-lam[s], Ew[s], Ef[s]);
+                }
+                const Phi<kSPL> pw_ = phi1234(zw);
+                const Vd<kSPL> inc = eam4_increment(sh, pw_, h, n0, n1, n2, n3);
+                double A = 1.0, B = 0.0;
+#pragma unroll
+                for (int s = 0; s < kSPL; ++s) { B = fma(pw_.e[s], B, inc[s]); A = A * pw_.e[s]; }
+                double om_wave;
+                scan_affine_block<W>(A, B, lds.tot[tp], wave, lane, om_s, om_wave);   // barrier: also orders the LDS image reads
+                tp ^= 1;                                                              // before the next pass overwrites it
+                const double Ax = lane_prev(A, 1.0), Bx = lane_prev(B, 0.0);
+                double wc = fma(Ax, om_wave, Bx);
+                bool all_ok = true, all_settled = true;
+#pragma unroll
+                for (int s = 0; s < kSPL; ++s) {
+                    wc = fma(pw_.e[s], wc, inc[s]);
+                    const double dw = fabs(wc - wg[s]), mag = fabs(wc);
+                    all_settled = all_settled && (dw <= 1.0e-3 * mag);
+                    all_ok = all_ok && dw <= sh.sweep_tol * mag;
+                    wg[s] = wc;
+                }
+                settled = all_settled;
+                not_ok = !all_ok;
+            }
+            sweeps_total += sweep;
+
+            // ---------------- luminosity; then ONE barrier publishes the light-curve tile, the carries for the next tile
+            // and every wavefront's failure verdict
+            Vd<kSPL> Lt, Lp, Ld;
+            luminosity(sh, w, d1, wg, Lt, Lp, Ld);
+            {
+                bool bad = false, over = false;
+#pragma unroll
+                for (int s = 0; s < kSPL; ++s) {
+                    const bool act = i0 + s < nsteps;
+                    bad = bad || (act && (!(isfinite(M1[s]) && isfinite(wg[s])) || M1[s] <= 0.0 || wg[s] <= 0.0));
+                    over = over || (act && sh.crot * wg[s] * wg[s] > 0.27);
+                }
+                const unsigned long long mb = __ballot(bad), mo = __ballot(over);
+                if (lane == 0) {
+                    lds.fail[tq][2 * wave] = mb ? wave * 64 + __ffsll(mb) - 1 : 0x7fffffff;
+                    lds.fail[tq][2 * wave + 1] = mo ? wave * 64 + __ffsll(mo) - 1 : 0x7fffffff;
+                }
+#pragma unroll
+                for (int s = 0; s < kSPL; ++s) {
+                    lds.L[tq][e0 + s + 1] = Lt[s];
+                    const int back = kTile - 1 - (e0 + s);          // 0 = last step end of the tile
+                    if (back < 3) { lds.carry[tq][back] = ES[3 + s]; lds.carry[tq][3 + back] = f1[s]; }
+                    if (back < 5) lds.carry[tq][6 + back] = wg[s];
+                    if (back == 0) { lds.carry[tq][11] = M1[s]; lds.carry[tq][12] = Lt[s]; }
+                }
+                if (gl == 0) lds.L[tq][0] = L_s;
+                __syncthreads();
+                int first_bad = 0x7fffffff, first_flag = 0x7fffffff;
+#pragma unroll
+                for (int v = 0; v < W; ++v) { first_bad = min(first_bad, lds.fail[tq][2 * v]); first_flag = min(first_flag, lds.fail[tq][2 * v + 1]); }
+                // a tile whose sweeps flagged an iterate or never settled: the reference's 'flag' (walker_eval)
+                if (flagged || pending) first_flag = 0;
+                if (first_bad != 0x7fffffff || first_flag != 0x7fffffff) {
+                    status = first_flag <= first_bad ? MP_STATUS_FLAG : MP_STATUS_NONFINITE;
+                    break;
+                }
+                const bool mine = ob_tile == tile;
+                int j0 = 0, j1 = 0;
+                if (long_lc) { j0 = max(tptr[tile * kSPL * W], kRes); j1 = tptr[min((tile + 1) * kSPL * W, sh.n_tiles)]; }
+                if (mine) {
+                    const int g = ob_g - tile * kTile;
+                    const double La = lds.L[tq][g], Lb = lds.L[tq][g + 1];
+                    const double mod = fma((Lb - La) * ob_idt, ob_dx, La) / 1.0e50;
+                    const double res = (ob_y - mod) / ob_ye;
+                    chi = fma(res, res, chi);
+                }
+                for (int j = j0 + gl; j < j1; j += kRes) {
+                    const int jj = dsd.obs_off + j;
+                    const int g = sh.obs_g[jj] - tile * kTile;
+                    const double La = lds.L[tq][g], Lb = lds.L[tq][g + 1];
+                    const double mod = fma((Lb - La) * sh.obs_idt[jj], sh.obs_dx[jj], La) / 1.0e50;
+                    const double res = (sh.obs_y[jj] - mod) / sh.obs_yerr[jj];
+                    chi = fma(res, res, chi);
+                }
+                cS0 = lds.carry[tq][0]; cS1 = lds.carry[tq][1]; cS2 = lds.carry[tq][2];
+                cf0 = lds.carry[tq][3]; cf1 = lds.carry[tq][4]; cf2 = lds.carry[tq][5];
+                om_s = lds.carry[tq][6]; cw1 = lds.carry[tq][7]; cw2 = lds.carry[tq][8]; cw3 = lds.carry[tq][9]; cw4 = lds.carry[tq][10];
+                M_s = lds.carry[tq][11]; L_s = lds.carry[tq][12];
+            }
+        }
+    }
+
+    double lnp = -INFINITY;
+    if (status == MP_STATUS_OK) {
+        const double part = wave_sum(chi);
+        __syncthreads();
+        if (lane == 0) lds.tot[0][wave] = part;
+        __syncthreads();
+        double tot = 0.0;
+#pragma unroll
+        for (int v = 0; v < W; ++v) tot += lds.tot[0][v];
+        lnp = -0.5 * tot;
+        if (!isfinite(lnp)) { lnp = -INFINITY; status = MP_STATUS_NONFINITE; }
+    }
+    lnp_out = lnp;
+    status_out = status;
+    sweeps_out = sweeps_total;
+}
+
 // ---------------------------------------------------------------- batched log-posterior kernel
 template <bool CURVES, int SPL>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, SPL >= 4 ? 1 : 2))) void lnprob_kernel(const DevShared sh, const LaunchArgs a) {
@@ -808,6 +1145,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, SPL >= 4 
     double lnp;
     int status, sweeps;
     walker_eval<CURVES, SPL>(sh, a, walker, par, Lbuf, lnp, status, sweeps);
+    if (threadIdx.x == 0) {
+        a.lnprob[walker] = lnp;
+        if (a.status) a.status[walker] = status;
+        if (a.sweeps) a.sweeps[walker] = sweeps;
+    }
+}
+
+template <int SPL, int W>
+__global__ __launch_bounds__(64 * W) void lnprob_mw_kernel(const DevShared sh, const LaunchArgs a) {
+    __shared__ MwLds<SPL, W> lds;
+    const int walker = blockIdx.x;
+    double par[MP_MAX_NDIM];
+    const double *pw = a.pars + (size_t)walker * a.ndim;
+#pragma unroll
+    for (int i = 0; i < MP_MAX_NDIM; ++i) par[i] = i < a.ndim ? pw[i] : 0.0;
+    double lnp;
+    int status, sweeps;
+    walker_eval_mw<SPL, W>(sh, a, walker, par, lds, lnp, status, sweeps);
     if (threadIdx.x == 0) {
         a.lnprob[walker] = lnp;
         if (a.status) a.status[walker] = status;
@@ -853,9 +1208,9 @@ MP_DEV double u01(uint32_t hi, uint32_t lo) {   // 53-bit uniform in [0, 1)
 // proposal (emcee's StretchMove.get_proposal), evaluate its log-posterior with walker_eval, accept or
 // reject against the walker's current value, update position / lnprob / counters in place and write the
 // step's row of the chain.  Walkers of the complementary half are only read, so the update is race-free.
-template <int SPL>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, SPL >= 4 ? 1 : 2))) void stretch_kernel(const DevShared sh, const StretchArgs g) {
-    __shared__ double Lbuf[64 * SPL + 1];
+template <int SPL, int W>
+__global__ __launch_bounds__(64 * W) void stretch_kernel(const DevShared sh, const StretchArgs g) {
+    __shared__ typename std::conditional<(W > 1), MwLds<SPL, W>, double[64 * SPL + 1]>::type lds;
     const int w_ens = blockIdx.x / g.n_half;                       // which ensemble
     const int slot = blockIdx.x - w_ens * g.n_half;                // which walker of the active half
     const int32_t *perm = g.perm + (size_t)w_ens * g.n_walkers;    // this step's random split of the ensemble
@@ -893,7 +1248,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, SPL >= 4 
         for (int i = 0; i < MP_MAX_NDIM; ++i) lnp = i < g.ndim ? sub_rn(lnp, mul_rn(mul_rn(0.5, prop[i]), prop[i])) : lnp;
         status = MP_STATUS_OK;
     } else {
-        walker_eval<false, SPL>(sh, a, k, par, Lbuf, lnp, status, sweeps);
+        if constexpr (W > 1) walker_eval_mw<SPL, W>(sh, a, k, par, lds, lnp, status, sweeps);
+        else walker_eval<false, SPL>(sh, a, k, par, lds, lnp, status, sweeps);
     }
     if (threadIdx.x == 0) {
         const double lnp_old = g.lnprob[k];
@@ -912,31 +1268,42 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, SPL >= 4 
     }
 }
 
-int launch_stretch(const DevShared &sh, const StretchArgs &g, void *stream) {
-    const int n_blocks = g.n_half * g.n_ensembles;
-    if (n_blocks <= 0) return 0;
-    dim3 grid((unsigned)n_blocks), block(64);
-    if (kernel_spl(n_blocks) == 4) hipLaunchKernelGGL((stretch_kernel<4>), grid, block, 0, (hipStream_t)stream, sh, g);
-    else hipLaunchKernelGGL((stretch_kernel<2>), grid, block, 0, (hipStream_t)stream, sh, g);
-    return (int)hipGetLastError();
-}
-
 int launch_lnprob(const DevShared &sh, const LaunchArgs &a, void *stream) {
     if (a.n <= 0) return 0;
     const bool curves = a.ltot || a.lprop || a.ldip || a.mdisc || a.omega;
     dim3 grid((unsigned)a.n), block(64);
-    // Four steps per lane (256-step tiles) amortise the wavefront scans best and are the fastest variant while
-    // every walker can have a SIMD to itself (256 CUs x 4 SIMDs); it needs > 256 VGPRs-worth of state per two
-    // waves, so larger batches use two steps per lane, which keeps two waves resident per SIMD.
+    // Variants (results agree to rounding):
+    //  - batches that leave SIMDs idle (256 CUs x 4 SIMDs) put 4 or 2 wavefronts on every walker;
+    //  - up to 1536 walkers: one wavefront per walker, four steps per lane (256-step tiles amortise the
+    //    wavefront scans best; needs the whole register file of a SIMD);
+    //  - beyond: two steps per lane, which keeps two waves resident per SIMD.
     const bool wide = kernel_spl(a.n) == 4;
     hipStream_t st = (hipStream_t)stream;
-    if (curves) {
+    const int wpw = curves ? 1 : (sh.force_wpw ? sh.force_wpw : waves_per_walker(a.n));
+    if (wpw == 4) {
+        hipLaunchKernelGGL((lnprob_mw_kernel<1, 4>), grid, dim3(256), 0, st, sh, a);
+    } else if (wpw == 2) {
+        hipLaunchKernelGGL((lnprob_mw_kernel<2, 2>), grid, dim3(128), 0, st, sh, a);
+    } else if (curves) {
         if (wide) hipLaunchKernelGGL((lnprob_kernel<true, 4>), grid, block, 0, st, sh, a);
         else hipLaunchKernelGGL((lnprob_kernel<true, 2>), grid, block, 0, st, sh, a);
     } else {
         if (wide) hipLaunchKernelGGL((lnprob_kernel<false, 4>), grid, block, 0, st, sh, a);
         else hipLaunchKernelGGL((lnprob_kernel<false, 2>), grid, block, 0, st, sh, a);
     }
+    return (int)hipGetLastError();
+}
+
+int launch_stretch(const DevShared &sh, const StretchArgs &g, void *stream) {
+    const int n_blocks = g.n_half * g.n_ensembles;
+    if (n_blocks <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)n_blocks);
+    const int wpw = g.target == 1 ? 1 : (sh.force_wpw ? sh.force_wpw : waves_per_walker(n_blocks));
+    if (wpw == 4) hipLaunchKernelGGL((stretch_kernel<1, 4>), grid, dim3(256), 0, st, sh, g);
+    else if (wpw == 2) hipLaunchKernelGGL((stretch_kernel<2, 2>), grid, dim3(128), 0, st, sh, g);
+    else if (kernel_spl(n_blocks) == 4) hipLaunchKernelGGL((stretch_kernel<4, 1>), grid, dim3(64), 0, st, sh, g);
+    else hipLaunchKernelGGL((stretch_kernel<2, 1>), grid, dim3(64), 0, st, sh, g);
     return (int)hipGetLastError();
 }
 

@@ -12,6 +12,12 @@ from conftest import CANON, REF_ATOL, REF_RTOL, TIGHT_ATOL, TIGHT_RTOL, TRUTHS, 
 pytestmark = pytest.mark.gpu
 
 GPU_VS_C_RTOL = 1e-10   # HIP kernel vs serial C oracle: same scheme, different evaluation order / algebra
+
+
+def kernel_variant(n):
+    """(wavefronts per walker, steps per lane) the library picks for a batch of n (mp_device.h): batches of different
+    variants agree to rounding, batches of the same variant bit for bit."""
+    return (4, 1) if n <= 256 else (2, 2) if n <= 512 else (1, 4) if n <= 1536 else (1, 2)
 LOG_MASK = 0b111100
 
 
@@ -292,7 +298,11 @@ def test_full_size_properties(synth_handle, gsynth, name, nwalk):
     assert np.array_equal(synth_handle.lnprob_batch(P[perm], ds_id=k), out[perm])          # bit-exact
     half = nwalk // 2
     split = np.concatenate([synth_handle.lnprob_batch(P[:half], ds_id=k), synth_handle.lnprob_batch(P[half:], ds_id=k)])
-    assert np.array_equal(split, out)                                                       # bit-exact
+    if kernel_variant(half) == kernel_variant(nwalk):
+        assert np.array_equal(split, out)                                                   # bit-exact
+    else:
+        fin_ = np.isfinite(out)
+        assert np.array_equal(np.isfinite(split), fin_) and np.allclose(split[fin_], out[fin_], rtol=1e-10, atol=0)
     # chi^2 laws: errors x2 -> lnlike / 4 ; dataset duplicated -> lnlike x 2
     x, y, yerr = gsynth[name + "_x"], gsynth[name + "_y"], gsynth[name + "_yerr"]
     synth_handle.set_dataset(20, x, y, 2.0 * yerr)
@@ -300,10 +310,9 @@ def test_full_size_properties(synth_handle, gsynth, name, nwalk):
     sub = P[:256]
     base = synth_handle.lnprob_batch(sub, ds_id=k)      # same batch size, hence same kernel variant, as below
     fin = np.isfinite(base)
-    # small batches run the 4-steps-per-lane kernel, large ones the 2-steps-per-lane kernel: same scheme,
-    # different tile length -> agreement to rounding, not bit for bit
-    if nwalk > 1536:
-        assert np.allclose(base[fin], out[:256][fin], rtol=1e-10, atol=0)
+    # batches of different size classes run different kernel variants (wavefronts per walker, steps per lane): same
+    # scheme, different tile length -> agreement to rounding, not bit for bit
+    assert np.allclose(base[fin], out[:256][fin], rtol=1e-10, atol=0)
     assert np.allclose(synth_handle.lnprob_batch(sub, ds_id=20)[fin], base[fin] / 4.0, rtol=1e-13, atol=0)
     assert np.allclose(synth_handle.lnprob_batch(sub, ds_id=21)[fin], base[fin] * 2.0, rtol=1e-13, atol=0)
 
