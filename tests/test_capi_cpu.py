@@ -52,6 +52,19 @@ def test_create_argument_validation():
     assert not L.mp_create(None, None, 0, 0)
 
 
+def test_only_log_spaced_grids_are_accepted():
+    """The integrator is built on np.logspace grids (the only ones the reference uses); anything else is refused."""
+    L = _capi.lib()
+    dp = ctypes.POINTER(ctypes.c_double)
+    t = np.linspace(1.0, 100.0, 200)
+    assert not L.mp_create(ctypes.byref(_capi.cfg_synth()), t.ctypes.data_as(dp), t.size, 0)
+    assert "log-spaced" in _capi.last_error()
+    t = np.logspace(0.0, 6.0, 10001)
+    t[5000] *= 1.0 + 1e-6
+    assert not L.mp_create(ctypes.byref(_capi.cfg_synth()), t.ctypes.data_as(dp), t.size, 0)
+    assert "log-spaced" in _capi.last_error()
+
+
 def test_product_never_imports_oracle():
     """The product package must not reference oracle/ in any way."""
     pkg = os.path.join(ROOT, "magprop_amd")
