@@ -15,7 +15,11 @@ import numpy as np
 
 from . import _capi, engine
 
-_LIMITS_CSV = os.path.join(os.path.dirname(os.path.abspath(__file__)), "mcmc_limits.csv")
+# Default prior box: the values of the reference's magnetar/mcmc_limits.csv:2-10 (rows B, P, log_MdiscI, log_RdiscI,
+# log_epsilon, log_delta, dipeff, propeff, f_beam), kept in code so that nothing depends on the working directory
+# (the reference re-reads a cwd-relative CSV on every call, magnetar/mcmc_eqns.py:55).
+DEFAULT_LIMITS_LOWER = np.array([1.0e-3, 0.69, -3.0, np.log10(50.0), -1.0, -5.0, 0.01, 0.01, 1.0])
+DEFAULT_LIMITS_UPPER = np.array([10.0, 10.0, -1.0, np.log10(2000.0), 3.0, np.log10(50.0), 1.0, 1.0, 600.0])
 _limits_cache = {}
 LIB_LOG_MASK = 0b111100
 
@@ -39,7 +43,7 @@ def _read_limits(path):
 
 
 def _bounds(ndim, custom_lims=None):
-    lo, hi = _read_limits(_LIMITS_CSV if custom_lims is None else custom_lims)
+    lo, hi = (DEFAULT_LIMITS_LOWER, DEFAULT_LIMITS_UPPER) if custom_lims is None else _read_limits(custom_lims)
     if ndim == 7:  # :64-75: the 7th parameter is f_beam, the last row
         return np.append(lo[:6], lo[-1]), np.append(hi[:6], hi[-1])
     return lo[:ndim].copy(), hi[:ndim].copy()

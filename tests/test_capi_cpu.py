@@ -96,8 +96,8 @@ def test_synth_lnprior(gsynth):
 
 def test_lib_lnprior_matches_reference(glib):
     """magnetar/mcmc_eqns.py:40-84 incl. the 7-parameter special case, on golden cases."""
-    assert np.array_equal(mcmc_eqns._read_limits(mcmc_eqns._LIMITS_CSV)[0], glib["limits_lower"])
-    assert np.array_equal(mcmc_eqns._read_limits(mcmc_eqns._LIMITS_CSV)[1], glib["limits_upper"])
+    assert np.array_equal(mcmc_eqns.DEFAULT_LIMITS_LOWER, glib["limits_lower"])
+    assert np.array_equal(mcmc_eqns.DEFAULT_LIMITS_UPPER, glib["limits_upper"])
     for row, ref in zip(glib["lnprior_pars"], glib["lnprior"]):
         p = row[~np.isnan(row)]
         assert mcmc_eqns.lnprior(p) == ref
