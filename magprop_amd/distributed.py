@@ -49,3 +49,68 @@ class ShardedLnprob:
         else:
             dist.all_gather_into_tensor(self._buf, local, group=self.group)
         return self._buf[:n]
+
+
+class DistributedStretchSampler:
+    """emcee's stretch move with the walkers' log-posterior evaluations sharded over the process group.
+
+    Every rank holds the full ensemble state and draws the same random numbers (replicated generator, same seed), so
+    the proposals of a half-step are identical everywhere; rank r evaluates its contiguous block of them on its GPU and
+    ONE all-gather of the lnprob slices (RCCL over xGMI) lets every rank take the same accept/reject decisions — the
+    pattern BASELINE.json's north star describes for 8 GPUs.  The move itself is a handful of small tensor operations on
+    the state's device; the single-GPU, fully fused version is `magprop_amd.EnsembleSampler`.
+
+    eval_local(pars_local) -> lnprob of the local block (same device), e.g. `LogProb.lnprob_device`.
+    """
+
+    def __init__(self, eval_local, nwalkers, ndim, seed=0, a=2.0, group=None, device="cpu", via_host=False):
+        if nwalkers % 2 or nwalkers < 2:
+            raise ValueError("nwalkers must be even")
+        self.nwalkers, self.ndim, self.a = int(nwalkers), int(ndim), float(a)
+        self.device = torch.device(device)
+        self.lnprob_fn = ShardedLnprob(eval_local, group=group, via_host=via_host)
+        self.gen = torch.Generator(device="cpu").manual_seed(int(seed))     # replicated on every rank
+        self.pos = None
+        self.lnp = None
+        self.naccepted = torch.zeros(self.nwalkers, dtype=torch.int64, device=self.device)
+        self.iteration = 0
+
+    def _rand(self, n):
+        return torch.rand(n, dtype=torch.float64, generator=self.gen).to(self.device)
+
+    def run_mcmc(self, pos, nsteps, store=True):
+        """Returns (chain[nsteps, nwalkers, ndim], lnprob[nsteps, nwalkers]) on the state's device (or None, None)."""
+        if pos is not None:
+            self.pos = torch.as_tensor(pos, dtype=torch.float64).to(self.device).contiguous().clone()
+            if self.pos.shape != (self.nwalkers, self.ndim):
+                raise ValueError(f"pos must have shape {(self.nwalkers, self.ndim)}")
+            self.lnp = self.lnprob_fn(self.pos).clone()
+        if self.pos is None:
+            raise RuntimeError("no state: pass the initial positions first")
+        n, half = self.nwalkers, self.nwalkers // 2
+        chain = torch.empty(nsteps, n, self.ndim, dtype=torch.float64, device=self.device) if store else None
+        clnp = torch.empty(nsteps, n, dtype=torch.float64, device=self.device) if store else None
+        for step in range(nsteps):
+            perm = torch.randperm(n, generator=self.gen).to(self.device)           # random red/blue split
+            for h in range(2):
+                act = perm[h * half:(h + 1) * half]
+                comp = perm[(1 - h) * half:(2 - h) * half]
+                zz = ((self.a - 1.0) * self._rand(half) + 1.0) ** 2 / self.a          # g(z) ~ 1/sqrt(z) on [1/a, a]
+                partner = comp[torch.randint(half, (half,), generator=self.gen).to(self.device)]
+                xk, xj = self.pos[act], self.pos[partner]
+                prop = (xj - (xj - xk) * zz[:, None]).contiguous()
+                new = self.lnprob_fn(prop)                                         # sharded kernel + all-gather
+                lnpdiff = (self.ndim - 1.0) * torch.log(zz) + new - self.lnp[act]
+                accept = lnpdiff > torch.log(self._rand(half))                     # False for NaN / -inf proposals
+                self.pos[act] = torch.where(accept[:, None], prop, xk)
+                self.lnp[act] = torch.where(accept, new, self.lnp[act])
+                self.naccepted[act] += accept.to(torch.int64)
+            if store:
+                chain[step] = self.pos
+                clnp[step] = self.lnp
+            self.iteration += 1
+        return chain, clnp
+
+    @property
+    def acceptance_fraction(self):
+        return self.naccepted.to(torch.float64) / max(self.iteration, 1)

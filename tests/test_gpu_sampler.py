@@ -122,3 +122,22 @@ def test_sampler_argument_validation(gsynth):
     from magprop_amd import _capi
     with pytest.raises(_capi.MagpropAmdError):
         s.run_mcmc(None, 1)              # no state yet
+
+
+def test_sharded_stretch_sampler_on_device(gsynth):
+    """magprop_amd.distributed.DistributedStretchSampler driving the HIP path through device tensors (one rank)."""
+    import torch
+    from magprop_amd import LogProb
+    from magprop_amd.distributed import DistributedStretchSampler
+    x, y, yerr = gsynth["Humped_x"], gsynth["Humped_y"], gsynth["Humped_yerr"]
+    lp = LogProb(x, y, yerr, device=0)
+    rng = np.random.default_rng(4)
+    pos = np.array(TRUTHS["Humped"]) + 1.0e-4 * rng.standard_normal((64, 6))
+    s = DistributedStretchSampler(lp.lnprob_device, 64, 6, seed=9, device="cuda:0")
+    chain, lnp = s.run_mcmc(pos, 80)
+    torch.cuda.synchronize()
+    c, l = chain.cpu().numpy(), lnp.cpu().numpy()
+    assert np.all(np.isfinite(l))
+    assert np.array_equal(lp(c[-1]), l[-1])            # stored values are the kernel's values at the stored positions
+    assert 0.15 < float(s.acceptance_fraction.mean()) < 0.8
+    assert np.std(c[-1][:, 0]) > 1e-4
