@@ -366,11 +366,17 @@ MP_DEV Flow<N> flow_state(const Walker &w, double n, const DiscPt<N> &p, const V
     FORN f.sq[i] = f.capped[i] ? w.sqrt_kc * y[i] : p.squ[i];       // sqrt(Rm)
     FORN f.fast[i] = f.capped[i] ? w.Kc * y[i] : om[i] * p.qu[i];
     FORN x[i] = fma(n, f.fast[i], -n);
-    FORN ea[i] = fmax(-2.0 * fabs(x[i]), -750.0);
-    f.e = exp_fast(ea);
-    FORN den[i] = 1.0 + f.e[i];
-    f.r = rcp_fast(den);
-    FORN f.th[i] = copysign((1.0 - f.e[i]) * f.r[i], x[i]);        // tanh(x) = eta2 - eta1
+    bool saturated = true;                                          // |x| > 19.5: tanh(x) = +-1 to the last bit
+    FORN saturated = saturated && fabs(x[i]) > 19.5;
+    if (__all(saturated)) {                                         // wave-uniform: deep propeller / deep accretion tiles
+        FORN { f.e[i] = 0.0; f.r[i] = 1.0; f.th[i] = copysign(1.0, x[i]); }
+    } else {
+        FORN ea[i] = fmax(-2.0 * fabs(x[i]), -750.0);
+        f.e = exp_fast(ea);
+        FORN den[i] = 1.0 + f.e[i];
+        f.r = rcp_fast(den);
+        FORN f.th[i] = copysign((1.0 - f.e[i]) * f.r[i], x[i]);    // tanh(x) = eta2 - eta1
+    }
     FORN f.big[i] = f.Rm[i] >= kR;
     return f;
 }
