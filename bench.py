@@ -67,7 +67,7 @@ def cpu_baseline(grb, budget_s, seed):
     tarr = lp.grid("L")
     cores = usable_cores()
     rng = np.random.default_rng(seed)
-    P = np.array(TRUTH[grb]) + 1.0e-4 * rng.standard_normal((4096, 6))
+    P = np.array(TRUTH[grb]) + 1.0e-4 * rng.standard_normal((16384, 6))
     ctx = mp.get_context("fork")
     done, t_used, vals = 0, 0.0, []
     with ctx.Pool(cores, initializer=lp._pool_init, initargs=(tarr, x, y, yerr)) as pool:
