@@ -1,0 +1,853 @@
+// mp_eval.hpp — evaluation of ONE walker's log-posterior on a wavefront (walker_eval) or on the W wavefronts of a
+// workgroup (walker_eval_mw): physics of the reference's RHS / luminosity stage in simplified algebra and the
+// time-parallel exponential Adams-Moulton solver.  Included by mp_kernels.hip only.
+#pragma once
+#include "mp_math.hpp"
+
+namespace mp {
+
+// ---------------------------------------------------------------- per-walker constants
+struct Walker {
+    double inv_tau;   // 1/tvisc
+    double S_amp;     // M0/tfb
+    double inv_tfb;   // 1/tfb
+    double Crm;       // mu^(4/7) GM^(-1/7) f_Rm^(-2/7)
+    double DI;        // mu^2/(6 c^3 I)          dipole torque / I = -DI*omega^3
+    double D;         // mu^2/(6 c^3)
+    double armI;      // sqrt(GM)/I
+    double kc;        // k*c
+    double sqrt_kc;   // sqrt(k*c)
+    double Kc;        // (k*c)^1.5 / sqrt(GM): fastness of a capped Alfven radius = Kc/sqrt(omega)
+    double dipeff, propeff, f_beam;
+};
+
+// What the omega equation needs to know about the disc at the N time points of a lane (all omega-independent,
+// computed once per tile in the time-parallel Mdisc phase).
+template <int N>
+struct DiscPt {
+    Vd<N> mdot;  // Mdisc/tvisc
+    Vd<N> rmu;   // uncapped Alfven radius, code/synthetic_datasets/funcs.py:105-106
+    Vd<N> squ;   // sqrt(rmu)
+    Vd<N> qu;    // rmu^1.5/sqrt(GM): uncapped fastness = omega*qu
+};
+
+template <int N>
+MP_DEV DiscPt<N> disc_point(const DevShared &sh, const Walker &w, const Vd<N> &Mdisc) {
+    DiscPt<N> p;
+    FORN p.mdot[i] = Mdisc[i] * w.inv_tau;
+    const Vd<N> pw_ = pow_m2_7_fast(p.mdot);
+    FORN p.rmu[i] = w.Crm * pw_[i];                                 // Crm * mdot^(-2/7)
+    const Vd<N> rs = rsqrt_fast(p.rmu);
+    FORN p.squ[i] = p.rmu[i] * rs[i];
+    FORN p.qu[i] = p.rmu[i] * p.squ[i] * sh.inv_sqrtGM;
+    return p;
+}
+
+// fallback accretion rate Mdotfb(t), code/synthetic_datasets/funcs.py:128
+template <int N>
+MP_DEV Vd<N> mdot_fb(const Walker &w, const Vd<N> &t) {
+    Vd<N> u;
+    FORN u[i] = fma(t[i], w.inv_tfb, 1.0);                          // (t + tfb)/tfb >= 1
+    const Vd<N> r = rcbrt_fast(u);
+    Vd<N> out;
+    FORN { const double r2 = r[i] * r[i]; out[i] = w.S_amp * (r2 * r2 * r[i]); }   // u^(-5/3)
+    return out;
+}
+
+// Radii / fastness / switch shared by the ODE right-hand side and the luminosity stage
+// (code/synthetic_datasets/funcs.py:105-123 / magnetar/funcs.py:64-84 in simplified algebra):
+//   Rm = min(rmu, k c/omega);  fastness = (Rm/Rc)^1.5 = omega Rm^1.5/sqrt(GM);  tanh(n (fastness-1)).
+template <int N>
+struct Flow {
+    Vd<N> inv_om, Rm, sq, fast, e, r, th;
+    Vb<N> capped, big;
+};
+
+template <int N>
+MP_DEV Flow<N> flow_state(const Walker &w, double n, const DiscPt<N> &p, const Vd<N> &om) {
+    Flow<N> f;
+    const Vd<N> y = rsqrt_fast(om);
+    Vd<N> x, ea, den;
+    FORN f.inv_om[i] = y[i] * y[i];
+    FORN {
+        const double rlc = w.kc * f.inv_om[i];
+        f.capped[i] = p.rmu[i] >= rlc;                              // Rm >= k*Rlc -> Rm = k*Rlc
+        f.Rm[i] = f.capped[i] ? rlc : p.rmu[i];
+    }
+    FORN f.sq[i] = f.capped[i] ? w.sqrt_kc * y[i] : p.squ[i];       // sqrt(Rm)
+    FORN f.fast[i] = f.capped[i] ? w.Kc * y[i] : om[i] * p.qu[i];
+    FORN x[i] = fma(n, f.fast[i], -n);
+    bool saturated = true;                                          // |x| > 19.5: tanh(x) = +-1 to the last bit
+    FORN saturated = saturated && fabs(x[i]) > 19.5;
+    if (__all(saturated)) {                                         // wave-uniform: deep propeller / deep accretion tiles
+        FORN { f.e[i] = 0.0; f.r[i] = 1.0; f.th[i] = copysign(1.0, x[i]); }
+    } else {
+        FORN ea[i] = fmax(-2.0 * fabs(x[i]), -750.0);
+        f.e = exp_fast(ea);
+        FORN den[i] = 1.0 + f.e[i];
+        f.r = rcp_fast(den);
+        FORN f.th[i] = copysign((1.0 - f.e[i]) * f.r[i], x[i]);    // tanh(x) = eta2 - eta1
+    }
+    FORN f.big[i] = f.Rm[i] >= kR;
+    return f;
+}
+
+// d(omega)/dt, code/synthetic_datasets/funcs.py:119,131-140; lam = d(omega_dot)/d(omega)
+template <bool WANT_LAM, int N>
+MP_DEV Vd<N> omega_rhs(const DevShared &sh, const Walker &w, const DiscPt<N> &p, const Vd<N> &om, Vd<N> &rot,
+                       Vd<N> &lam) {
+    const Flow<N> f = flow_state(w, sh.cfg.n_ode, p, om);
+    Vd<N> out;
+    FORN {
+        const double om2 = om[i] * om[i];
+        rot[i] = sh.crot * om2;
+        // break-up (Nacc = 0) as a 0/1 factor: only the high dword of the double differs
+        const double live = __hiloint2double(rot[i] > 0.27 ? 0 : 0x3FF00000, 0);
+        const double arm = live * (w.armI * fmax(f.sq[i], sh.sqrtR));      // sqrt(GM*max(Rm,R))/I, or 0 beyond break-up
+        const double nacc = -arm * p.mdot[i] * f.th[i];                    // Nacc/I ; Macc - Mprop = -tanh * mdot
+        if (WANT_LAM) {
+            const double cf = __hiloint2double(f.capped[i] ? (int)0xBFE00000 : 0x3FF00000, 0);   // -0.5 : 1.0
+            const double dfast = cf * f.fast[i] * f.inv_om[i];
+            const double dth = sh.cfg.n_ode * (4.0 * f.e[i] * f.r[i] * f.r[i]) * dfast;   // n sech^2 dfast
+            const double cd = __hiloint2double((f.capped[i] && f.sq[i] >= sh.sqrtR) ? (int)0xBFE00000 : 0, 0);   // -0.5 : 0
+            const double darm = cd * arm * f.inv_om[i];
+            const double dn = -p.mdot[i] * fma(darm, f.th[i], arm * dth);
+            lam[i] = fma(-3.0 * w.DI, om2, dn);
+        }
+        out[i] = fma(-w.DI * om2, om[i], nacc);
+    }
+    return out;
+}
+
+// luminosities (erg/s) at the lane's N grid points, reference luminosity stage
+// (code/synthetic_datasets/funcs.py:204-229, magnetar/funcs.py:191-210)
+template <int N>
+MP_DEV void luminosity(const DevShared &sh, const Walker &w, const DiscPt<N> &p, const Vd<N> &om, Vd<N> &Ltot,
+                       Vd<N> &Lprop, Vd<N> &Ldip) {
+    const Flow<N> f = flow_state(w, sh.cfg.n_lum, p, om);
+    Vd<N> irm;
+    if (sh.cfg.lprop_gm_term) irm = rcp_fast(f.Rm);
+    FORN {
+        const double eta2 = f.th[i] >= 0.0 ? f.r[i] : f.e[i] * f.r[i];     // 0.5*(1 + tanh x)
+        const double om2 = om[i] * om[i];
+        const double rot = sh.crot * om2;
+        const double arm = sh.sqrtGM * (f.big[i] ? f.sq[i] : sh.sqrtR);
+        const double Nacc = rot > sh.cfg.nacc_lum_threshold ? 0.0 : -arm * p.mdot[i] * f.th[i];
+        double ld = w.dipeff * (w.D * om2 * om2);
+        if (ld <= 0.0) ld = 0.0;
+        if (!isfinite(ld)) ld = 0.0;
+        double lp = -Nacc * om[i];
+        if (sh.cfg.lprop_gm_term) lp -= sh.GM * irm[i] * eta2 * p.mdot[i];
+        lp *= w.propeff;
+        if (lp <= 0.0) lp = 0.0;
+        if (!isfinite(lp)) lp = 0.0;
+        Ltot[i] = w.f_beam * (ld + lp);
+        Lprop[i] = lp;
+        Ldip[i] = ld;
+    }
+}
+
+// Prior box, un-logging of the log-masked coordinates and the per-walker constants
+// (code/synthetic_datasets/mcmc_eqns.py:16-17,28-49; funcs.py:98-102).  Returns MP_STATUS_OK or MP_STATUS_PRIOR.
+MP_DEV int walker_setup(const DevShared &sh, const LaunchArgs &a, double (&par)[MP_MAX_NDIM], Walker &w) {
+    // ---- prior, un-logging (code/synthetic_datasets/mcmc_eqns.py:16-17,28-49)
+    int status = MP_STATUS_OK;
+    if (!a.physical) {
+        bool outside = false;
+#pragma unroll
+        for (int i = 0; i < MP_MAX_NDIM; ++i)
+            if (i < sh.n_prior && (!(par[i] >= sh.lower[i]) || !(par[i] <= sh.upper[i]))) outside = true;
+        if (outside) status = MP_STATUS_PRIOR;
+#pragma unroll
+        for (int i = 0; i < MP_MAX_NDIM; ++i)
+            if (i < a.ndim && ((sh.log_mask >> i) & 1u)) par[i] = pow(10.0, par[i]);
+    }
+
+    // ---- walker constants (code/synthetic_datasets/funcs.py:98-102)
+    {
+        const double B = par[0], MdiscI = par[2], RdiscI = par[3], epsilon = par[4], delta = par[5];
+        const double tau = (RdiscI * 1.0e5) / (sh.cfg.alpha * sh.cfg.cs7 * 1.0e7);
+        const double mu = 1.0e15 * B * (kR * kR * kR);
+        const double M0 = delta * MdiscI * kMsol;
+        const double tfb = epsilon * tau;
+        w.inv_tau = 1.0 / tau;
+        w.S_amp = M0 / tfb;
+        w.inv_tfb = 1.0 / tfb;
+        w.Crm = pow(mu, 4.0 / 7.0) * pow(sh.GM, -1.0 / 7.0) * pow(sh.cfg.rm_massflow_factor, -2.0 / 7.0);
+        w.D = (mu * mu) / (6.0 * kC * kC * kC);
+        w.DI = w.D * sh.inv_inertia;
+        w.armI = sh.sqrtGM * sh.inv_inertia;
+        w.kc = sh.cfg.k * kC;
+        w.sqrt_kc = sqrt(w.kc);
+        w.Kc = w.kc * w.sqrt_kc * sh.inv_sqrtGM;
+        w.dipeff = sh.cfg.dipeff;
+        w.propeff = sh.cfg.propeff;
+        w.f_beam = sh.cfg.f_beam;
+        // 7/8/9-parameter likelihoods, magnetar/mcmc_eqns.py:22-34
+        if (a.ndim == 7) w.f_beam = par[6];
+        if (a.ndim == 8) { w.dipeff = par[6]; w.propeff = par[7]; }
+        if (a.ndim == 9) { w.dipeff = par[6]; w.propeff = par[7]; w.f_beam = par[8]; }
+    }
+
+    return status;
+}
+
+constexpr int kMaxSweepsMargin = 16;  // sweeps allowed beyond the tile length (after which every step is exact)
+
+// ---------------------------------------------------------------- the kernel
+// Evaluate ONE walker on the calling wavefront (all 64 lanes enter with identical arguments).
+// SPL = consecutive steps owned by one lane; a tile is 64*SPL steps.  par[] holds the sampler coordinates
+// (prior checked and log-masked coordinates un-logged here unless a.physical); walker indexes ds_id and the
+// optional curve outputs; Lbuf is the wave's LDS tile [64*SPL + 1].
+template <bool CURVES, int SPL>
+MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, double (&par)[MP_MAX_NDIM], double *Lbuf,
+                        double &lnp_out, int &status_out, int &sweeps_out) {
+    constexpr int kSPL = SPL, kTile = 64 * SPL, kMaxSweeps = kTile + kMaxSweepsMargin;
+    const int n_tiles = (sh.n_grid - 1 + kTile - 1) / kTile;
+    const int lane = threadIdx.x & 63;
+
+    const int n_grid = sh.n_grid;
+    const int nsteps = n_grid - 1;
+    const size_t row = (size_t)walker * (size_t)n_grid;
+
+    Walker w;
+    int status = walker_setup(sh, a, par, w);
+
+    // ---- state carried from tile to tile (all wave-uniform).  Index 0 = the tile's start point P0,
+    // 1 = P0-1, 2 = P0-2: the history the multistep formulas reach back to.
+    const double t0 = sh.tgrid[0];
+    double t_s = t0;
+    double M_s = par[2] * kMsol;                         // initial conditions, code/synthetic_datasets/funcs.py:66-69
+    double om_s = (2.0 * M_PI) / (1.0e-3 * par[1]);
+    double cS0, cS1, cS2;
+    {
+        const Vd<3> tg{{t0, t0 * sh.inv_q, t0 * sh.inv_q * sh.inv_q}};     // the grid continued backwards
+        const Vd<3> Sg = mdot_fb(w, tg);
+        cS0 = Sg[0]; cS1 = Sg[1]; cS2 = Sg[2];
+    }
+    double cf0, cf1, cf2, cw1 = om_s, cw2 = om_s, cw3 = om_s, cw4 = om_s;   // (omega_dot, omega) history; cw0 == om_s (cw3, cw4: predictor only)
+    double L_s, Lp_s, Ld_s;
+    bool L_valid = true;          // L_s holds the luminosity at the current tile start
+    {
+        const Vd<1> Mv{{M_s}}, ov{{om_s}};
+        const DiscPt<1> d_s = disc_point(sh, w, Mv);
+        Vd<1> rot0, dummy, Lt0, Lp0, Ld0;
+        cf0 = omega_rhs<false>(sh, w, d_s, ov, rot0, dummy)[0];
+        cf1 = cf2 = cf0;
+        if (status == MP_STATUS_OK) {
+            if (!(isfinite(M_s) && isfinite(om_s)) || M_s <= 0.0 || om_s <= 0.0) status = MP_STATUS_NONFINITE;
+            else if (rot0[0] > 0.27) status = MP_STATUS_FLAG;
+        }
+        luminosity(sh, w, d_s, ov, Lt0, Lp0, Ld0);
+        L_s = Lt0[0]; Lp_s = Lp0[0]; Ld_s = Ld0[0];
+    }
+
+    const int dsid = a.ds_id ? a.ds_id[walker] : 0;
+    const DsDesc dsd = sh.ds ? sh.ds[(dsid >= 0 && dsid < sh.n_ds) ? dsid : 0] : DsDesc{0, 0, 0, 0};
+    const int32_t *tptr = sh.tile_ptr + dsd.tile_off;
+    // The first 64 observations of the walker's light curve live in registers, one per lane (time-sorted;
+    // every synthetic set has 50).  Longer light curves take the tile-bucketed global-memory path for the rest.
+    int ob_g = -1;
+    double ob_dx = 0.0, ob_idt = 0.0, ob_y = 0.0, ob_ye = 1.0;
+    if (a.want_chi2 && lane < dsd.n_obs) {
+        const int jj = dsd.obs_off + lane;
+        ob_g = sh.obs_g[jj];
+        ob_dx = sh.obs_dx[jj];
+        ob_idt = sh.obs_idt[jj];
+        ob_y = sh.obs_y[jj];
+        ob_ye = sh.obs_yerr[jj];
+    }
+    const int ob_tile = ob_g >= 0 ? ob_g / kTile : -1;
+    const bool long_lc = a.want_chi2 && dsd.n_obs > 64;
+    double chi = 0.0;
+    int sweeps_total = 0;
+
+    if (status == MP_STATUS_OK) {
+        if (CURVES && lane == 0) {
+            if (a.ltot) a.ltot[row] = L_s / 1.0e50;
+            if (a.lprop) a.lprop[row] = Lp_s / 1.0e50;
+            if (a.ldip) a.ldip[row] = Ld_s / 1.0e50;
+            if (a.mdisc) a.mdisc[row] = M_s;
+            if (a.omega) a.omega[row] = om_s;
+        }
+        // Each lane owns kSPL consecutive steps of the tile: steps tile*kTile + lane*kSPL + s, s = 0..kSPL-1.
+        // Step end times are fetched one tile ahead of their use.
+        double tb_next[kSPL];
+#pragma unroll
+        for (int s = 0; s < kSPL; ++s) tb_next[s] = sh.tgrid[min(lane * kSPL + s + 1, nsteps)];
+
+        for (int tile = 0; tile < n_tiles; ++tile) {
+            const int i0 = tile * kTile + lane * kSPL;   // this lane's first step: tgrid[i0] -> tgrid[i0+1]
+            Vd<kSPL> tb, h;
+            Vb<kSPL> active;
+#pragma unroll
+            for (int s = 0; s < kSPL; ++s) {
+                tb[s] = tb_next[s];
+                tb_next[s] = sh.tgrid[min(i0 + kTile + s + 1, nsteps)];
+                active[s] = i0 + s < nsteps;
+            }
+            {
+                const double ta0 = lane_prev(tb[kSPL - 1], t_s);
+#pragma unroll
+                for (int s = 0; s < kSPL; ++s) h[s] = tb[s] - (s == 0 ? ta0 : tb[s - 1]);   // 0 for the padding steps of the last tile
+            }
+
+            // ---------------- Mdisc: exponential Adams-Moulton step (explicit: the source is known) + affine scan.
+            // E*[k]: values at the three grid points before this lane's first step (k = 0,1,2) and at its step ends (k = 3+s).
+            Vd<kSPL> M1;
+            double ES[kSPL + 3];
+            {
+                const Vd<kSPL> S1 = mdot_fb(w, tb);
+#pragma unroll
+                for (int s = 0; s < kSPL; ++s) ES[3 + s] = S1[s];
+                ES[2] = lane_prev(ES[kSPL + 2], cS0);
+                ES[1] = lane_prev(ES[kSPL + 1], cS1);
+                ES[0] = lane_prev(ES[kSPL + 0], cS2);
+                Vd<kSPL> zm, v0, v1, v2, v3;
+#pragma unroll
+                for (int s = 0; s < kSPL; ++s) {
+                    zm[s] = -h[s] * w.inv_tau;
+                    v0[s] = ES[3 + s]; v1[s] = ES[2 + s]; v2[s] = ES[1 + s]; v3[s] = ES[s];
+                }
+                const Phi<kSPL> pm = phi1234(zm);
+                const Vd<kSPL> inc = eam4_increment(sh, pm, h, v0, v1, v2, v3);
+                Vd<kSPL> am, bm;
+                double A = 1.0, B = 0.0;                  // composition of this lane's step maps
+#pragma unroll
+                for (int s = 0; s < kSPL; ++s) {
+                    am[s] = pm.e[s];      // padding steps: h = 0 -> e = 1, inc = 0
+                    bm[s] = inc[s];
+                    B = fma(am[s], B, bm[s]);
+                    A = A * am[s];
+                }
+                scan_affine(A, B);
+                const double Ax = lane_prev(A, 1.0), Bx = lane_prev(B, 0.0);   // exclusive prefix
+                double Mc = fma(Ax, M_s, Bx);            // Mdisc at this lane's first step start
+#pragma unroll
+                for (int s = 0; s < kSPL; ++s) { Mc = fma(am[s], Mc, bm[s]); M1[s] = Mc; }
+            }
+            const DiscPt<kSPL> d1 = disc_point(sh, w, M1);
+
+            // ---------------- omega: predictor = extrapolation of the last five grid values in the step index
+            // (the grid is logarithmic, so power laws are smooth in the index) ...
+            Vd<kSPL> wg;                                  // current guess of omega at this lane's step ends
+            {
+                // Newton backward-difference extrapolation (quartic once five grid values exist)
+                const double g1 = om_s - cw1, g2 = g1 - (cw1 - cw2);
+                const double d2b = (cw1 - cw2) - (cw2 - cw3);
+                const double g3 = tile == 0 ? 0.0 : g2 - d2b;
+                const double g4 = tile == 0 ? 0.0 : g3 - (d2b - ((cw2 - cw3) - (cw3 - cw4)));
+#pragma unroll
+                for (int s = 0; s < kSPL; ++s) {
+                    const double k = (double)(lane * kSPL + s + 1);
+                    const double c2 = 0.5 * k * (k + 1.0);
+                    const double c3 = c2 * (k + 2.0) * (1.0 / 3.0);
+                    wg[s] = fma(k, g1, fma(c2, g2, fma(c3, g3, fma(c3 * (k + 3.0) * 0.25, g4, om_s))));
+                }
+            }
+            // ... then Newton-type sweeps of the linearised step maps
+            double Ef[kSPL + 3], Ew[kSPL + 3];
+            unsigned long long flagged = 0ull, pending = ~0ull;
+            bool settled = false;    // this lane's guesses moved by < 1e-3 in the previous sweep
+            int sweep = 0;
+            Ew[2] = om_s;
+            while (true) {
+                ++sweep;
+                {
+                    bool wild = false;
+#pragma unroll
+                    for (int s = 0; s < kSPL; ++s) wild = wild || !(wg[s] > 0.0);
+                    if (__any(wild)) {   // keep the iteration alive after a wild or NaN guess (rare)
+#pragma unroll
+                        for (int s = 0; s < kSPL; ++s)
+                            if (!(wg[s] > 0.0)) wg[s] = Ew[2] > 0.0 ? Ew[2] : om_s;
+                    }
+                }
+                Vd<kSPL> rot, lam;
+                const Vd<kSPL> f1 = omega_rhs<true>(sh, w, d1, wg, rot, lam);
+                bool flg = false;
+#pragma unroll
+                for (int s = 0; s < kSPL; ++s) {
+                    Ef[3 + s] = f1[s];
+                    Ew[3 + s] = wg[s];
+                    flg = flg || (active[s] && rot[s] > 0.27);
+                }
+                // break-up reached by an iterate that is no longer a wild guess: the reference's 'flag'
+                flagged |= __ballot(settled && flg);
+                double h1 = cf1, h2 = cf2, u1 = cw1, u2 = cw2;
+                if (tile == 0) {   // start-up: the two points before the grid continue points 0 and 1 linearly in the index
+                    const double fp1 = lane_bcast(Ef[3], 0), wp1 = lane_bcast(Ew[3], 0);
+                    h1 = 2.0 * cf0 - fp1; u1 = 2.0 * om_s - wp1;
+                    h2 = 3.0 * cf0 - 2.0 * fp1; u2 = 3.0 * om_s - 2.0 * wp1;
+                }
+                Ef[2] = lane_prev(Ef[kSPL + 2], cf0);  Ew[2] = lane_prev(Ew[kSPL + 2], om_s);
+                Ef[1] = lane_prev(Ef[kSPL + 1], h1);   Ew[1] = lane_prev(Ew[kSPL + 1], u1);
+                Ef[0] = lane_prev(Ef[kSPL + 0], h2);   Ew[0] = lane_prev(Ew[kSPL + 0], u2);
+                Vd<kSPL> zw, n0, n1, n2, n3;
+#pragma unroll
+                for (int s = 0; s < kSPL; ++s) {
+                    zw[s] = h[s] * lam[s];
+                    n0[s] = fma(-lam[s], Ew[3 + s], Ef[3 + s]);
+                    n1[s] = fma(-lam[s], Ew[2 + s], Ef[2 + s]);
+                    n2[s] = fma(-lam[s], Ew[1 + s], Ef[1 + s]);
+                    n3[s] = fma(-lam[s], Ew[s], Ef[s]);
+                }
+                const Phi<kSPL> pw_ = phi1234(zw);
+                const Vd<kSPL> inc = eam4_increment(sh, pw_, h, n0, n1, n2, n3);
+                Vd<kSPL> aw, bw;
+                double A = 1.0, B = 0.0;
+#pragma unroll
+                for (int s = 0; s < kSPL; ++s) {
+                    aw[s] = pw_.e[s];
+                    bw[s] = inc[s];
+                    B = fma(aw[s], B, bw[s]);
+                    A = A * aw[s];
+                }
+                scan_affine(A, B);
+                const double Ax = lane_prev(A, 1.0), Bx = lane_prev(B, 0.0);
+                double wc = fma(Ax, om_s, Bx);           // omega at this lane's first step start
+                bool all_ok = true, all_settled = true;
+#pragma unroll
+                for (int s = 0; s < kSPL; ++s) {
+                    wc = fma(aw[s], wc, bw[s]);
+                    const double dw = fabs(wc - wg[s]), mag = fabs(wc);
+                    all_settled = all_settled && (dw <= 1.0e-3 * mag);               // false for NaN
+                    all_ok = all_ok && dw <= sh.sweep_tol * mag;
+                    wg[s] = wc;
+                }
+                settled = all_settled;
+                pending = __ballot(!all_ok);
+                if (pending == 0ull || flagged != 0ull || sweep >= kMaxSweeps) break;
+            }
+            sweeps_total += sweep;
+
+            // ---------------- failure detection in time order (oracle/mp_oracle.c)
+            {
+                bool bad = false, over = false;
+#pragma unroll
+                for (int s = 0; s < kSPL; ++s) {
+                    bad = bad || (active[s] && (!(isfinite(M1[s]) && isfinite(wg[s])) || M1[s] <= 0.0 || wg[s] <= 0.0));
+                    over = over || (active[s] && sh.crot * wg[s] * wg[s] > 0.27);
+                }
+                const unsigned long long mb = __ballot(bad);
+                // a step whose sweeps never settle is chattering on the Nacc discontinuity: same verdict as a flag
+                const unsigned long long mf = flagged | __ballot(over) | (flagged ? 0ull : pending);
+                if (mb | mf) {
+                    const int first = __ffsll((unsigned long long)(mb | mf)) - 1;
+                    status = ((mf >> first) & 1ull) ? MP_STATUS_FLAG : MP_STATUS_NONFINITE;
+                    break;
+                }
+            }
+
+            // ---------------- luminosity at the step ends, light curve through LDS, chi^2
+            // (tiles that hold no observation and are not written out skip the luminosity stage altogether)
+            const bool mine = ob_tile == tile;
+            int j0 = 0, j1 = 0;
+            if (long_lc) { j0 = max(tptr[tile * kSPL], 64); j1 = tptr[min((tile + 1) * kSPL, sh.n_tiles)]; }   // 64-step buckets
+            const bool tile_has_obs = __any(mine) || j1 > j0;
+            Vd<kSPL> Lt, Lp, Ld;
+            if (CURVES || tile_has_obs) luminosity(sh, w, d1, wg, Lt, Lp, Ld);
+#pragma unroll
+            for (int s = 0; s < kSPL; ++s) {
+                if (CURVES && active[s]) {
+                    const size_t o = row + (size_t)(i0 + s) + 1;
+                    if (a.ltot) a.ltot[o] = Lt[s] / 1.0e50;
+                    if (a.lprop) a.lprop[o] = Lp[s] / 1.0e50;
+                    if (a.ldip) a.ldip[o] = Ld[s] / 1.0e50;
+                    if (a.mdisc) a.mdisc[o] = M1[s];
+                    if (a.omega) a.omega[o] = wg[s];
+                }
+            }
+            {
+                if (tile_has_obs) {
+#pragma unroll
+                    for (int s = 0; s < kSPL; ++s) Lbuf[lane * kSPL + s + 1] = Lt[s];
+                    if (!L_valid) {   // the previous tile skipped its luminosity stage: evaluate its end point now
+                        const Vd<1> Mv{{M_s}}, ov{{om_s}};
+                        const DiscPt<1> dps = disc_point(sh, w, Mv);
+                        Vd<1> l0, l1, l2;
+                        luminosity(sh, w, dps, ov, l0, l1, l2);
+                        L_s = l0[0];
+                        L_valid = true;
+                    }
+                    if (lane == 0) Lbuf[0] = L_s;
+                    __syncthreads();
+                    if (mine) {
+                        const int g = ob_g - tile * kTile;
+                        const double La = Lbuf[g], Lb = Lbuf[g + 1];
+                        const double mod = fma((Lb - La) * ob_idt, ob_dx, La) / 1.0e50;   // np.interp, then /1e50
+                        const double res = (ob_y - mod) / ob_ye;
+                        chi = fma(res, res, chi);
+                    }
+                    for (int j = j0 + lane; j < j1; j += 64) {
+                        const int jj = dsd.obs_off + j;
+                        const int g = sh.obs_g[jj] - tile * kTile;
+                        const double La = Lbuf[g], Lb = Lbuf[g + 1];
+                        const double mod = fma((Lb - La) * sh.obs_idt[jj], sh.obs_dx[jj], La) / 1.0e50;
+                        const double res = (sh.obs_y[jj] - mod) / sh.obs_yerr[jj];
+                        chi = fma(res, res, chi);
+                    }
+                    __syncthreads();
+                }
+            }
+
+            // ---------------- carry the tile end (and the history behind it) to the next tile: only full tiles
+            // have a successor, so the sources are the last three step ends of lane 63
+            if (tile + 1 < n_tiles) {
+                // step end number e of the tile (0-based) lives in lane e / kSPL, slot e % kSPL
+                constexpr int e1 = kTile - 2, e2 = kTile - 3, e3 = kTile - 4, e4 = kTile - 5;
+                cS0 = lane_bcast(ES[3 + kSPL - 1], 63);            cf0 = lane_bcast(Ef[3 + kSPL - 1], 63);
+                cS1 = lane_bcast(ES[3 + e1 % kSPL], e1 / kSPL);    cf1 = lane_bcast(Ef[3 + e1 % kSPL], e1 / kSPL);
+                cS2 = lane_bcast(ES[3 + e2 % kSPL], e2 / kSPL);    cf2 = lane_bcast(Ef[3 + e2 % kSPL], e2 / kSPL);
+                cw1 = lane_bcast(wg[e1 % kSPL], e1 / kSPL);
+                cw2 = lane_bcast(wg[e2 % kSPL], e2 / kSPL);
+                cw3 = lane_bcast(wg[e3 % kSPL], e3 / kSPL);
+                cw4 = lane_bcast(wg[e4 % kSPL], e4 / kSPL);
+                t_s = lane_bcast(tb[kSPL - 1], 63);
+                M_s = lane_bcast(M1[kSPL - 1], 63);
+                om_s = lane_bcast(wg[kSPL - 1], 63);
+                L_valid = CURVES || tile_has_obs;
+                if (L_valid) L_s = lane_bcast(Lt[kSPL - 1], 63);
+            }
+        }
+    }
+
+    double lnp = -INFINITY;
+    if (status == MP_STATUS_OK) {
+        lnp = -0.5 * wave_sum(chi);
+        if (!isfinite(lnp)) { lnp = -INFINITY; status = MP_STATUS_NONFINITE; }
+    }
+    lnp_out = lnp;
+    status_out = status;
+    sweeps_out = sweeps_total;
+}
+
+// ---------------------------------------------------------------- W wavefronts per walker
+// Small batches cannot give every SIMD a walker (256 CUs x 4 SIMDs): the stretch move only ever has half an
+// ensemble in flight, and the reference's own configuration has 24 walkers.  walker_eval_mw spreads ONE walker
+// over the W wavefronts of a 64*W-thread workgroup: a tile is 64*W*SPL steps, every lane still owns SPL
+// consecutive steps, the wavefront scans stay in DPP, and what has to cross wavefronts goes through LDS:
+//   - the step history (Mdotfb, omega_dot, omega at the three previous grid points) is read from an LDS image
+//     of the tile instead of the neighbouring lane;
+//   - the affine scan is completed with the per-wavefront totals;
+//   - loop exits are agreed with __syncthreads_or.
+// Same scheme, same arithmetic per step as walker_eval; only the tile length differs (results agree to
+// rounding, like the SPL variants).  lds: [2*(kTile+3) + 2*W + (kTile+1) + 16] doubles, see MwLds.
+template <int SPL, int W>
+struct MwLds {
+    static constexpr int kTile = 64 * W * SPL;
+    double s[kTile + 3];        // Mdotfb at step ends e = -3..kTile-1, stored at [e + 3]
+    double f[kTile + 3];        // omega_dot
+    double w[kTile + 3];        // omega
+    double tot[2][2 * W];       // per-wavefront scan totals (a, b); double-buffered by use
+    int flags[2][W];            // per-wavefront (pending | flagged << 1); double-buffered by sweep
+    double L[2][kTile + 1];     // model light curve of the tile; double-buffered by tile
+    double carry[2][16];        // tile-end state for the next tile; double-buffered by tile
+    int fail[2][2 * W];         // per-wavefront first non-finite / first over-limit lane; double-buffered by tile
+};
+
+// Complete a wavefront-level affine scan across the W wavefronts of the workgroup: x_wave = value at this
+// wavefront's first step start, given the tile's start value x0.  One barrier.
+template <int W>
+MP_DEV void scan_affine_block(double &A, double &B, double (&tot)[2 * W], int wave, int lane, double x0, double &x_wave) {
+    scan_affine(A, B);
+    if (lane == 63) { tot[2 * wave] = A; tot[2 * wave + 1] = B; }
+    __syncthreads();
+    double xw = x0;
+#pragma unroll
+    for (int v = 0; v < W; ++v)
+        if (v < wave) xw = fma(tot[2 * v], xw, tot[2 * v + 1]);
+    x_wave = xw;
+}
+
+template <int SPL, int W>
+MP_DEV void walker_eval_mw(const DevShared &sh, const LaunchArgs &a, int walker, double (&par)[MP_MAX_NDIM], MwLds<SPL, W> &lds,
+                           double &lnp_out, int &status_out, int &sweeps_out) {
+    constexpr int kSPL = SPL, kTile = 64 * W * SPL, kMaxSweeps = kTile + kMaxSweepsMargin;
+    const int n_tiles = (sh.n_grid - 1 + kTile - 1) / kTile;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, gl = threadIdx.x;
+    const int nsteps = sh.n_grid - 1;
+
+    Walker w;
+    int status = walker_setup(sh, a, par, w);
+
+    const double t0 = sh.tgrid[0];
+    double M_s = par[2] * kMsol;
+    double om_s = (2.0 * M_PI) / (1.0e-3 * par[1]);
+    double cS0, cS1, cS2;
+    {
+        const Vd<3> tg{{t0, t0 * sh.inv_q, t0 * sh.inv_q * sh.inv_q}};
+        const Vd<3> Sg = mdot_fb(w, tg);
+        cS0 = Sg[0]; cS1 = Sg[1]; cS2 = Sg[2];
+    }
+    double cf0, cf1, cf2, cw1 = om_s, cw2 = om_s, cw3 = om_s, cw4 = om_s;
+    double L_s;
+    {
+        const Vd<1> Mv{{M_s}}, ov{{om_s}};
+        const DiscPt<1> d_s = disc_point(sh, w, Mv);
+        Vd<1> rot0, dummy, Lt0, Lp0, Ld0;
+        cf0 = omega_rhs<false>(sh, w, d_s, ov, rot0, dummy)[0];
+        cf1 = cf2 = cf0;
+        if (status == MP_STATUS_OK) {
+            if (!(isfinite(M_s) && isfinite(om_s)) || M_s <= 0.0 || om_s <= 0.0) status = MP_STATUS_NONFINITE;
+            else if (rot0[0] > 0.27) status = MP_STATUS_FLAG;
+        }
+        luminosity(sh, w, d_s, ov, Lt0, Lp0, Ld0);
+        L_s = Lt0[0];
+    }
+
+    const int dsid = a.ds_id ? a.ds_id[walker] : 0;
+    const DsDesc dsd = sh.ds ? sh.ds[(dsid >= 0 && dsid < sh.n_ds) ? dsid : 0] : DsDesc{0, 0, 0, 0};
+    const int32_t *tptr = sh.tile_ptr + dsd.tile_off;
+    constexpr int kRes = 64 * W;                     // observations resident in registers (one per lane of the workgroup)
+    int ob_g = -1;
+    double ob_dx = 0.0, ob_idt = 0.0, ob_y = 0.0, ob_ye = 1.0;
+    if (a.want_chi2 && gl < dsd.n_obs) {
+        const int jj = dsd.obs_off + gl;
+        ob_g = sh.obs_g[jj]; ob_dx = sh.obs_dx[jj]; ob_idt = sh.obs_idt[jj]; ob_y = sh.obs_y[jj]; ob_ye = sh.obs_yerr[jj];
+    }
+    const int ob_tile = ob_g >= 0 ? ob_g / kTile : -1;
+    const bool long_lc = a.want_chi2 && dsd.n_obs > kRes;
+    double chi = 0.0;
+    int sweeps_total = 0;
+    int tp = 0;      // buffer parity of the scan totals
+    int fp = 0;      // buffer parity of the sweep flags
+
+    if (status == MP_STATUS_OK) {
+        double tb_next[kSPL];
+#pragma unroll
+        for (int s = 0; s < kSPL; ++s) tb_next[s] = sh.tgrid[min(gl * kSPL + s + 1, nsteps)];
+        double ta_next = sh.tgrid[min(gl * kSPL, nsteps)];
+
+        for (int tile = 0; tile < n_tiles; ++tile) {
+            const int i0 = tile * kTile + gl * kSPL;
+            const int e0 = gl * kSPL;                    // index of this lane's first step inside the tile
+            const int tq = tile & 1;                     // buffer parity of the per-tile LDS regions
+            Vd<kSPL> tb, h;
+#pragma unroll
+            for (int s = 0; s < kSPL; ++s) {
+                tb[s] = tb_next[s];
+                tb_next[s] = sh.tgrid[min(i0 + kTile + s + 1, nsteps)];
+            }
+            const double ta0 = ta_next;
+            ta_next = sh.tgrid[min(i0 + kTile, nsteps)];
+#pragma unroll
+            for (int s = 0; s < kSPL; ++s) h[s] = tb[s] - (s == 0 ? ta0 : tb[s - 1]);   // 0 for the padding steps
+
+            // ---------------- Mdisc (2 barriers)
+            Vd<kSPL> M1;
+            double ES[kSPL + 3];
+            {
+                const Vd<kSPL> S1 = mdot_fb(w, tb);
+#pragma unroll
+                for (int s = 0; s < kSPL; ++s) { ES[3 + s] = S1[s]; lds.s[e0 + s + 3] = S1[s]; }
+                if (gl == 0) { lds.s[2] = cS0; lds.s[1] = cS1; lds.s[0] = cS2; }
+                __syncthreads();
+                ES[2] = lds.s[e0 + 2]; ES[1] = lds.s[e0 + 1]; ES[0] = lds.s[e0];
+                Vd<kSPL> zm, v0, v1, v2, v3;
+#pragma unroll
+                for (int s = 0; s < kSPL; ++s) {
+                    zm[s] = -h[s] * w.inv_tau;
+                    v0[s] = ES[3 + s]; v1[s] = ES[2 + s]; v2[s] = ES[1 + s]; v3[s] = ES[s];
+                }
+                const Phi<kSPL> pm = phi1234(zm);
+                const Vd<kSPL> inc = eam4_increment(sh, pm, h, v0, v1, v2, v3);
+                double A = 1.0, B = 0.0;
+#pragma unroll
+                for (int s = 0; s < kSPL; ++s) { B = fma(pm.e[s], B, inc[s]); A = A * pm.e[s]; }
+                double M_wave;
+                scan_affine_block<W>(A, B, lds.tot[tp], wave, lane, M_s, M_wave);
+                tp ^= 1;
+                const double Ax = lane_prev(A, 1.0), Bx = lane_prev(B, 0.0);
+                double Mc = fma(Ax, M_wave, Bx);
+#pragma unroll
+                for (int s = 0; s < kSPL; ++s) { Mc = fma(pm.e[s], Mc, inc[s]); M1[s] = Mc; }
+            }
+            const DiscPt<kSPL> d1 = disc_point(sh, w, M1);
+
+            // ---------------- omega: predictor
+            Vd<kSPL> wg;
+            {
+                const double g1 = om_s - cw1, g2 = g1 - (cw1 - cw2);
+                const double d2b = (cw1 - cw2) - (cw2 - cw3);
+                const double g3 = tile == 0 ? 0.0 : g2 - d2b;
+                const double g4 = tile == 0 ? 0.0 : g3 - (d2b - ((cw2 - cw3) - (cw3 - cw4)));
+#pragma unroll
+                for (int s = 0; s < kSPL; ++s) {
+                    const double k = (double)(e0 + s + 1);
+                    const double c2 = 0.5 * k * (k + 1.0);
+                    const double c3 = c2 * (k + 2.0) * (1.0 / 3.0);
+                    wg[s] = fma(k, g1, fma(c2, g2, fma(c3, g3, fma(c3 * (k + 3.0) * 0.25, g4, om_s))));
+                }
+            }
+            // ---------------- Newton sweeps.  Each pass starts with the right-hand side at the current values and ONE
+            // barrier that publishes (omega_dot, omega) for the neighbours together with every wavefront's verdict on the
+            // previous pass; when nobody is pending those values are final (and omega_dot is exact at them).  A full pass
+            // adds a second barrier for the scan totals.
+            Vd<kSPL> f1;
+            bool flagged = false, pending = true, not_ok = false, settled = false;
+            int sweep = 0;
+            double w_guard = om_s;
+            while (true) {
+                {
+                    bool wild = false;
+#pragma unroll
+                    for (int s = 0; s < kSPL; ++s) wild = wild || !(wg[s] > 0.0);
+                    if (__any(wild)) {
+#pragma unroll
+                        for (int s = 0; s < kSPL; ++s)
+                            if (!(wg[s] > 0.0)) wg[s] = w_guard > 0.0 ? w_guard : om_s;
+                    }
+                }
+                Vd<kSPL> rot, lam;
+                f1 = omega_rhs<true>(sh, w, d1, wg, rot, lam);
+                bool flg = false;
+#pragma unroll
+                for (int s = 0; s < kSPL; ++s) {
+                    lds.f[e0 + s + 3] = f1[s];
+                    lds.w[e0 + s + 3] = wg[s];
+                    flg = flg || (i0 + s < nsteps && rot[s] > 0.27);
+                }
+                if (gl == 0) {
+                    double h1 = cf1, h2 = cf2, u1 = cw1, u2 = cw2;
+                    if (tile == 0) {   // start-up ghosts: linear continuation of points 0 and 1 in the index
+                        h1 = 2.0 * cf0 - f1[0]; u1 = 2.0 * om_s - wg[0];
+                        h2 = 3.0 * cf0 - 2.0 * f1[0]; u2 = 3.0 * om_s - 2.0 * wg[0];
+                    }
+                    lds.f[2] = cf0; lds.f[1] = h1; lds.f[0] = h2;
+                    lds.w[2] = om_s; lds.w[1] = u1; lds.w[0] = u2;
+                }
+                {
+                    const int word = (__any(not_ok) ? 1 : 0) | (__any(settled && flg) ? 2 : 0);
+                    if (lane == 0) lds.flags[fp][wave] = word;
+                }
+                __syncthreads();
+                {
+                    int all = 0;
+#pragma unroll
+                    for (int v = 0; v < W; ++v) all |= lds.flags[fp][v];
+                    fp ^= 1;
+                    pending = sweep == 0 || (all & 1);
+                    flagged = flagged || (all & 2);
+                }
+                if (!pending || flagged || sweep >= kMaxSweeps) break;
+                ++sweep;
+                double Ef[kSPL + 3], Ew[kSPL + 3];
+#pragma unroll
+                for (int s = 0; s < kSPL; ++s) { Ef[3 + s] = f1[s]; Ew[3 + s] = wg[s]; }
+                Ef[2] = lds.f[e0 + 2]; Ef[1] = lds.f[e0 + 1]; Ef[0] = lds.f[e0];
+                Ew[2] = lds.w[e0 + 2]; Ew[1] = lds.w[e0 + 1]; Ew[0] = lds.w[e0];
+                w_guard = Ew[2];
+                Vd<kSPL> zw, n0, n1, n2, n3;
+#pragma unroll
+                for (int s = 0; s < kSPL; ++s) {
+                    zw[s] = h[s] * lam[s];
+                    n0[s] = fma(-lam[s], Ew[3 + s], Ef[3 + s]);
+                    n1[s] = fma(-lam[s], Ew[2 + s], Ef[2 + s]);
+                    n2[s] = fma(-lam[s], Ew[1 + s], Ef[1 + s]);
+                    n3[s] = fma(-lam[s], Ew[s], Ef[s]);
+                }
+                const Phi<kSPL> pw_ = phi1234(zw);
+                const Vd<kSPL> inc = eam4_increment(sh, pw_, h, n0, n1, n2, n3);
+                double A = 1.0, B = 0.0;
+#pragma unroll
+                for (int s = 0; s < kSPL; ++s) { B = fma(pw_.e[s], B, inc[s]); A = A * pw_.e[s]; }
+                double om_wave;
+                scan_affine_block<W>(A, B, lds.tot[tp], wave, lane, om_s, om_wave);   // barrier: also orders the LDS image reads
+                tp ^= 1;                                                              // before the next pass overwrites it
+                const double Ax = lane_prev(A, 1.0), Bx = lane_prev(B, 0.0);
+                double wc = fma(Ax, om_wave, Bx);
+                bool all_ok = true, all_settled = true;
+#pragma unroll
+                for (int s = 0; s < kSPL; ++s) {
+                    wc = fma(pw_.e[s], wc, inc[s]);
+                    const double dw = fabs(wc - wg[s]), mag = fabs(wc);
+                    all_settled = all_settled && (dw <= 1.0e-3 * mag);
+                    all_ok = all_ok && dw <= sh.sweep_tol * mag;
+                    wg[s] = wc;
+                }
+                settled = all_settled;
+                not_ok = !all_ok;
+            }
+            sweeps_total += sweep;
+
+            // ---------------- luminosity; then ONE barrier publishes the light-curve tile, the carries for the next tile
+            // and every wavefront's failure verdict
+            Vd<kSPL> Lt, Lp, Ld;
+            luminosity(sh, w, d1, wg, Lt, Lp, Ld);
+            {
+                bool bad = false, over = false;
+#pragma unroll
+                for (int s = 0; s < kSPL; ++s) {
+                    const bool act = i0 + s < nsteps;
+                    bad = bad || (act && (!(isfinite(M1[s]) && isfinite(wg[s])) || M1[s] <= 0.0 || wg[s] <= 0.0));
+                    over = over || (act && sh.crot * wg[s] * wg[s] > 0.27);
+                }
+                const unsigned long long mb = __ballot(bad), mo = __ballot(over);
+                if (lane == 0) {
+                    lds.fail[tq][2 * wave] = mb ? wave * 64 + __ffsll(mb) - 1 : 0x7fffffff;
+                    lds.fail[tq][2 * wave + 1] = mo ? wave * 64 + __ffsll(mo) - 1 : 0x7fffffff;
+                }
+#pragma unroll
+                for (int s = 0; s < kSPL; ++s) {
+                    lds.L[tq][e0 + s + 1] = Lt[s];
+                    const int back = kTile - 1 - (e0 + s);          // 0 = last step end of the tile
+                    if (back < 3) { lds.carry[tq][back] = ES[3 + s]; lds.carry[tq][3 + back] = f1[s]; }
+                    if (back < 5) lds.carry[tq][6 + back] = wg[s];
+                    if (back == 0) { lds.carry[tq][11] = M1[s]; lds.carry[tq][12] = Lt[s]; }
+                }
+                if (gl == 0) lds.L[tq][0] = L_s;
+                __syncthreads();
+                int first_bad = 0x7fffffff, first_flag = 0x7fffffff;
+#pragma unroll
+                for (int v = 0; v < W; ++v) { first_bad = min(first_bad, lds.fail[tq][2 * v]); first_flag = min(first_flag, lds.fail[tq][2 * v + 1]); }
+                // a tile whose sweeps flagged an iterate or never settled: the reference's 'flag' (walker_eval)
+                if (flagged || pending) first_flag = 0;
+                if (first_bad != 0x7fffffff || first_flag != 0x7fffffff) {
+                    status = first_flag <= first_bad ? MP_STATUS_FLAG : MP_STATUS_NONFINITE;
+                    break;
+                }
+                const bool mine = ob_tile == tile;
+                int j0 = 0, j1 = 0;
+                if (long_lc) { j0 = max(tptr[tile * kSPL * W], kRes); j1 = tptr[min((tile + 1) * kSPL * W, sh.n_tiles)]; }
+                if (mine) {
+                    const int g = ob_g - tile * kTile;
+                    const double La = lds.L[tq][g], Lb = lds.L[tq][g + 1];
+                    const double mod = fma((Lb - La) * ob_idt, ob_dx, La) / 1.0e50;
+                    const double res = (ob_y - mod) / ob_ye;
+                    chi = fma(res, res, chi);
+                }
+                for (int j = j0 + gl; j < j1; j += kRes) {
+                    const int jj = dsd.obs_off + j;
+                    const int g = sh.obs_g[jj] - tile * kTile;
+                    const double La = lds.L[tq][g], Lb = lds.L[tq][g + 1];
+                    const double mod = fma((Lb - La) * sh.obs_idt[jj], sh.obs_dx[jj], La) / 1.0e50;
+                    const double res = (sh.obs_y[jj] - mod) / sh.obs_yerr[jj];
+                    chi = fma(res, res, chi);
+                }
+                cS0 = lds.carry[tq][0]; cS1 = lds.carry[tq][1]; cS2 = lds.carry[tq][2];
+                cf0 = lds.carry[tq][3]; cf1 = lds.carry[tq][4]; cf2 = lds.carry[tq][5];
+                om_s = lds.carry[tq][6]; cw1 = lds.carry[tq][7]; cw2 = lds.carry[tq][8]; cw3 = lds.carry[tq][9]; cw4 = lds.carry[tq][10];
+                M_s = lds.carry[tq][11]; L_s = lds.carry[tq][12];
+            }
+        }
+    }
+
+    double lnp = -INFINITY;
+    if (status == MP_STATUS_OK) {
+        const double part = wave_sum(chi);
+        __syncthreads();
+        if (lane == 0) lds.tot[0][wave] = part;
+        __syncthreads();
+        double tot = 0.0;
+#pragma unroll
+        for (int v = 0; v < W; ++v) tot += lds.tot[0][v];
+        lnp = -0.5 * tot;
+        if (!isfinite(lnp)) { lnp = -INFINITY; status = MP_STATUS_NONFINITE; }
+    }
+    lnp_out = lnp;
+    status_out = status;
+    sweeps_out = sweeps_total;
+}
+
+}  // namespace mp

@@ -1,0 +1,271 @@
+// mp_math.hpp — device-side building blocks of the gfx950 kernels: DPP wavefront primitives (affine-map scan,
+// neighbour fetch, broadcast), the per-lane N-vector type, hand-rolled fp64 elementary functions and the
+// exponential-integrator phi functions.  Included by mp_kernels.hip only.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+
+#include "mp_device.h"
+
+namespace mp {
+
+#define MP_DEV __device__ __forceinline__
+
+// ---------------------------------------------------------------- wavefront helpers (DPP, no LDS)
+// DPP controls (GFX9 encoding): row_shr:n = 0x110+n, wave_shr:1 = 0x138, row_bcast:15 = 0x142, row_bcast:31 = 0x143.
+template <int CTRL, int ROW_MASK>
+MP_DEV double dpp_move(double keep, double src) {
+    // lanes with a valid DPP source (and enabled by ROW_MASK) receive src from that lane, all others `keep`
+    const int klo = __double2loint(keep), khi = __double2hiint(keep);
+    const int slo = __double2loint(src), shi = __double2hiint(src);
+    const int lo = __builtin_amdgcn_update_dpp(klo, slo, CTRL, ROW_MASK, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(khi, shi, CTRL, ROW_MASK, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+
+// value of lane-1 (lane 0 receives `first`)
+MP_DEV double lane_prev(double v, double first) { return dpp_move<0x138, 0xF>(first, v); }
+
+// broadcast lane `src` (wave-uniform index) to all lanes
+MP_DEV double lane_bcast(double v, int src) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+
+// Inclusive scan of affine maps x -> a*x + b over the 64 lanes: afterwards lane l holds
+// m_l o m_{l-1} o ... o m_0.  Lanes without a DPP source combine with the identity (1, 0).
+template <int CTRL, int ROW_MASK>
+MP_DEV void scan_step(double &a, double &b) {
+    const double pa = dpp_move<CTRL, ROW_MASK>(1.0, a);
+    const double pb = dpp_move<CTRL, ROW_MASK>(0.0, b);
+    b = fma(a, pb, b);
+    a = a * pa;
+}
+
+MP_DEV void scan_affine(double &a, double &b) {
+    scan_step<0x111, 0xF>(a, b);  // row_shr:1
+    scan_step<0x112, 0xF>(a, b);  // row_shr:2
+    scan_step<0x114, 0xF>(a, b);  // row_shr:4
+    scan_step<0x118, 0xF>(a, b);  // row_shr:8   -> every 16-lane row scanned
+    scan_step<0x142, 0xA>(a, b);  // row_bcast:15 into rows 1 and 3
+    scan_step<0x143, 0xC>(a, b);  // row_bcast:31 into rows 2 and 3
+}
+
+MP_DEV double wave_sum(double v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------- N independent values per lane
+// Every lane owns N consecutive time steps.  All per-step mathematics below is written on N-vectors, one
+// statement at a time across the N steps, so that the N dependent chains (Horner polynomials, Newton
+// refinements) sit next to each other in the instruction stream and hide each other's latency: with one
+// wave per SIMD there is no other wave to do it.
+template <int N>
+struct Vd {
+    double v[N];
+    MP_DEV double &operator[](int i) { return v[i]; }
+    MP_DEV const double &operator[](int i) const { return v[i]; }
+};
+template <int N>
+struct Vb {
+    bool v[N];
+    MP_DEV bool &operator[](int i) { return v[i]; }
+    MP_DEV const bool &operator[](int i) const { return v[i]; }
+};
+#define FORN _Pragma("unroll") for (int i = 0; i < N; ++i)
+
+// ---------------------------------------------------------------- fp64 elementary functions
+// Three-address FMA for Horner chains.  hipcc selects the two-address v_fmac_f64 there and then has to
+// copy every polynomial coefficient into the accumulator first (one v_mov_b64 per term); the explicit
+// v_fma_f64 reads the coefficient in place.  Only plain VALU results feed it (no transcendental-op hazard).
+MP_DEV double fma3(double a, double b, double c) {
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
+// p <- p*x + c on all N chains
+template <int N>
+MP_DEV void horner(Vd<N> &p, const Vd<N> &x, double c) {
+    FORN p[i] = fma3(p[i], x[i], c);
+}
+
+// Hand-rolled for this kernel's argument ranges (positive, normal, far from overflow): hardware
+// seed (v_rcp_f64 / v_rsq_f64, ~2^-23) + two Newton steps, without the scaling / fix-up code the
+// general-purpose library versions carry.  All are accurate to ~1-2 ulp.
+template <int N>
+MP_DEV Vd<N> rcp_fast(const Vd<N> &x) {
+    Vd<N> r, e;
+    FORN r[i] = __builtin_amdgcn_rcp(x[i]);
+    FORN e[i] = fma(-x[i], r[i], 1.0);
+    FORN r[i] = fma(e[i], r[i], r[i]);
+    FORN e[i] = fma(-x[i], r[i], 1.0);
+    FORN r[i] = fma(e[i], r[i], r[i]);
+    return r;
+}
+
+template <int N>
+MP_DEV Vd<N> rsqrt_fast(const Vd<N> &x) {
+    Vd<N> y, hx, t;
+    FORN y[i] = __builtin_amdgcn_rsq(x[i]);
+    FORN hx[i] = 0.5 * x[i];
+    FORN t[i] = hx[i] * y[i];
+    FORN t[i] = fma(-t[i], y[i], 0.5);
+    FORN y[i] = fma(y[i], t[i], y[i]);
+    FORN t[i] = hx[i] * y[i];
+    FORN t[i] = fma(-t[i], y[i], 0.5);
+    FORN y[i] = fma(y[i], t[i], y[i]);
+    return y;
+}
+
+// e^x for x in [-750, 700]; underflows cleanly to 0 below
+template <int N>
+MP_DEV Vd<N> exp_fast(const Vd<N> &x) {
+    Vd<N> k, r, p;
+    FORN k[i] = __builtin_rint(x[i] * 1.4426950408889634074);
+    FORN r[i] = fma(k[i], -6.93147180369123816490e-01, x[i]);
+    FORN r[i] = fma(k[i], -1.90821492927058770002e-10, r[i]);
+    FORN p[i] = 1.0 / 479001600.0;               // Taylor degree 12 on |r| <= ln2/2: 1.7e-16
+    horner(p, r, 1.0 / 39916800.0);
+    horner(p, r, 1.0 / 3628800.0);
+    horner(p, r, 1.0 / 362880.0);
+    horner(p, r, 1.0 / 40320.0);
+    horner(p, r, 1.0 / 5040.0);
+    horner(p, r, 1.0 / 720.0);
+    horner(p, r, 1.0 / 120.0);
+    horner(p, r, 1.0 / 24.0);
+    horner(p, r, 1.0 / 6.0);
+    horner(p, r, 0.5);
+    horner(p, r, 1.0);
+    horner(p, r, 1.0);
+    FORN p[i] = ldexp(p[i], (int)k[i]);
+    return p;
+}
+
+// x^(-1/3) for positive normal x within float range: v_log_f32/v_exp_f32 seed (~1e-6) + two Newton steps
+// y <- y (4 - x y^3)/3 (error -> 2 e^2): ~1 ulp.
+template <int N>
+MP_DEV Vd<N> rcbrt_fast(const Vd<N> &x) {
+    Vd<N> y, x3, y3;
+    FORN y[i] = (double)__builtin_amdgcn_exp2f(-0.33333333f * __builtin_amdgcn_logf((float)x[i]));
+    FORN x3[i] = x[i] * (1.0 / 3.0);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        FORN y3[i] = y[i] * y[i];
+        FORN y3[i] = y3[i] * y[i];
+        FORN y3[i] = fma(-x3[i], y3[i], 4.0 / 3.0);
+        FORN y[i] = y[i] * y3[i];
+    }
+    return y;
+}
+
+// x^(-2/7) for positive normal x within float range: y = (x^2)^(-1/7), Newton y <- y (8 - x^2 y^7)/7 (error -> 4 e^2)
+template <int N>
+MP_DEV Vd<N> pow_m2_7_fast(const Vd<N> &x) {
+    Vd<N> y, z7, y2, y4, y7;
+    FORN y[i] = (double)__builtin_amdgcn_exp2f(-0.28571429f * __builtin_amdgcn_logf((float)x[i]));
+    FORN z7[i] = (x[i] * x[i]) * (1.0 / 7.0);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        FORN y2[i] = y[i] * y[i];
+        FORN y4[i] = y2[i] * y2[i];
+        FORN y7[i] = y4[i] * y2[i];
+        FORN y7[i] = y7[i] * y[i];
+        FORN y7[i] = fma(-z7[i], y7[i], 8.0 / 7.0);
+        FORN y[i] = y[i] * y7[i];
+    }
+    return y;
+}
+
+// ---------------------------------------------------------------- phi functions
+// phi_j(z) = sum_k z^k/(k+j)!  : phi_1 = (e^z-1)/z, phi_{j+1} = (phi_j - 1/j!)/z
+template <int N>
+struct Phi {
+    Vd<N> e, p1, p2, p3, p4;
+};
+
+template <int N>
+MP_DEV Phi<N> phi1234(const Vd<N> &z) {
+    // Taylor series of phi_4: 7 terms when every |z| of the wavefront is below 1/32 (< 2e-17 relative), 13 terms
+    // for |z| < 1/2, closed forms elsewhere
+    Vd<N> s;
+    bool all_tiny = true;
+    FORN all_tiny = all_tiny && fabs(z[i]) < 0.03125;
+    if (__all(all_tiny)) {
+        FORN s[i] = 1.0 / 3628800.0;              // 1/10!
+        horner(s, z, 1.0 / 362880.0);             // 1/9!
+        horner(s, z, 1.0 / 40320.0);              // 1/8!
+        horner(s, z, 1.0 / 5040.0);               // 1/7!
+        horner(s, z, 1.0 / 720.0);                // 1/6!
+        horner(s, z, 1.0 / 120.0);                // 1/5!
+        horner(s, z, 1.0 / 24.0);                 // 1/4!
+    } else {
+        FORN s[i] = 1.0 / 20922789888000.0;       // 1/16!
+        horner(s, z, 1.0 / 1307674368000.0);      // 1/15!
+        horner(s, z, 1.0 / 87178291200.0);        // 1/14!
+        horner(s, z, 1.0 / 6227020800.0);         // 1/13!
+        horner(s, z, 1.0 / 479001600.0);          // 1/12!
+        horner(s, z, 1.0 / 39916800.0);           // 1/11!
+        horner(s, z, 1.0 / 3628800.0);            // 1/10!
+        horner(s, z, 1.0 / 362880.0);             // 1/9!
+        horner(s, z, 1.0 / 40320.0);              // 1/8!
+        horner(s, z, 1.0 / 5040.0);               // 1/7!
+        horner(s, z, 1.0 / 720.0);                // 1/6!
+        horner(s, z, 1.0 / 120.0);                // 1/5!
+        horner(s, z, 1.0 / 24.0);                 // 1/4!
+    }
+    Phi<N> r;
+    r.p4 = s;
+    FORN r.p3[i] = fma(z[i], s[i], 1.0 / 6.0);
+    FORN r.p2[i] = fma(z[i], r.p3[i], 0.5);
+    FORN r.p1[i] = fma(z[i], r.p2[i], 1.0);
+    FORN r.e[i] = fma(z[i], r.p1[i], 1.0);
+    Vb<N> big;
+    bool any_big = false;
+    FORN { big[i] = !(fabs(z[i]) < 0.5); any_big = any_big || big[i]; }
+    if (__any(any_big)) {                          // wave-uniform: only stiff / late-time tiles pay for this
+        Vd<N> zc, zs;
+        FORN zc[i] = fmax(z[i], -750.0);
+        FORN zs[i] = big[i] ? z[i] : 1.0;
+        const Vd<N> ce = exp_fast(zc);
+        const Vd<N> rz = rcp_fast(zs);
+        FORN {
+            const double c1 = (ce[i] - 1.0) * rz[i];
+            const double c2 = (c1 - 1.0) * rz[i];
+            const double c3 = (c2 - 0.5) * rz[i];
+            const double c4 = (c3 - 1.0 / 6.0) * rz[i];
+            r.e[i] = big[i] ? ce[i] : r.e[i];
+            r.p1[i] = big[i] ? c1 : r.p1[i];
+            r.p2[i] = big[i] ? c2 : r.p2[i];
+            r.p3[i] = big[i] ? c3 : r.p3[i];
+            r.p4[i] = big[i] ? c4 : r.p4[i];
+        }
+    }
+    return r;
+}
+
+// h * int_0^1 e^{z(1-theta)} P(theta) dtheta for the cubic P through the node values v0..v3 at
+// t_{j+1}, t_j, t_{j-1}, t_{j-2} (quadrature matrix W of the geometric grid, DevShared::eamW)
+template <int N>
+MP_DEV Vd<N> eam4_increment(const DevShared &sh, const Phi<N> &p, const Vd<N> &h, const Vd<N> &v0, const Vd<N> &v1,
+                            const Vd<N> &v2, const Vd<N> &v3) {
+    Vd<N> acc, g;
+    FORN acc[i] = 0.0;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const Vd<N> &ph = m == 0 ? p.p1 : m == 1 ? p.p2 : m == 2 ? p.p3 : p.p4;
+        FORN g[i] = sh.eamW[3][m] * v3[i];
+        FORN g[i] = fma(sh.eamW[2][m], v2[i], g[i]);
+        FORN g[i] = fma(sh.eamW[1][m], v1[i], g[i]);
+        FORN g[i] = fma(sh.eamW[0][m], v0[i], g[i]);
+        FORN acc[i] = fma(ph[i], g[i], acc[i]);
+    }
+    FORN acc[i] = h[i] * acc[i];
+    return acc;
+}
+
+}  // namespace mp

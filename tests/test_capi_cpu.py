@@ -70,7 +70,7 @@ def test_product_never_imports_oracle():
     pkg = os.path.join(ROOT, "magprop_amd")
     for dirpath, _, files in os.walk(pkg):
         for f in files:
-            if f.endswith((".py", ".cpp", ".hip", ".h")):
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src and "libmp_oracle" not in src, f
                 assert "scipy.integrate" not in src and "odeint(" not in src, f
