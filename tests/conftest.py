@@ -50,6 +50,11 @@ def gflag():
 
 
 @pytest.fixture(scope="session")
+def glibscan():
+    return np.load(os.path.join(GOLDEN, "golden_libscan.npz"))
+
+
+@pytest.fixture(scope="session")
 def gcorners():
     return np.load(os.path.join(GOLDEN, "golden_corners.npz"))
 

@@ -19,7 +19,7 @@ What is called (paths relative to /root/reference):
                   tests/test_data/model_light_curve.csv — decimated (every 20th row) copies.
 `*_tight` arrays: the same reference code with its odeint call given rtol=atol=1e-12 (integrator noise
 removed; see tight_lsoda).
-Outputs: golden_synth.npz, golden_lib.npz, golden_flagscan.npz, golden_corners.npz, MANIFEST.json.
+Outputs: golden_synth.npz, golden_lib.npz, golden_flagscan.npz, golden_corners.npz, golden_libscan.npz, MANIFEST.json.
 """
 import argparse
 import contextlib
@@ -209,6 +209,30 @@ def make_corners():
     print("corners: flags", int((st == 1).sum()), "rode break-up but survived", int(((st == 0) & (rot >= 0.27)).sum()))
 
 
+def make_libscan(n=300):
+    """Library variant over its own prior box (magnetar/mcmc_limits.csv rows 1-6, log rows un-logged): model_lc + the
+    chi-square line of magnetar/mcmc_eqns.py:37 on the golden "L" dataset; 'flag' where model_lc returns it."""
+    os.chdir(REF)
+    import pandas as pd
+    lims = pd.read_csv(os.path.join(REF, "magnetar/mcmc_limits.csv"), index_col="pars")
+    lo, hi = lims["lower"].values[:6], lims["upper"].values[:6]
+    gl = np.load(os.path.join(HERE, "golden_lib.npz"))
+    x, y, yerr = gl["ds_L"]
+    rng = np.random.default_rng(SEED0 + 303)
+    P = lo + (hi - lo) * rng.random((n, 6))
+    phys = P.copy(); phys[:, 2:] = 10.0 ** phys[:, 2:]
+    lnl = np.empty(n); st = np.empty(n, dtype=np.int32)
+    for i, p in enumerate(phys):
+        mod = quiet(lib.model_lc, p, xdata=x, GRBtype="L")
+        if isinstance(mod, str):
+            lnl[i], st[i] = -np.inf, 1
+        else:
+            v = -0.5 * np.sum(((y - mod) / yerr) ** 2.0)
+            lnl[i], st[i] = (v, 0) if np.isfinite(v) else (-np.inf, 2)
+    np.savez_compressed(os.path.join(HERE, "golden_libscan.npz"), pars_sampler=P, pars_physical=phys, lnlike=lnl, status=st)
+    print("libscan: flags", int((st == 1).sum()), "of", n)
+
+
 def make_lib():
     os.chdir(REF)  # magnetar/mcmc_eqns.py:55 reads a cwd-relative CSV
     import pandas as pd
@@ -291,7 +315,7 @@ def make_lib():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--flag-scan", type=int, default=1500)
-    ap.add_argument("--only", choices=["all", "lib", "corners"], default="all", help="regenerate only one file")
+    ap.add_argument("--only", choices=["all", "lib", "corners", "libscan"], default="all", help="regenerate only one file")
     a = ap.parse_args()
     import scipy, pandas
     if a.only == "all":
@@ -301,6 +325,8 @@ def main():
         make_corners()
     if a.only in ("all", "lib"):
         make_lib()
+    if a.only in ("all", "libscan"):
+        make_libscan()
     manifest = {
         "generator": "tests/golden/make_golden.py",
         "reference": "sgibson91/magprop mounted at /root/reference (magnetar v%s)" % lib.__version__

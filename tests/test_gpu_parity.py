@@ -204,6 +204,20 @@ def test_lib_lnlike_6_to_9_parameters(mpa, glib, kind):
         assert np.all(np.abs(out - glib[f"lnlike_{kind}"][sel]) <= REF_ATOL + REF_RTOL * np.abs(out))
 
 
+def test_lib_prior_wide_scan(mpa, glib, glibscan):
+    """300 points uniform in the library variant's prior box: lnprob (log-space sampler coordinates) and lnlike
+    (physical parameters) against the reference's model_lc + chi-square."""
+    import pandas as pd
+    x, y, yerr = glib["ds_L"]
+    data = pd.DataFrame({"t": x, "Lum50": y, "Lum50err": yerr})
+    ref = glibscan["lnlike"]
+    assert np.all(glibscan["status"] == 0)
+    out = mpa.lnlike(glibscan["pars_physical"], data, "L")
+    assert np.all(np.abs(out - ref) <= REF_ATOL + REF_RTOL * np.abs(ref))
+    out2 = mpa.lnprob(glibscan["pars_sampler"], data, "L")          # inside the prior: lnprior = 0
+    assert np.all(np.abs(out2 - ref) <= REF_ATOL + REF_RTOL * np.abs(ref))
+
+
 def test_lib_lnprob_intent(mpa, glib):
     """lnprob = box prior in log space + un-logged likelihood."""
     import pandas as pd

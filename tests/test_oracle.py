@@ -189,6 +189,16 @@ def test_lib_lnlike_6_to_9_parameters(glib, kind):
         assert abs(ll - ref) <= REF_ATOL + REF_RTOL * abs(ref), (p, ll, ref)
 
 
+def test_lib_prior_wide_scan(glib, glibscan, tarr):
+    """300 points uniform in the library variant's prior box (magnetar/mcmc_limits.csv), golden "L" dataset."""
+    x, y, yerr = glib["ds_L"]
+    ref, rst = glibscan["lnlike"], glibscan["status"]
+    for p, r, s0 in zip(glibscan["pars_physical"][::3], ref[::3], rst[::3]):
+        ll, st = co.lnlike(co.cfg_lib(), p, tarr, x, y, yerr)
+        assert st == s0
+        assert abs(ll - r) <= REF_ATOL + REF_RTOL * abs(r)
+
+
 # ---------------------------------------------------------------- scipy/LSODA port
 @pytest.mark.parametrize("name", TYPES)
 def test_lsoda_port_matches_reference(gsynth, tarr, name):
