@@ -198,7 +198,7 @@ constexpr int kMaxSweepsMargin = 16;  // sweeps allowed beyond the tile length (
 // Evaluate ONE walker on the calling wavefront (all 64 lanes enter with identical arguments).
 // SPL = consecutive steps owned by one lane; a tile is 64*SPL steps.  par[] holds the sampler coordinates
 // (prior checked and log-masked coordinates un-logged here unless a.physical); walker indexes ds_id and the
-// optional curve outputs; Lbuf is the wave's LDS tile [64*SPL + 1].
+// optional curve outputs; Lbuf is the wave's LDS staging area [2*(64*SPL + 1)].
 template <bool CURVES, int SPL>
 MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, double (&par)[MP_MAX_NDIM], double *Lbuf,
                         double &lnp_out, int &status_out, int &sweeps_out) {
@@ -259,6 +259,8 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
     }
     const int ob_tile = ob_g >= 0 ? ob_g / kTile : -1;
     const bool long_lc = a.want_chi2 && dsd.n_obs > 64;
+    const bool deferred = !CURVES && a.want_chi2 && !long_lc;   // see "luminosity and chi^2" below
+    double obM[2] = {1.0e30, 1.0e30}, obW[2] = {1.0e3, 1.0e3};  // (Mdisc, omega) at the observation's bracketing grid points
     double chi = 0.0;
     int sweeps_total = 0;
 
@@ -439,26 +441,43 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 }
             }
 
-            // ---------------- luminosity at the step ends, light curve through LDS, chi^2
-            // (tiles that hold no observation and are not written out skip the luminosity stage altogether)
+            // ---------------- luminosity and chi^2
             const bool mine = ob_tile == tile;
-            int j0 = 0, j1 = 0;
-            if (long_lc) { j0 = max(tptr[tile * kSPL], 64); j1 = tptr[min((tile + 1) * kSPL, sh.n_tiles)]; }   // 64-step buckets
-            const bool tile_has_obs = __any(mine) || j1 > j0;
-            Vd<kSPL> Lt, Lp, Ld;
-            if (CURVES || tile_has_obs) luminosity(sh, w, d1, wg, Lt, Lp, Ld);
+            if (deferred) {
+                // Light curves of at most 64 points (every synthetic set): the model is only needed at the two grid
+                // points bracketing each observation.  The lane holding an observation picks (Mdisc, omega) at those
+                // two points out of the tile's LDS image as the tile goes by; the luminosity stage runs ONCE, after the
+                // last tile, on those captured states (the 10 001-point light curve is never formed).
+                if (__any(mine)) {
+                    double *Mbuf = Lbuf, *Wbuf = Lbuf + kTile + 1;
 #pragma unroll
-            for (int s = 0; s < kSPL; ++s) {
-                if (CURVES && active[s]) {
-                    const size_t o = row + (size_t)(i0 + s) + 1;
-                    if (a.ltot) a.ltot[o] = Lt[s] / 1.0e50;
-                    if (a.lprop) a.lprop[o] = Lp[s] / 1.0e50;
-                    if (a.ldip) a.ldip[o] = Ld[s] / 1.0e50;
-                    if (a.mdisc) a.mdisc[o] = M1[s];
-                    if (a.omega) a.omega[o] = wg[s];
+                    for (int s = 0; s < kSPL; ++s) { Mbuf[lane * kSPL + s + 1] = M1[s]; Wbuf[lane * kSPL + s + 1] = wg[s]; }
+                    if (lane == 0) { Mbuf[0] = M_s; Wbuf[0] = om_s; }
+                    __syncthreads();
+                    if (mine) {
+                        const int g = ob_g - tile * kTile;
+                        obM[0] = Mbuf[g]; obM[1] = Mbuf[g + 1];
+                        obW[0] = Wbuf[g]; obW[1] = Wbuf[g + 1];
+                    }
+                    __syncthreads();
                 }
-            }
-            {
+            } else {
+                int j0 = 0, j1 = 0;
+                if (long_lc) { j0 = max(tptr[tile * kSPL], 64); j1 = tptr[min((tile + 1) * kSPL, sh.n_tiles)]; }   // 64-step buckets
+                const bool tile_has_obs = __any(mine) || j1 > j0;
+                Vd<kSPL> Lt, Lp, Ld;
+                if (CURVES || tile_has_obs) luminosity(sh, w, d1, wg, Lt, Lp, Ld);
+#pragma unroll
+                for (int s = 0; s < kSPL; ++s) {
+                    if (CURVES && active[s]) {
+                        const size_t o = row + (size_t)(i0 + s) + 1;
+                        if (a.ltot) a.ltot[o] = Lt[s] / 1.0e50;
+                        if (a.lprop) a.lprop[o] = Lp[s] / 1.0e50;
+                        if (a.ldip) a.ldip[o] = Ld[s] / 1.0e50;
+                        if (a.mdisc) a.mdisc[o] = M1[s];
+                        if (a.omega) a.omega[o] = wg[s];
+                    }
+                }
                 if (tile_has_obs) {
 #pragma unroll
                     for (int s = 0; s < kSPL; ++s) Lbuf[lane * kSPL + s + 1] = Lt[s];
@@ -489,6 +508,8 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                     }
                     __syncthreads();
                 }
+                L_valid = CURVES || tile_has_obs;
+                if (L_valid) L_s = lane_bcast(Lt[kSPL - 1], 63);
             }
 
             // ---------------- carry the tile end (and the history behind it) to the next tile: only full tiles
@@ -506,8 +527,17 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 t_s = lane_bcast(tb[kSPL - 1], 63);
                 M_s = lane_bcast(M1[kSPL - 1], 63);
                 om_s = lane_bcast(wg[kSPL - 1], 63);
-                L_valid = CURVES || tile_has_obs;
-                if (L_valid) L_s = lane_bcast(Lt[kSPL - 1], 63);
+            }
+        }
+        if (deferred && status == MP_STATUS_OK) {   // the one luminosity evaluation of this walker
+            const Vd<2> Mv{{obM[0], obM[1]}}, Wv{{obW[0], obW[1]}};
+            const DiscPt<2> dp = disc_point(sh, w, Mv);
+            Vd<2> Lt, Lp, Ld;
+            luminosity(sh, w, dp, Wv, Lt, Lp, Ld);
+            if (ob_g >= 0) {
+                const double mod = fma((Lt[1] - Lt[0]) * ob_idt, ob_dx, Lt[0]) / 1.0e50;   // np.interp, then /1e50
+                const double res = (ob_y - mod) / ob_ye;
+                chi = res * res;
             }
         }
     }

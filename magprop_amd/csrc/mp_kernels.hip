@@ -38,7 +38,7 @@ namespace mp {
 // ---------------------------------------------------------------- batched log-posterior kernel
 template <bool CURVES, int SPL>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, SPL >= 4 ? 1 : 2))) void lnprob_kernel(const DevShared sh, const LaunchArgs a) {
-    __shared__ double Lbuf[64 * SPL + 1];
+    __shared__ double Lbuf[2 * (64 * SPL + 1)];
     const int walker = blockIdx.x;
     double par[MP_MAX_NDIM];
     const double *pw = a.pars + (size_t)walker * a.ndim;
@@ -112,7 +112,7 @@ MP_DEV double u01(uint32_t hi, uint32_t lo) {   // 53-bit uniform in [0, 1)
 // step's row of the chain.  Walkers of the complementary half are only read, so the update is race-free.
 template <int SPL, int W>
 __global__ __launch_bounds__(64 * W) void stretch_kernel(const DevShared sh, const StretchArgs g) {
-    __shared__ typename std::conditional<(W > 1), MwLds<SPL, W>, double[64 * SPL + 1]>::type lds;
+    __shared__ typename std::conditional<(W > 1), MwLds<SPL, W>, double[2 * (64 * SPL + 1)]>::type lds;
     const int w_ens = blockIdx.x / g.n_half;                       // which ensemble
     const int slot = blockIdx.x - w_ens * g.n_half;                // which walker of the active half
     const int32_t *perm = g.perm + (size_t)w_ens * g.n_walkers;    // this step's random split of the ensemble
