@@ -638,6 +638,8 @@ MP_DEV void walker_eval_mw(const DevShared &sh, const LaunchArgs &a, int walker,
     }
     const int ob_tile = ob_g >= 0 ? ob_g / kTile : -1;
     const bool long_lc = a.want_chi2 && dsd.n_obs > kRes;
+    const bool deferred = a.want_chi2 && !long_lc;              // see walker_eval: one luminosity evaluation per walker
+    double obM[2] = {1.0e30, 1.0e30}, obW[2] = {1.0e3, 1.0e3};
     double chi = 0.0;
     int sweeps_total = 0;
     int tp = 0;      // buffer parity of the scan totals
@@ -804,7 +806,7 @@ MP_DEV void walker_eval_mw(const DevShared &sh, const LaunchArgs &a, int walker,
             // ---------------- luminosity; then ONE barrier publishes the light-curve tile, the carries for the next tile
             // and every wavefront's failure verdict
             Vd<kSPL> Lt, Lp, Ld;
-            luminosity(sh, w, d1, wg, Lt, Lp, Ld);
+            if (!deferred) luminosity(sh, w, d1, wg, Lt, Lp, Ld);
             {
                 bool bad = false, over = false;
 #pragma unroll
@@ -820,13 +822,17 @@ MP_DEV void walker_eval_mw(const DevShared &sh, const LaunchArgs &a, int walker,
                 }
 #pragma unroll
                 for (int s = 0; s < kSPL; ++s) {
-                    lds.L[tq][e0 + s + 1] = Lt[s];
+                    if (deferred) { lds.L[0][e0 + s + 1] = M1[s]; lds.L[1][e0 + s + 1] = wg[s]; }   // (Mdisc, omega) image
+                    else lds.L[tq][e0 + s + 1] = Lt[s];
                     const int back = kTile - 1 - (e0 + s);          // 0 = last step end of the tile
                     if (back < 3) { lds.carry[tq][back] = ES[3 + s]; lds.carry[tq][3 + back] = f1[s]; }
                     if (back < 5) lds.carry[tq][6 + back] = wg[s];
                     if (back == 0) { lds.carry[tq][11] = M1[s]; lds.carry[tq][12] = Lt[s]; }
                 }
-                if (gl == 0) lds.L[tq][0] = L_s;
+                if (gl == 0) {
+                    if (deferred) { lds.L[0][0] = M_s; lds.L[1][0] = om_s; }
+                    else lds.L[tq][0] = L_s;
+                }
                 __syncthreads();
                 int first_bad = 0x7fffffff, first_flag = 0x7fffffff;
 #pragma unroll
@@ -840,7 +846,11 @@ MP_DEV void walker_eval_mw(const DevShared &sh, const LaunchArgs &a, int walker,
                 const bool mine = ob_tile == tile;
                 int j0 = 0, j1 = 0;
                 if (long_lc) { j0 = max(tptr[tile * kSPL * W], kRes); j1 = tptr[min((tile + 1) * kSPL * W, sh.n_tiles)]; }
-                if (mine) {
+                if (mine && deferred) {
+                    const int g = ob_g - tile * kTile;
+                    obM[0] = lds.L[0][g]; obM[1] = lds.L[0][g + 1];
+                    obW[0] = lds.L[1][g]; obW[1] = lds.L[1][g + 1];
+                } else if (mine) {
                     const int g = ob_g - tile * kTile;
                     const double La = lds.L[tq][g], Lb = lds.L[tq][g + 1];
                     const double mod = fma((Lb - La) * ob_idt, ob_dx, La) / 1.0e50;
@@ -863,6 +873,17 @@ MP_DEV void walker_eval_mw(const DevShared &sh, const LaunchArgs &a, int walker,
         }
     }
 
+    if (deferred && status == MP_STATUS_OK) {   // the one luminosity evaluation of this walker
+        const Vd<2> Mv{{obM[0], obM[1]}}, Wv{{obW[0], obW[1]}};
+        const DiscPt<2> dp = disc_point(sh, w, Mv);
+        Vd<2> Lt, Lp, Ld;
+        luminosity(sh, w, dp, Wv, Lt, Lp, Ld);
+        if (ob_g >= 0) {
+            const double mod = fma((Lt[1] - Lt[0]) * ob_idt, ob_dx, Lt[0]) / 1.0e50;
+            const double res = (ob_y - mod) / ob_ye;
+            chi = res * res;
+        }
+    }
     double lnp = -INFINITY;
     if (status == MP_STATUS_OK) {
         const double part = wave_sum(chi);
