@@ -12,6 +12,8 @@ struct Walker {
     double S_amp;     // M0/tfb
     double inv_tfb;   // 1/tfb
     double Crm;       // mu^(4/7) GM^(-1/7) f_Rm^(-2/7)
+    double sqrtCrm;   // sqrt(Crm)
+    double Crm15;     // Crm^1.5 / sqrt(GM)
     double DI;        // mu^2/(6 c^3 I)          dipole torque / I = -DI*omega^3
     double D;         // mu^2/(6 c^3)
     double armI;      // sqrt(GM)/I
@@ -35,11 +37,13 @@ template <int N>
 MP_DEV DiscPt<N> disc_point(const DevShared &sh, const Walker &w, const Vd<N> &Mdisc) {
     DiscPt<N> p;
     FORN p.mdot[i] = Mdisc[i] * w.inv_tau;
-    const Vd<N> pw_ = pow_m2_7_fast(p.mdot);
-    FORN p.rmu[i] = w.Crm * pw_[i];                                 // Crm * mdot^(-2/7)
-    const Vd<N> rs = rsqrt_fast(p.rmu);
-    FORN p.squ[i] = p.rmu[i] * rs[i];
-    FORN p.qu[i] = p.rmu[i] * p.squ[i] * sh.inv_sqrtGM;
+    const Vd<N> t = pow_m1_7_fast(p.mdot);                          // mdot^(-1/7)
+    FORN {
+        const double t2 = t[i] * t[i];
+        p.rmu[i] = w.Crm * t2;                                      // Crm * mdot^(-2/7)
+        p.squ[i] = w.sqrtCrm * t[i];                                // sqrt(rmu)
+        p.qu[i] = w.Crm15 * (t2 * t[i]);                            // rmu^1.5 / sqrt(GM)
+    }
     return p;
 }
 
@@ -174,6 +178,8 @@ MP_DEV int walker_setup(const DevShared &sh, const LaunchArgs &a, double (&par)[
         w.S_amp = M0 / tfb;
         w.inv_tfb = 1.0 / tfb;
         w.Crm = pow(mu, 4.0 / 7.0) * pow(sh.GM, -1.0 / 7.0) * pow(sh.cfg.rm_massflow_factor, -2.0 / 7.0);
+        w.sqrtCrm = sqrt(w.Crm);
+        w.Crm15 = w.Crm * w.sqrtCrm * sh.inv_sqrtGM;
         w.D = (mu * mu) / (6.0 * kC * kC * kC);
         w.DI = w.D * sh.inv_inertia;
         w.armI = sh.sqrtGM * sh.inv_inertia;
