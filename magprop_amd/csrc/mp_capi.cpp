@@ -93,6 +93,7 @@ struct mp_handle {
     // workspace of the host-buffer entry points
     DevBuf<double> w_pars, w_lnprob, w_curves;
     DevBuf<int32_t> w_dsid, w_status, w_sweeps;
+    DevBuf<double> w_scratch;   // DevShared::obs_scratch (only allocated once a light curve longer than 64 points is set)
     double last_mean_sweeps = 0.0;
 };
 
@@ -144,6 +145,22 @@ static int upload_datasets(mp_handle *h) {
     h->sh.obs_idt = h->d_obs_idt.p;
     h->sh.obs_y = h->d_obs_y.p;
     h->sh.obs_yerr = h->d_obs_yerr.p;
+    int extra = 0;
+    for (int d = 0; d < n_ds; ++d) extra = std::max(extra, desc[d].n_obs - 64);
+    h->sh.scratch_stride = (extra + 63) / 64 * 64;
+    return MP_OK;
+}
+
+// Rows of DevShared::obs_scratch for a launch over walker indices [0, n_walkers).  Growing the buffer waits for the
+// device first (kernels in flight still write the old one); launches that fit never synchronise.
+static int ensure_scratch(mp_handle *h, int n_walkers) {
+    const size_t need = (size_t)n_walkers * 4 * (size_t)h->sh.scratch_stride;
+    if (need > h->w_scratch.cap) {
+        HIP_TRY(hipDeviceSynchronize());
+        const int rc = h->w_scratch.ensure(need);
+        if (rc) return rc;
+    }
+    h->sh.obs_scratch = h->w_scratch.p;
     return MP_OK;
 }
 
@@ -278,7 +295,7 @@ int mp_destroy(mp_handle *h) {
     h->d_tgrid.release(); h->d_obs_dx.release(); h->d_obs_idt.release(); h->d_obs_y.release();
     h->d_obs_yerr.release(); h->d_obs_g.release(); h->d_tile_ptr.release(); h->d_ds.release();
     h->w_pars.release(); h->w_lnprob.release(); h->w_curves.release();
-    h->w_dsid.release(); h->w_status.release(); h->w_sweeps.release();
+    h->w_dsid.release(); h->w_status.release(); h->w_sweeps.release(); h->w_scratch.release();
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return MP_OK;
@@ -355,6 +372,7 @@ int mp_lnprob_batch_dev(mp_handle *h, const double *d_pars, const int32_t *d_ds_
     a.lnprob = d_lnprob;
     a.status = d_status;
     a.ltot = d_ltot;
+    if ((rc = ensure_scratch(h, n))) return rc;
     const int e = mp::launch_lnprob(h->sh, a, stream);
     if (e) return fail(MP_EHIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
     return MP_OK;
@@ -376,7 +394,7 @@ int mp_lnprob_batch(mp_handle *h, const double *pars, const int32_t *ds_id, int 
     const size_t ng = h->tgrid.size();
     if ((rc = h->w_pars.ensure((size_t)n * ndim)) || (rc = h->w_lnprob.ensure(n)) || (rc = h->w_status.ensure(n)) ||
         (rc = h->w_sweeps.ensure(n)) || (ds_id && (rc = h->w_dsid.ensure(n))) ||
-        (ltot_out && (rc = h->w_curves.ensure((size_t)n * ng))))
+        (ltot_out && (rc = h->w_curves.ensure((size_t)n * ng))) || (rc = ensure_scratch(h, n)))
         return rc;
     hipStream_t st = h->stream;
     HIP_TRY(hipMemcpyAsync(h->w_pars.p, pars, sizeof(double) * (size_t)n * ndim, hipMemcpyHostToDevice, st));
@@ -547,6 +565,8 @@ int mp_sampler_set_positions(mp_sampler *s, const double *pos) {
         mp::LaunchArgs a{};
         a.pars = s->d_pos.p; a.ds_id = s->d_dsid.p; a.n = s->n_total; a.ndim = s->ndim; a.want_chi2 = 1;
         a.lnprob = s->d_lnprob.p; a.status = s->d_status.p;
+        const int rc = ensure_scratch(h, s->n_total);
+        if (rc) return rc;
         const int e = mp::launch_lnprob(h->sh, a, h->stream);
         if (e) return fail(MP_EHIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
         HIP_TRY(hipStreamSynchronize(h->stream));
@@ -566,6 +586,7 @@ int mp_sampler_run(mp_sampler *s, int n_steps, double *chain, double *chain_lnpr
     const int chunk_max = chain ? std::max<int>(1, (int)std::min<size_t>((size_t)n_steps, (256u << 20) / (row * sizeof(double)))) : n_steps;
     std::vector<int32_t> perm;
     int rc;
+    if ((rc = ensure_scratch(h, s->n_total))) return rc;
     for (int done = 0; done < n_steps;) {
         const int chunk = std::min(chunk_max, n_steps - done);
         // random split of every ensemble for every step of the chunk (emcee's randomize_split)

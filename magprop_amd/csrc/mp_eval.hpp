@@ -252,7 +252,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
     const DsDesc dsd = sh.ds ? sh.ds[(dsid >= 0 && dsid < sh.n_ds) ? dsid : 0] : DsDesc{0, 0, 0, 0};
     const int32_t *tptr = sh.tile_ptr + dsd.tile_off;
     // The first 64 observations of the walker's light curve live in registers, one per lane (time-sorted;
-    // every synthetic set has 50).  Longer light curves take the tile-bucketed global-memory path for the rest.
+    // every synthetic set has 50).  Longer light curves park the states they need in the walker's scratch rows.
     int ob_g = -1;
     double ob_dx = 0.0, ob_idt = 0.0, ob_y = 0.0, ob_ye = 1.0;
     if (a.want_chi2 && lane < dsd.n_obs) {
@@ -265,7 +265,9 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
     }
     const int ob_tile = ob_g >= 0 ? ob_g / kTile : -1;
     const bool long_lc = a.want_chi2 && dsd.n_obs > 64;
-    const bool deferred = !CURVES && a.want_chi2 && !long_lc;   // see "luminosity and chi^2" below
+    const bool deferred = !CURVES && a.want_chi2;               // see "luminosity and chi^2" below
+    const size_t sc_stride = (size_t)sh.scratch_stride;
+    double *sc = sh.obs_scratch + (size_t)walker * 4 * sc_stride;   // [4][stride]: observations 64.. of this walker
     double obM[2] = {1.0e30, 1.0e30}, obW[2] = {1.0e3, 1.0e3};  // (Mdisc, omega) at the observation's bracketing grid points
     double chi = 0.0;
     int sweeps_total = 0;
@@ -450,11 +452,14 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
             // ---------------- luminosity and chi^2
             const bool mine = ob_tile == tile;
             if (deferred) {
-                // Light curves of at most 64 points (every synthetic set): the model is only needed at the two grid
-                // points bracketing each observation.  The lane holding an observation picks (Mdisc, omega) at those
-                // two points out of the tile's LDS image as the tile goes by; the luminosity stage runs ONCE, after the
-                // last tile, on those captured states (the 10 001-point light curve is never formed).
-                if (__any(mine)) {
+                // The model is only needed at the two grid points bracketing each observation.  The lane holding an
+                // observation picks (Mdisc, omega) at those two points out of the tile's LDS image as the tile goes by
+                // (observations beyond the 64 register-resident ones: into the walker's scratch rows); the luminosity
+                // stage runs after the last tile on those captured states, once per 64 observations (the 10 001-point
+                // light curve is never formed).
+                int j0 = 0, j1 = 0;
+                if (long_lc) { j0 = max(tptr[tile * kSPL], 64); j1 = tptr[min((tile + 1) * kSPL, sh.n_tiles)]; }   // 64-step buckets
+                if (__any(mine) || j1 > j0) {
                     double *Mbuf = Lbuf, *Wbuf = Lbuf + kTile + 1;
 #pragma unroll
                     for (int s = 0; s < kSPL; ++s) { Mbuf[lane * kSPL + s + 1] = M1[s]; Wbuf[lane * kSPL + s + 1] = wg[s]; }
@@ -465,9 +470,15 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                         obM[0] = Mbuf[g]; obM[1] = Mbuf[g + 1];
                         obW[0] = Wbuf[g]; obW[1] = Wbuf[g + 1];
                     }
+                    for (int j = j0 + lane; j < j1; j += 64) {
+                        const int g = sh.obs_g[dsd.obs_off + j] - tile * kTile;
+                        double *p = sc + (j - 64);
+                        p[0] = Mbuf[g]; p[sc_stride] = Mbuf[g + 1];
+                        p[2 * sc_stride] = Wbuf[g]; p[3 * sc_stride] = Wbuf[g + 1];
+                    }
                     __syncthreads();
                 }
-            } else {
+            } else {   // curve outputs requested: the whole light curve is formed anyway
                 int j0 = 0, j1 = 0;
                 if (long_lc) { j0 = max(tptr[tile * kSPL], 64); j1 = tptr[min((tile + 1) * kSPL, sh.n_tiles)]; }   // 64-step buckets
                 const bool tile_has_obs = __any(mine) || j1 > j0;
@@ -535,7 +546,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 om_s = lane_bcast(wg[kSPL - 1], 63);
             }
         }
-        if (deferred && status == MP_STATUS_OK) {   // the one luminosity evaluation of this walker
+        if (deferred && status == MP_STATUS_OK) {   // the luminosity evaluations of this walker: one per 64 observations
             const Vd<2> Mv{{obM[0], obM[1]}}, Wv{{obW[0], obW[1]}};
             const DiscPt<2> dp = disc_point(sh, w, Mv);
             Vd<2> Lt, Lp, Ld;
@@ -544,6 +555,22 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 const double mod = fma((Lt[1] - Lt[0]) * ob_idt, ob_dx, Lt[0]) / 1.0e50;   // np.interp, then /1e50
                 const double res = (ob_y - mod) / ob_ye;
                 chi = res * res;
+            }
+            if (long_lc) {
+                __syncthreads();   // scratch rows written by other lanes
+                for (int jb = 64; jb < dsd.n_obs; jb += 64) {
+                    const bool valid = jb + lane < dsd.n_obs;
+                    const int j = valid ? jb + lane : dsd.n_obs - 1;
+                    const double *p = sc + (j - 64);
+                    const Vd<2> Mx{{p[0], p[sc_stride]}}, Wx{{p[2 * sc_stride], p[3 * sc_stride]}};
+                    const DiscPt<2> dx = disc_point(sh, w, Mx);
+                    Vd<2> Lx, Lpx, Ldx;
+                    luminosity(sh, w, dx, Wx, Lx, Lpx, Ldx);
+                    const int jj = dsd.obs_off + j;
+                    const double mod = fma((Lx[1] - Lx[0]) * sh.obs_idt[jj], sh.obs_dx[jj], Lx[0]) / 1.0e50;
+                    const double res = (sh.obs_y[jj] - mod) / sh.obs_yerr[jj];
+                    if (valid) chi = fma(res, res, chi);
+                }
             }
         }
     }
@@ -577,7 +604,7 @@ struct MwLds {
     double w[kTile + 3];        // omega
     double tot[2][2 * W];       // per-wavefront scan totals (a, b); double-buffered by use
     int flags[2][W];            // per-wavefront (pending | flagged << 1); double-buffered by sweep
-    double L[2][kTile + 1];     // model light curve of the tile; double-buffered by tile
+    double L[2][kTile + 1];     // (Mdisc, omega) at the tile's grid points (start point first), for the observations
     double carry[2][16];        // tile-end state for the next tile; double-buffered by tile
     int fail[2][2 * W];         // per-wavefront first non-finite / first over-limit lane; double-buffered by tile
 };
@@ -617,19 +644,16 @@ MP_DEV void walker_eval_mw(const DevShared &sh, const LaunchArgs &a, int walker,
         cS0 = Sg[0]; cS1 = Sg[1]; cS2 = Sg[2];
     }
     double cf0, cf1, cf2, cw1 = om_s, cw2 = om_s, cw3 = om_s, cw4 = om_s;
-    double L_s;
     {
         const Vd<1> Mv{{M_s}}, ov{{om_s}};
         const DiscPt<1> d_s = disc_point(sh, w, Mv);
-        Vd<1> rot0, dummy, Lt0, Lp0, Ld0;
+        Vd<1> rot0, dummy;
         cf0 = omega_rhs<false>(sh, w, d_s, ov, rot0, dummy)[0];
         cf1 = cf2 = cf0;
         if (status == MP_STATUS_OK) {
             if (!(isfinite(M_s) && isfinite(om_s)) || M_s <= 0.0 || om_s <= 0.0) status = MP_STATUS_NONFINITE;
             else if (rot0[0] > 0.27) status = MP_STATUS_FLAG;
         }
-        luminosity(sh, w, d_s, ov, Lt0, Lp0, Ld0);
-        L_s = Lt0[0];
     }
 
     const int dsid = a.ds_id ? a.ds_id[walker] : 0;
@@ -644,7 +668,9 @@ MP_DEV void walker_eval_mw(const DevShared &sh, const LaunchArgs &a, int walker,
     }
     const int ob_tile = ob_g >= 0 ? ob_g / kTile : -1;
     const bool long_lc = a.want_chi2 && dsd.n_obs > kRes;
-    const bool deferred = a.want_chi2 && !long_lc;              // see walker_eval: one luminosity evaluation per walker
+    const bool deferred = a.want_chi2;                          // see walker_eval: the luminosity stage runs after the last tile
+    const size_t sc_stride = (size_t)sh.scratch_stride;
+    double *sc = sh.obs_scratch + (size_t)walker * 4 * sc_stride;   // [4][stride]: observation j >= kRes at column j - 64
     double obM[2] = {1.0e30, 1.0e30}, obW[2] = {1.0e3, 1.0e3};
     double chi = 0.0;
     int sweeps_total = 0;
@@ -809,10 +835,8 @@ MP_DEV void walker_eval_mw(const DevShared &sh, const LaunchArgs &a, int walker,
             }
             sweeps_total += sweep;
 
-            // ---------------- luminosity; then ONE barrier publishes the light-curve tile, the carries for the next tile
+            // ---------------- ONE barrier publishes the tile's (Mdisc, omega) image, the carries for the next tile
             // and every wavefront's failure verdict
-            Vd<kSPL> Lt, Lp, Ld;
-            if (!deferred) luminosity(sh, w, d1, wg, Lt, Lp, Ld);
             {
                 bool bad = false, over = false;
 #pragma unroll
@@ -829,16 +853,12 @@ MP_DEV void walker_eval_mw(const DevShared &sh, const LaunchArgs &a, int walker,
 #pragma unroll
                 for (int s = 0; s < kSPL; ++s) {
                     if (deferred) { lds.L[0][e0 + s + 1] = M1[s]; lds.L[1][e0 + s + 1] = wg[s]; }   // (Mdisc, omega) image
-                    else lds.L[tq][e0 + s + 1] = Lt[s];
                     const int back = kTile - 1 - (e0 + s);          // 0 = last step end of the tile
                     if (back < 3) { lds.carry[tq][back] = ES[3 + s]; lds.carry[tq][3 + back] = f1[s]; }
                     if (back < 5) lds.carry[tq][6 + back] = wg[s];
-                    if (back == 0) { lds.carry[tq][11] = M1[s]; lds.carry[tq][12] = Lt[s]; }
+                    if (back == 0) lds.carry[tq][11] = M1[s];
                 }
-                if (gl == 0) {
-                    if (deferred) { lds.L[0][0] = M_s; lds.L[1][0] = om_s; }
-                    else lds.L[tq][0] = L_s;
-                }
+                if (gl == 0 && deferred) { lds.L[0][0] = M_s; lds.L[1][0] = om_s; }
                 __syncthreads();
                 int first_bad = 0x7fffffff, first_flag = 0x7fffffff;
 #pragma unroll
@@ -852,34 +872,26 @@ MP_DEV void walker_eval_mw(const DevShared &sh, const LaunchArgs &a, int walker,
                 const bool mine = ob_tile == tile;
                 int j0 = 0, j1 = 0;
                 if (long_lc) { j0 = max(tptr[tile * kSPL * W], kRes); j1 = tptr[min((tile + 1) * kSPL * W, sh.n_tiles)]; }
-                if (mine && deferred) {
+                if (mine) {
                     const int g = ob_g - tile * kTile;
                     obM[0] = lds.L[0][g]; obM[1] = lds.L[0][g + 1];
                     obW[0] = lds.L[1][g]; obW[1] = lds.L[1][g + 1];
-                } else if (mine) {
-                    const int g = ob_g - tile * kTile;
-                    const double La = lds.L[tq][g], Lb = lds.L[tq][g + 1];
-                    const double mod = fma((Lb - La) * ob_idt, ob_dx, La) / 1.0e50;
-                    const double res = (ob_y - mod) / ob_ye;
-                    chi = fma(res, res, chi);
                 }
                 for (int j = j0 + gl; j < j1; j += kRes) {
-                    const int jj = dsd.obs_off + j;
-                    const int g = sh.obs_g[jj] - tile * kTile;
-                    const double La = lds.L[tq][g], Lb = lds.L[tq][g + 1];
-                    const double mod = fma((Lb - La) * sh.obs_idt[jj], sh.obs_dx[jj], La) / 1.0e50;
-                    const double res = (sh.obs_y[jj] - mod) / sh.obs_yerr[jj];
-                    chi = fma(res, res, chi);
+                    const int g = sh.obs_g[dsd.obs_off + j] - tile * kTile;
+                    double *p = sc + (j - 64);
+                    p[0] = lds.L[0][g]; p[sc_stride] = lds.L[0][g + 1];
+                    p[2 * sc_stride] = lds.L[1][g]; p[3 * sc_stride] = lds.L[1][g + 1];
                 }
                 cS0 = lds.carry[tq][0]; cS1 = lds.carry[tq][1]; cS2 = lds.carry[tq][2];
                 cf0 = lds.carry[tq][3]; cf1 = lds.carry[tq][4]; cf2 = lds.carry[tq][5];
                 om_s = lds.carry[tq][6]; cw1 = lds.carry[tq][7]; cw2 = lds.carry[tq][8]; cw3 = lds.carry[tq][9]; cw4 = lds.carry[tq][10];
-                M_s = lds.carry[tq][11]; L_s = lds.carry[tq][12];
+                M_s = lds.carry[tq][11];
             }
         }
     }
 
-    if (deferred && status == MP_STATUS_OK) {   // the one luminosity evaluation of this walker
+    if (deferred && status == MP_STATUS_OK) {   // the luminosity evaluations of this walker: one per 64*W observations
         const Vd<2> Mv{{obM[0], obM[1]}}, Wv{{obW[0], obW[1]}};
         const DiscPt<2> dp = disc_point(sh, w, Mv);
         Vd<2> Lt, Lp, Ld;
@@ -888,6 +900,22 @@ MP_DEV void walker_eval_mw(const DevShared &sh, const LaunchArgs &a, int walker,
             const double mod = fma((Lt[1] - Lt[0]) * ob_idt, ob_dx, Lt[0]) / 1.0e50;
             const double res = (ob_y - mod) / ob_ye;
             chi = res * res;
+        }
+        if (long_lc) {
+            __syncthreads();   // scratch rows written by other lanes
+            for (int jb = kRes; jb < dsd.n_obs; jb += kRes) {
+                const bool valid = jb + gl < dsd.n_obs;
+                const int j = valid ? jb + gl : dsd.n_obs - 1;
+                const double *p = sc + (j - 64);
+                const Vd<2> Mx{{p[0], p[sc_stride]}}, Wx{{p[2 * sc_stride], p[3 * sc_stride]}};
+                const DiscPt<2> dx = disc_point(sh, w, Mx);
+                Vd<2> Lx, Lpx, Ldx;
+                luminosity(sh, w, dx, Wx, Lx, Lpx, Ldx);
+                const int jj = dsd.obs_off + j;
+                const double mod = fma((Lx[1] - Lx[0]) * sh.obs_idt[jj], sh.obs_dx[jj], Lx[0]) / 1.0e50;
+                const double res = (sh.obs_y[jj] - mod) / sh.obs_yerr[jj];
+                if (valid) chi = fma(res, res, chi);
+            }
         }
     }
     double lnp = -INFINITY;

@@ -266,6 +266,47 @@ def test_mixed_datasets_and_lengths(mpa, co, gsynth, tarr):
         lp_(P, ds_id=np.full(nw, 40, np.int32))     # unset dataset
 
 
+@pytest.mark.parametrize("nw", [40, 700, 1700])
+def test_long_light_curves_every_kernel_variant(mpa, co, gsynth, tarr, nw):
+    """Real GRB light curves have up to 1 944 points (data/real_data/): observations beyond the register-resident
+    ones go through the per-walker scratch rows.  40 / 700 / 1 700 walkers select the 4-wavefront, 4-steps-per-lane
+    and 2-steps-per-lane kernels; a few walkers are checked against the C oracle, all against each other."""
+    from magprop_amd import LogProb
+    rng = np.random.default_rng(19)
+    base = mpa.model_lum(CANON["Classic"])
+    sets = []
+    for n in (65, 257, 700, 1944):
+        x = np.sort(10.0 ** rng.uniform(0.0, 6.0, n))
+        x[0], x[-1] = tarr[0], tarr[-1]
+        if n == 700:
+            x[100:400] = np.sort(rng.uniform(tarr[5000], tarr[5003], 300))   # 300 observations in three grid intervals
+            x = np.sort(x)
+        y0 = np.interp(x, tarr, base[1])
+        yerr = 0.2 * y0
+        sets.append((x, y0 + rng.normal(0, yerr), yerr))
+    lp_ = LogProb(*sets[0])
+    for s_ in sets[1:]:
+        lp_.add_dataset(*s_)
+    P = np.array(TRUTHS["Classic"]) + 0.02 * rng.standard_normal((nw, 6))
+    P[3] = gsynth["prior_upper"] + 1.0                         # one walker outside the prior
+    ids = (np.arange(nw) % len(sets)).astype(np.int32)
+    out = lp_(P, ds_id=ids)
+    assert out[3] == -np.inf and np.all(np.isfinite(np.delete(out, 3)))
+    for i in list(range(0, 12)) + [nw - 2, nw - 1]:
+        if i == 3:
+            continue
+        x, y, yerr = sets[ids[i]]
+        ref, _ = co.lnprob_batch(co.cfg_synth(), P[i], tarr, x, y, yerr, gsynth["prior_lower"],
+                                 gsynth["prior_upper"], LOG_MASK)
+        assert abs(out[i] - ref[0]) <= GPU_VS_C_RTOL * abs(ref[0]) * 10 + 1e-9, (i, ids[i], out[i], ref[0])
+    # the same walkers through another kernel variant (a batch of 8 -> 4 wavefronts per walker) agree to rounding
+    sub = np.r_[0:3, 4:9]
+    small = lp_(P[sub], ds_id=ids[sub])
+    assert np.allclose(small, out[sub], rtol=1e-10, atol=1e-9)
+    # repeatable bit for bit (the scratch rows carry nothing over from one launch to the next)
+    assert np.array_equal(lp_(P, ds_id=ids), out)
+
+
 def test_edge_cases(mpa, synth_handle, gsynth):
     from magprop_amd import _capi
     out = synth_handle.lnprob_batch(np.empty((0, 6)), ds_id=0)

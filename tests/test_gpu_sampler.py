@@ -111,6 +111,31 @@ def test_four_grb_ensembles_in_one_launch(gsynth):
     assert 0.1 < s.acceptance_fraction.mean() < 0.8
 
 
+def test_sampler_on_a_long_light_curve(gsynth):
+    """A 600-point light curve (longer than the register-resident 64 / 256 observations) through the fused move."""
+    from magprop_amd import EnsembleSampler, LogProb, model_lum
+    from magprop_amd import engine
+    rng = np.random.default_rng(8)
+    tarr = engine.grid(None)
+    truth = np.array(TRUTHS["Classic"])
+    phys = truth.copy()
+    phys[2:] = 10.0 ** phys[2:]
+    x = np.sort(10.0 ** rng.uniform(0.0, 6.0, 600))
+    y0 = model_lum(phys, xdata=x)
+    yerr = 0.2 * y0
+    y = y0 + rng.normal(0, yerr)
+    for nwalk in (32, 640):                                    # 4 wavefronts per walker / one wavefront per walker
+        pos = truth + 1.0e-4 * rng.standard_normal((nwalk, 6))
+        s = EnsembleSampler(nwalk, 6, x, y, yerr, seed=77)
+        s.run_mcmc(pos, 20)
+        chain, lnp = s.get_chain(), s.get_log_prob()
+        assert np.all(np.isfinite(lnp))
+        ref = LogProb(x, y, yerr)(chain[-1])
+        assert np.allclose(ref, lnp[-1], rtol=1e-10, atol=1e-9)
+        assert 0.05 < s.acceptance_fraction.mean() < 0.9
+    assert tarr[0] <= x[0] and x[-1] <= tarr[-1]
+
+
 def test_sampler_argument_validation(gsynth):
     from magprop_amd import EnsembleSampler
     x, y, yerr = gsynth["Humped_x"], gsynth["Humped_y"], gsynth["Humped_yerr"]
