@@ -49,6 +49,31 @@ def build(force=False, verbose=False):
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64 (same SONAME as the
+    system one, different file name), and two HIP/HSA runtimes in one process do not work: whichever
+    initialises second sees no GPU.  If torch is loaded first, the dynamic linker already resolves our
+    NEEDED libamdhip64.so.7 to torch's copy.  For the other order (magprop_amd first, torch later) torch's
+    copy is preloaded here, found without importing torch.  No torch, or MAGPROP_AMD_SYSTEM_HIP=1: the
+    runtime under /opt/rocm is used."""
+    import sys
+    if "torch" in sys.modules or os.environ.get("MAGPROP_AMD_SYSTEM_HIP") == "1":
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.origin:
+        return
+    bundled = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(bundled):
+        try:
+            C.CDLL(bundled, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass  # fall back to the system runtime (fine as long as torch is not used in this process)
+
+
 def lib():
     """Load libmagprop_amd.so (building it if hipcc is available and it is missing)."""
     global _lib
@@ -61,6 +86,7 @@ def lib():
             raise MagpropAmdError(
                 f"{LIB_PATH} is missing and could not be built ({exc}); run `python -c 'import "
                 "__graft_entry__ as g; g.build()'` on a machine with hipcc") from exc
+    _share_hip_runtime_with_torch()
     try:
         L = C.CDLL(LIB_PATH)
     except OSError as exc:

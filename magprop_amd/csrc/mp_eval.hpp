@@ -205,7 +205,7 @@ constexpr int kMaxSweepsMargin = 16;  // sweeps allowed beyond the tile length (
 // SPL = consecutive steps owned by one lane; a tile is 64*SPL steps.  par[] holds the sampler coordinates
 // (prior checked and log-masked coordinates un-logged here unless a.physical); walker indexes ds_id and the
 // optional curve outputs; Lbuf is the wave's LDS staging area [2*(64*SPL + 1)].
-template <bool CURVES, int SPL>
+template <bool CURVES, int SPL, bool LONG>
 MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, double (&par)[MP_MAX_NDIM], double *Lbuf,
                         double &lnp_out, int &status_out, int &sweeps_out) {
     constexpr int kSPL = SPL, kTile = 64 * SPL, kMaxSweeps = kTile + kMaxSweepsMargin;
@@ -264,7 +264,9 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
         ob_ye = sh.obs_yerr[jj];
     }
     const int ob_tile = ob_g >= 0 ? ob_g / kTile : -1;
-    const bool long_lc = a.want_chi2 && dsd.n_obs > 64;
+    // LONG: compiled with the scratch-row path for light curves of more than 64 points (the launcher picks this
+    // variant when the handle holds such a dataset; the short variant keeps that code out of the register budget)
+    const bool long_lc = (CURVES || LONG) && a.want_chi2 && dsd.n_obs > 64;
     const bool deferred = !CURVES && a.want_chi2;               // see "luminosity and chi^2" below
     const size_t sc_stride = (size_t)sh.scratch_stride;
     double *sc = sh.obs_scratch + (size_t)walker * 4 * sc_stride;   // [4][stride]: observations 64.. of this walker
@@ -451,7 +453,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
 
             // ---------------- luminosity and chi^2
             const bool mine = ob_tile == tile;
-            if (deferred) {
+            if constexpr (!CURVES) {
                 // The model is only needed at the two grid points bracketing each observation.  The lane holding an
                 // observation picks (Mdisc, omega) at those two points out of the tile's LDS image as the tile goes by
                 // (observations beyond the 64 register-resident ones: into the walker's scratch rows); the luminosity
@@ -459,7 +461,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 // light curve is never formed).
                 int j0 = 0, j1 = 0;
                 if (long_lc) { j0 = max(tptr[tile * kSPL], 64); j1 = tptr[min((tile + 1) * kSPL, sh.n_tiles)]; }   // 64-step buckets
-                if (__any(mine) || j1 > j0) {
+                if (deferred && (__any(mine) || j1 > j0)) {
                     double *Mbuf = Lbuf, *Wbuf = Lbuf + kTile + 1;
 #pragma unroll
                     for (int s = 0; s < kSPL; ++s) { Mbuf[lane * kSPL + s + 1] = M1[s]; Wbuf[lane * kSPL + s + 1] = wg[s]; }
@@ -623,7 +625,7 @@ MP_DEV void scan_affine_block(double &A, double &B, double (&tot)[2 * W], int wa
     x_wave = xw;
 }
 
-template <int SPL, int W>
+template <int SPL, int W, bool LONG>
 MP_DEV void walker_eval_mw(const DevShared &sh, const LaunchArgs &a, int walker, double (&par)[MP_MAX_NDIM], MwLds<SPL, W> &lds,
                            double &lnp_out, int &status_out, int &sweeps_out) {
     constexpr int kSPL = SPL, kTile = 64 * W * SPL, kMaxSweeps = kTile + kMaxSweepsMargin;
@@ -667,7 +669,7 @@ MP_DEV void walker_eval_mw(const DevShared &sh, const LaunchArgs &a, int walker,
         ob_g = sh.obs_g[jj]; ob_dx = sh.obs_dx[jj]; ob_idt = sh.obs_idt[jj]; ob_y = sh.obs_y[jj]; ob_ye = sh.obs_yerr[jj];
     }
     const int ob_tile = ob_g >= 0 ? ob_g / kTile : -1;
-    const bool long_lc = a.want_chi2 && dsd.n_obs > kRes;
+    const bool long_lc = LONG && a.want_chi2 && dsd.n_obs > kRes;
     const bool deferred = a.want_chi2;                          // see walker_eval: the luminosity stage runs after the last tile
     const size_t sc_stride = (size_t)sh.scratch_stride;
     double *sc = sh.obs_scratch + (size_t)walker * 4 * sc_stride;   // [4][stride]: observation j >= kRes at column j - 64

@@ -21,8 +21,9 @@
 //      per-lane chi^2 partial sums; optional coalesced stores write the model light curve to HBM.
 //   4. A wavefront reduction gives -0.5*chi^2 (code/synthetic_datasets/mcmc_eqns.py:25).
 //
-// Kernels: lnprob_kernel<CURVES, SPL> (one wavefront per walker), lnprob_mw_kernel<SPL, W> (W wavefronts per walker
-// for batches that cannot fill the 1 024 SIMDs), stretch_kernel<SPL, W> (emcee's stretch move fused around either).
+// Kernels: lnprob_kernel<CURVES, SPL, LONG> (one wavefront per walker), lnprob_mw_kernel<SPL, W, LONG> (W wavefronts per
+// walker for batches that cannot fill the 1 024 SIMDs), stretch_kernel<SPL, W, LONG> (emcee's stretch move fused around
+// either); LONG = built with the scratch-row path for light curves of more than 64 points.
 // No MFMA (no dense contraction anywhere on this path), fp64 throughout; bound by the VALU issue rate of one wave per
 // SIMD (profiles/, tools/ubench).  The arithmetic is algebraically simplified with respect to the reference formulas
 // (e.g. fastness w = (Rm/Rc)^1.5 = omega*Rm^1.5/sqrt(GM), eta1-eta2 = -tanh); oracle/mp_oracle.c keeps the literal
@@ -36,7 +37,7 @@
 namespace mp {
 
 // ---------------------------------------------------------------- batched log-posterior kernel
-template <bool CURVES, int SPL>
+template <bool CURVES, int SPL, bool LONG>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, SPL >= 4 ? 1 : 2))) void lnprob_kernel(const DevShared sh, const LaunchArgs a) {
     __shared__ double Lbuf[2 * (64 * SPL + 1)];
     const int walker = blockIdx.x;
@@ -46,7 +47,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, SPL >= 4 
     for (int i = 0; i < MP_MAX_NDIM; ++i) par[i] = i < a.ndim ? pw[i] : 0.0;
     double lnp;
     int status, sweeps;
-    walker_eval<CURVES, SPL>(sh, a, walker, par, Lbuf, lnp, status, sweeps);
+    walker_eval<CURVES, SPL, LONG>(sh, a, walker, par, Lbuf, lnp, status, sweeps);
     if (threadIdx.x == 0) {
         a.lnprob[walker] = lnp;
         if (a.status) a.status[walker] = status;
@@ -54,7 +55,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, SPL >= 4 
     }
 }
 
-template <int SPL, int W>
+template <int SPL, int W, bool LONG>
 __global__ __launch_bounds__(64 * W) void lnprob_mw_kernel(const DevShared sh, const LaunchArgs a) {
     __shared__ MwLds<SPL, W> lds;
     const int walker = blockIdx.x;
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(64 * W) void lnprob_mw_kernel(const DevShared sh, c
     for (int i = 0; i < MP_MAX_NDIM; ++i) par[i] = i < a.ndim ? pw[i] : 0.0;
     double lnp;
     int status, sweeps;
-    walker_eval_mw<SPL, W>(sh, a, walker, par, lds, lnp, status, sweeps);
+    walker_eval_mw<SPL, W, LONG>(sh, a, walker, par, lds, lnp, status, sweeps);
     if (threadIdx.x == 0) {
         a.lnprob[walker] = lnp;
         if (a.status) a.status[walker] = status;
@@ -110,7 +111,7 @@ MP_DEV double u01(uint32_t hi, uint32_t lo) {   // 53-bit uniform in [0, 1)
 // proposal (emcee's StretchMove.get_proposal), evaluate its log-posterior with walker_eval, accept or
 // reject against the walker's current value, update position / lnprob / counters in place and write the
 // step's row of the chain.  Walkers of the complementary half are only read, so the update is race-free.
-template <int SPL, int W>
+template <int SPL, int W, bool LONG>
 __global__ __launch_bounds__(64 * W) void stretch_kernel(const DevShared sh, const StretchArgs g) {
     __shared__ typename std::conditional<(W > 1), MwLds<SPL, W>, double[2 * (64 * SPL + 1)]>::type lds;
     const int w_ens = blockIdx.x / g.n_half;                       // which ensemble
@@ -150,8 +151,8 @@ __global__ __launch_bounds__(64 * W) void stretch_kernel(const DevShared sh, con
         for (int i = 0; i < MP_MAX_NDIM; ++i) lnp = i < g.ndim ? sub_rn(lnp, mul_rn(mul_rn(0.5, prop[i]), prop[i])) : lnp;
         status = MP_STATUS_OK;
     } else {
-        if constexpr (W > 1) walker_eval_mw<SPL, W>(sh, a, k, par, lds, lnp, status, sweeps);
-        else walker_eval<false, SPL>(sh, a, k, par, lds, lnp, status, sweeps);
+        if constexpr (W > 1) walker_eval_mw<SPL, W, LONG>(sh, a, k, par, lds, lnp, status, sweeps);
+        else walker_eval<false, SPL, LONG>(sh, a, k, par, lds, lnp, status, sweeps);
     }
     if (threadIdx.x == 0) {
         const double lnp_old = g.lnprob[k];
@@ -179,19 +180,25 @@ int launch_lnprob(const DevShared &sh, const LaunchArgs &a, void *stream) {
     //  - up to 1536 walkers: one wavefront per walker, four steps per lane (256-step tiles amortise the
     //    wavefront scans best; needs the whole register file of a SIMD);
     //  - beyond: two steps per lane, which keeps two waves resident per SIMD.
+    //  - a handle that holds a light curve of more than 64 points runs the LONG builds of the same kernels.
     const bool wide = kernel_spl(a.n) == 4;
+    const bool lng = sh.scratch_stride > 0;
     hipStream_t st = (hipStream_t)stream;
     const int wpw = curves ? 1 : (sh.force_wpw ? sh.force_wpw : waves_per_walker(a.n));
     if (wpw == 4) {
-        hipLaunchKernelGGL((lnprob_mw_kernel<1, 4>), grid, dim3(256), 0, st, sh, a);
+        if (lng) hipLaunchKernelGGL((lnprob_mw_kernel<1, 4, true>), grid, dim3(256), 0, st, sh, a);
+        else hipLaunchKernelGGL((lnprob_mw_kernel<1, 4, false>), grid, dim3(256), 0, st, sh, a);
     } else if (wpw == 2) {
-        hipLaunchKernelGGL((lnprob_mw_kernel<2, 2>), grid, dim3(128), 0, st, sh, a);
+        hipLaunchKernelGGL((lnprob_mw_kernel<2, 2, true>), grid, dim3(128), 0, st, sh, a);
     } else if (curves) {
-        if (wide) hipLaunchKernelGGL((lnprob_kernel<true, 4>), grid, block, 0, st, sh, a);
-        else hipLaunchKernelGGL((lnprob_kernel<true, 2>), grid, block, 0, st, sh, a);
+        if (wide) hipLaunchKernelGGL((lnprob_kernel<true, 4, false>), grid, block, 0, st, sh, a);
+        else hipLaunchKernelGGL((lnprob_kernel<true, 2, false>), grid, block, 0, st, sh, a);
+    } else if (wide) {
+        if (lng) hipLaunchKernelGGL((lnprob_kernel<false, 4, true>), grid, block, 0, st, sh, a);
+        else hipLaunchKernelGGL((lnprob_kernel<false, 4, false>), grid, block, 0, st, sh, a);
     } else {
-        if (wide) hipLaunchKernelGGL((lnprob_kernel<false, 4>), grid, block, 0, st, sh, a);
-        else hipLaunchKernelGGL((lnprob_kernel<false, 2>), grid, block, 0, st, sh, a);
+        if (lng) hipLaunchKernelGGL((lnprob_kernel<false, 2, true>), grid, block, 0, st, sh, a);
+        else hipLaunchKernelGGL((lnprob_kernel<false, 2, false>), grid, block, 0, st, sh, a);
     }
     return (int)hipGetLastError();
 }
@@ -202,10 +209,19 @@ int launch_stretch(const DevShared &sh, const StretchArgs &g, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)n_blocks);
     const int wpw = g.target == 1 ? 1 : (sh.force_wpw ? sh.force_wpw : waves_per_walker(n_blocks));
-    if (wpw == 4) hipLaunchKernelGGL((stretch_kernel<1, 4>), grid, dim3(256), 0, st, sh, g);
-    else if (wpw == 2) hipLaunchKernelGGL((stretch_kernel<2, 2>), grid, dim3(128), 0, st, sh, g);
-    else if (kernel_spl(n_blocks) == 4) hipLaunchKernelGGL((stretch_kernel<4, 1>), grid, dim3(64), 0, st, sh, g);
-    else hipLaunchKernelGGL((stretch_kernel<2, 1>), grid, dim3(64), 0, st, sh, g);
+    const bool lng = sh.scratch_stride > 0;
+    if (wpw == 4) {
+        if (lng) hipLaunchKernelGGL((stretch_kernel<1, 4, true>), grid, dim3(256), 0, st, sh, g);
+        else hipLaunchKernelGGL((stretch_kernel<1, 4, false>), grid, dim3(256), 0, st, sh, g);
+    } else if (wpw == 2) {
+        hipLaunchKernelGGL((stretch_kernel<2, 2, true>), grid, dim3(128), 0, st, sh, g);
+    } else if (kernel_spl(n_blocks) == 4) {
+        if (lng) hipLaunchKernelGGL((stretch_kernel<4, 1, true>), grid, dim3(64), 0, st, sh, g);
+        else hipLaunchKernelGGL((stretch_kernel<4, 1, false>), grid, dim3(64), 0, st, sh, g);
+    } else {
+        if (lng) hipLaunchKernelGGL((stretch_kernel<2, 1, true>), grid, dim3(64), 0, st, sh, g);
+        else hipLaunchKernelGGL((stretch_kernel<2, 1, false>), grid, dim3(64), 0, st, sh, g);
+    }
     return (int)hipGetLastError();
 }
 

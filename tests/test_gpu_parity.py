@@ -307,6 +307,29 @@ def test_long_light_curves_every_kernel_variant(mpa, co, gsynth, tarr, nw):
     assert np.array_equal(lp_(P, ds_id=ids), out)
 
 
+def test_library_first_then_torch_in_one_process(gsynth):
+    """The library and PyTorch must end up on ONE HIP runtime whichever is loaded first (torch wheels bundle their
+    own libamdhip64; a second runtime in the process sees no GPU).  Fresh interpreter: magprop_amd first, torch after."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import numpy as np, sys\n"
+        "import magprop_amd as mpa\n"
+        "assert 'torch' not in sys.modules\n"
+        "g = np.load('tests/golden/golden_synth.npz')\n"
+        "lp = mpa.LogProb(g['Humped_x'], g['Humped_y'], g['Humped_yerr'])\n"
+        "a = lp(np.array([[1.0, 5.0, -3.0, 2.0, -1.0, 0.0]]))\n"
+        "import torch\n"
+        "p = torch.tensor([[1.0, 5.0, -3.0, 2.0, -1.0, 0.0]], dtype=torch.float64, device='cuda')\n"
+        "b = lp.lnprob_device(p).cpu().numpy()\n"
+        "assert a[0] == b[0], (a, b)\n"
+        "print('one-runtime-ok', a[0])\n")
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "one-runtime-ok" in r.stdout, r.stderr[-2000:]
+
+
 def test_edge_cases(mpa, synth_handle, gsynth):
     from magprop_amd import _capi
     out = synth_handle.lnprob_batch(np.empty((0, 6)), ds_id=0)

@@ -136,6 +136,26 @@ def test_sampler_on_a_long_light_curve(gsynth):
     assert tarr[0] <= x[0] and x[-1] <= tarr[-1]
 
 
+def test_synth_mcmc_tool_rerun_reproduces_the_chain(tmp_path, capsys):
+    """synth_mcmc.py:139-149 (--re-run): the run recorded in <grb>_info.json is repeated bit for bit."""
+    import filecmp
+    import importlib.util
+    import os
+    import shutil
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("run_synth_mcmc", os.path.join(root, "tools", "run_synth_mcmc.py"))
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    a, b = tmp_path / "a", tmp_path / "b"
+    tool.main(["--grb", "Sloped", "-w", "24", "-s", "12", "--seed", "99", "--out", str(a)])
+    os.makedirs(b)
+    shutil.copy(a / "Sloped_info.json", b / "Sloped_info.json")
+    tool.main(["--grb", "Sloped", "--re-run", "--out", str(b)])
+    assert "Mean acceptance fraction" in capsys.readouterr().out
+    for name in ("Sloped_chain.csv", "Sloped_lnp.csv", "Sloped_0.csv", "Sloped_5.csv"):
+        assert filecmp.cmp(a / name, b / name, shallow=False), name
+
+
 def test_sampler_argument_validation(gsynth):
     from magprop_amd import EnsembleSampler
     x, y, yerr = gsynth["Humped_x"], gsynth["Humped_y"], gsynth["Humped_yerr"]
