@@ -254,6 +254,11 @@ mp_handle *mp_create(const mp_model_cfg *cfg, const double *tgrid, int n_grid, i
     s.q = q;
     s.sweep_tol = 1.0e-9;
     s.force_wpw = 0;
+    s.force_spl = 0;
+    if (const char *e = std::getenv("MAGPROP_AMD_SPL")) {          // experiments only
+        const int v = std::atoi(e);
+        if (v == 2 || v == 4) s.force_spl = v;
+    }
     if (const char *e = std::getenv("MAGPROP_AMD_WPW")) {          // experiments only
         const int v = std::atoi(e);
         if (v == 1 || v == 2 || v == 4) s.force_wpw = v;
@@ -425,7 +430,7 @@ int mp_lnprob_batch(mp_handle *h, const double *pars, const int32_t *ds_id, int 
     int cnt = 0;
     for (int i = 0; i < n; ++i)
         if (status[i] == MP_STATUS_OK) { tot += sweeps[i]; ++cnt; }
-    const int ktile = mp::kTile * mp::kernel_spl(n);
+    const int ktile = mp::kTile * (h->sh.force_spl ? h->sh.force_spl : mp::kernel_spl(n));
     const int kernel_tiles = ((int)h->tgrid.size() - 1 + ktile - 1) / ktile;
     h->last_mean_sweeps = cnt ? tot / ((double)cnt * kernel_tiles) : 0.0;
     return MP_OK;

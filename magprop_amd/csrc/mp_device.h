@@ -53,7 +53,7 @@ struct DevShared {
     double q, inv_q;
     double sweep_tol;     // relative change of the step-end values that ends the Newton sweeps of a tile
     int32_t force_wpw;    // experiments: 0 = automatic, else wavefronts per walker (1, 2, 4)
-    int32_t pad1;
+    int32_t force_spl;    // experiments: 0 = automatic, else steps per lane of the one-wavefront kernels (2, 4)
     double eamW[4][4];
     mp_model_cfg cfg;
 };
@@ -100,7 +100,7 @@ struct StretchArgs {
 };
 
 // Steps per lane of the kernel variant used for a batch of n walkers (tiles are 64*spl steps): see launch_lnprob.
-inline int kernel_spl(int n) { return n <= 1536 ? 4 : 2; }
+inline int kernel_spl(int n) { return n <= 1024 ? 4 : 2; }   // 1 024 SIMDs: beyond one wave each, two resident waves win (tools/spl_scan.sh)
 // Wavefronts that cooperate on one walker: small batches cannot give every SIMD (256 CUs x 4) a walker of its own.
 inline int waves_per_walker(int n) { return n <= 256 ? 4 : 1; }
 

@@ -176,12 +176,12 @@ int launch_lnprob(const DevShared &sh, const LaunchArgs &a, void *stream) {
     const bool curves = a.ltot || a.lprop || a.ldip || a.mdisc || a.omega;
     dim3 grid((unsigned)a.n), block(64);
     // Variants (results agree to rounding):
-    //  - batches that leave SIMDs idle (256 CUs x 4 SIMDs) put 4 or 2 wavefronts on every walker;
-    //  - up to 1536 walkers: one wavefront per walker, four steps per lane (256-step tiles amortise the
-    //    wavefront scans best; needs the whole register file of a SIMD);
-    //  - beyond: two steps per lane, which keeps two waves resident per SIMD.
+    //  - batches that leave most SIMDs idle (256 CUs x 4 SIMDs; n <= 256) put 4 wavefronts on every walker;
+    //  - up to 1024 walkers (one wave per SIMD): one wavefront per walker, four steps per lane (256-step tiles
+    //    amortise the wavefront scans best; needs the whole register file of a SIMD);
+    //  - beyond: two steps per lane, which keeps two waves resident per SIMD (they fill each other's issue gaps).
     //  - a handle that holds a light curve of more than 64 points runs the LONG builds of the same kernels.
-    const bool wide = kernel_spl(a.n) == 4;
+    const bool wide = (sh.force_spl ? sh.force_spl : kernel_spl(a.n)) == 4;
     const bool lng = sh.scratch_stride > 0;
     hipStream_t st = (hipStream_t)stream;
     const int wpw = curves ? 1 : (sh.force_wpw ? sh.force_wpw : waves_per_walker(a.n));
@@ -215,7 +215,7 @@ int launch_stretch(const DevShared &sh, const StretchArgs &g, void *stream) {
         else hipLaunchKernelGGL((stretch_kernel<1, 4, false>), grid, dim3(256), 0, st, sh, g);
     } else if (wpw == 2) {
         hipLaunchKernelGGL((stretch_kernel<2, 2, true>), grid, dim3(128), 0, st, sh, g);
-    } else if (kernel_spl(n_blocks) == 4) {
+    } else if ((sh.force_spl ? sh.force_spl : kernel_spl(n_blocks)) == 4) {
         if (lng) hipLaunchKernelGGL((stretch_kernel<4, 1, true>), grid, dim3(64), 0, st, sh, g);
         else hipLaunchKernelGGL((stretch_kernel<4, 1, false>), grid, dim3(64), 0, st, sh, g);
     } else {

@@ -17,7 +17,7 @@ GPU_VS_C_RTOL = 1e-10   # HIP kernel vs serial C oracle: same scheme, different 
 def kernel_variant(n):
     """(wavefronts per walker, steps per lane) the library picks for a batch of n (mp_device.h): batches of different
     variants agree to rounding, batches of the same variant bit for bit."""
-    return (4, 1) if n <= 256 else (2, 2) if n <= 512 else (1, 4) if n <= 1536 else (1, 2)
+    return (4, 1) if n <= 256 else (1, 4) if n <= 1024 else (1, 2)
 LOG_MASK = 0b111100
 
 
