@@ -55,6 +55,11 @@ def glibscan():
 
 
 @pytest.fixture(scope="session")
+def glonglc():
+    return np.load(os.path.join(GOLDEN, "golden_longlc.npz"))
+
+
+@pytest.fixture(scope="session")
 def gcorners():
     return np.load(os.path.join(GOLDEN, "golden_corners.npz"))
 

@@ -19,7 +19,8 @@ What is called (paths relative to /root/reference):
                   tests/test_data/model_light_curve.csv — decimated (every 20th row) copies.
 `*_tight` arrays: the same reference code with its odeint call given rtol=atol=1e-12 (integrator noise
 removed; see tight_lsoda).
-Outputs: golden_synth.npz, golden_lib.npz, golden_flagscan.npz, golden_corners.npz, golden_libscan.npz, MANIFEST.json.
+Outputs: golden_synth.npz, golden_lib.npz, golden_flagscan.npz, golden_corners.npz, golden_libscan.npz, golden_longlc.npz,
+MANIFEST.json.
 """
 import argparse
 import contextlib
@@ -312,10 +313,58 @@ def make_lib():
     print("lib lnlike L:", g["lnlike_L"][:4])
 
 
+def make_longlc():
+    """Light curves of real-GRB length (data/SGRBS/*_raw.txt have 8..1944 rows; the synthetic sets all have 50):
+    the reference's own interpolation + chi-square over 112 / 410 / 1944 observed times, both variants."""
+    import pandas as pd
+    rng = np.random.default_rng(SEED0 + 77)
+    g = {}
+    truth = np.array(TRUTHS["Humped"])
+    model = sf.model_lum(np.array(GRB_PARS["Humped"]))
+    for n in (112, 410, 1944):
+        x = 10.0 ** rng.uniform(np.log10(1.2), np.log10(9.0e5), n)
+        k = n // 4                                                     # early-time cluster: many points per grid interval
+        x[:k] = rng.uniform(model[0, 3000], model[0, 3010], k)
+        x = np.sort(x)
+        x[0], x[-1] = model[0, 0], model[0, -1]                        # exactly the first / last knot
+        y0 = np.interp(x, model[0], model[1])
+        yerr = 0.25 * y0
+        y = y0 + rng.normal(0.0, yerr)
+        P = [truth.copy()] + [truth + 1.0e-4 * rng.standard_normal(6) for _ in range(5)]
+        P += [truth + 0.05 * np.maximum(np.abs(truth), 0.5) * rng.standard_normal(6) for _ in range(3)]
+        P += [LOWER + (UPPER - LOWER) * rng.random(6) for _ in range(3)]
+        P = np.array(P)
+        res = [synth_lnprob(p, x, y, yerr) for p in P]
+        with tight_lsoda():
+            tight = [synth_lnprob(p, x, y, yerr) for p in P]
+        g[f"synth{n}_ds"] = np.array([x, y, yerr])
+        g[f"synth{n}_pars"] = P
+        g[f"synth{n}_lnprob"] = np.array([r[0] for r in res])
+        g[f"synth{n}_status"] = np.array([r[1] for r in res], dtype=np.int32)
+        g[f"synth{n}_lnprob_tight"] = np.array([r[0] for r in tight])
+    # lib variant, short-GRB grid (1e-3 .. 1e6 s), 1944 points, physical parameters (magnetar/mcmc_eqns.py:17-37)
+    os.chdir(REF)
+    pars = np.array(GRB_PARS["Humped"])
+    lc = lib.model_lc(pars, GRBtype="S")
+    n = 1944
+    x = np.sort(10.0 ** rng.uniform(-2.9, 5.9, n))
+    x[0], x[-1] = lc[0, 0], lc[0, -1]
+    y0 = np.interp(x, lc[0], lc[1])
+    yerr = 0.2 * y0
+    y = y0 + rng.normal(0.0, yerr)
+    data = pd.DataFrame({"t": x, "Lum50": y, "Lum50err": yerr})
+    P = np.array([np.abs(pars * (1.0 + 0.1 * rng.standard_normal(6))) for _ in range(8)])
+    g["libS1944_ds"] = np.array([x, y, yerr])
+    g["libS1944_pars"] = P
+    g["libS1944_lnlike"] = np.array([lib.lnlike(p, data, "S") for p in P])
+    np.savez_compressed(os.path.join(HERE, "golden_longlc.npz"), **g)
+    print("longlc synth1944:", g["synth1944_lnprob"][:3], g["synth1944_lnprob_tight"][:3])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--flag-scan", type=int, default=1500)
-    ap.add_argument("--only", choices=["all", "lib", "corners", "libscan"], default="all", help="regenerate only one file")
+    ap.add_argument("--only", choices=["all", "lib", "corners", "libscan", "longlc"], default="all", help="regenerate only one file")
     a = ap.parse_args()
     import scipy, pandas
     if a.only == "all":
@@ -327,6 +376,8 @@ def main():
         make_lib()
     if a.only in ("all", "libscan"):
         make_libscan()
+    if a.only in ("all", "longlc"):
+        make_longlc()
     manifest = {
         "generator": "tests/golden/make_golden.py",
         "reference": "sgibson91/magprop mounted at /root/reference (magnetar v%s)" % lib.__version__

@@ -307,6 +307,36 @@ def test_long_light_curves_every_kernel_variant(mpa, co, gsynth, tarr, nw):
     assert np.array_equal(lp_(P, ds_id=ids), out)
 
 
+@pytest.mark.parametrize("n", [112, 410, 1944])
+def test_long_light_curves_vs_reference(mpa, gsynth, glonglc, n):
+    """The scratch-row path against the reference itself (golden_longlc.npz: reference model_lum + chi-square over
+    112 / 410 / 1944 observed times, a quarter of them clustered in ten grid intervals)."""
+    from magprop_amd import LogProb
+    x, y, yerr = glonglc[f"synth{n}_ds"]
+    P, ref, rst = glonglc[f"synth{n}_pars"], glonglc[f"synth{n}_lnprob"], glonglc[f"synth{n}_status"]
+    lp_ = LogProb(x, y, yerr)
+    out, st = lp_.handle.lnprob_batch(P, want_status=True)
+    assert np.array_equal(st, rst)
+    ok = np.isfinite(ref)
+    assert np.array_equal(np.isfinite(out), ok)
+    assert np.all(np.abs(out[ok] - ref[ok]) <= REF_ATOL + REF_RTOL * np.abs(ref[ok]))
+    tight = glonglc[f"synth{n}_lnprob_tight"]
+    assert np.all(np.abs(out[ok] - tight[ok]) <= TIGHT_ATOL + TIGHT_RTOL * np.abs(tight[ok]))
+    # the one-wavefront kernels (batch > 256) on the same walkers
+    big = np.tile(P, (60, 1))
+    out_big = lp_(big)[: len(P)]
+    assert np.allclose(out_big[ok], out[ok], rtol=1e-10, atol=1e-9) and np.all(out_big[~ok] == -np.inf)
+
+
+def test_long_light_curve_lib_short_grb_grid(mpa, glonglc):
+    import pandas as pd
+    x, y, yerr = glonglc["libS1944_ds"]
+    data = pd.DataFrame({"t": x, "Lum50": y, "Lum50err": yerr})
+    ref = glonglc["libS1944_lnlike"]
+    out = mpa.lnlike(glonglc["libS1944_pars"], data, "S")
+    assert np.all(np.abs(out - ref) <= REF_ATOL + REF_RTOL * np.abs(ref))
+
+
 def test_library_first_then_torch_in_one_process(gsynth):
     """The library and PyTorch must end up on ONE HIP runtime whichever is loaded first (torch wheels bundle their
     own libamdhip64; a second runtime in the process sees no GPU).  Fresh interpreter: magprop_amd first, torch after."""

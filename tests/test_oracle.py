@@ -199,6 +199,28 @@ def test_lib_prior_wide_scan(glib, glibscan, tarr):
         assert abs(ll - r) <= REF_ATOL + REF_RTOL * abs(r)
 
 
+@pytest.mark.parametrize("n", [112, 410, 1944])
+def test_c_oracle_long_light_curves_vs_reference(gsynth, glonglc, tarr, cfg, n):
+    """Light curves of real-GRB length (the synthetic sets all have 50 points): reference interpolation + chi-square."""
+    x, y, yerr = glonglc[f"synth{n}_ds"]
+    P, ref, rst = glonglc[f"synth{n}_pars"], glonglc[f"synth{n}_lnprob"], glonglc[f"synth{n}_status"]
+    out, st = co.lnprob_batch(cfg, P, tarr, x, y, yerr, gsynth["prior_lower"], gsynth["prior_upper"], LOG_MASK)
+    assert np.array_equal(st, rst)
+    ok = np.isfinite(ref)
+    assert np.array_equal(np.isfinite(out), ok) and ok.sum() >= 9
+    assert np.all(np.abs(out[ok] - ref[ok]) <= REF_ATOL + REF_RTOL * np.abs(ref[ok]))
+    tight = glonglc[f"synth{n}_lnprob_tight"]
+    assert np.all(np.abs(out[ok] - tight[ok]) <= TIGHT_ATOL + TIGHT_RTOL * np.abs(tight[ok]))
+
+
+def test_c_oracle_long_light_curve_lib_short_grb_grid(glonglc, tarr_S):
+    x, y, yerr = glonglc["libS1944_ds"]
+    for p, ref in zip(glonglc["libS1944_pars"], glonglc["libS1944_lnlike"]):
+        ll, st = co.lnlike(co.cfg_lib(), p, tarr_S, x, y, yerr)
+        assert st == 0
+        assert abs(ll - ref) <= REF_ATOL + REF_RTOL * abs(ref), (p, ll, ref)
+
+
 # ---------------------------------------------------------------- scipy/LSODA port
 @pytest.mark.parametrize("name", TYPES)
 def test_lsoda_port_matches_reference(gsynth, tarr, name):
