@@ -77,6 +77,28 @@ struct DevBuf {
     }
 };
 
+// Page-locked host staging area of the host-buffer entry points: copies to and from it are true asynchronous DMA
+// (pageable user buffers would be staged by the runtime copy by copy).
+struct PinnedBuf {
+    unsigned char *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t n) {
+        if (n <= cap) return MP_OK;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        const size_t want = std::max<size_t>(n, 4096);
+        HIP_TRY(hipHostMalloc((void **)&p, want, hipHostMallocDefault));
+        cap = want;
+        return MP_OK;
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
 }  // namespace
 
 struct mp_handle {
@@ -93,6 +115,8 @@ struct mp_handle {
     // workspace of the host-buffer entry points
     DevBuf<double> w_pars, w_lnprob, w_curves;
     DevBuf<int32_t> w_dsid, w_status, w_sweeps;
+    DevBuf<unsigned char> w_io;   // mp_lnprob_batch: [pars | ds_id] in, [lnprob | status | sweeps] out, one copy each way
+    PinnedBuf h_io;
     DevBuf<double> w_scratch;   // DevShared::obs_scratch (only allocated once a light curve longer than 64 points is set)
     double last_mean_sweeps = 0.0;
 };
@@ -301,6 +325,7 @@ int mp_destroy(mp_handle *h) {
     h->d_obs_yerr.release(); h->d_obs_g.release(); h->d_tile_ptr.release(); h->d_ds.release();
     h->w_pars.release(); h->w_lnprob.release(); h->w_curves.release();
     h->w_dsid.release(); h->w_status.release(); h->w_sweeps.release(); h->w_scratch.release();
+    h->w_io.release(); h->h_io.release();
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return MP_OK;
@@ -397,35 +422,39 @@ int mp_lnprob_batch(mp_handle *h, const double *pars, const int32_t *ds_id, int 
     }
     DeviceScope scope(h->device);
     const size_t ng = h->tgrid.size();
-    if ((rc = h->w_pars.ensure((size_t)n * ndim)) || (rc = h->w_lnprob.ensure(n)) || (rc = h->w_status.ensure(n)) ||
-        (rc = h->w_sweeps.ensure(n)) || (ds_id && (rc = h->w_dsid.ensure(n))) ||
+    // one staging block each way: [pars n*ndim f64 | ds_id n i32] in, [lnprob n f64 | status n i32 | sweeps n i32] out
+    const size_t in_pars = sizeof(double) * (size_t)n * ndim, in_ids = ds_id ? sizeof(int32_t) * (size_t)n : 0;
+    const size_t in_bytes = (in_pars + in_ids + 7) & ~(size_t)7;
+    const size_t out_bytes = (sizeof(double) + 2 * sizeof(int32_t)) * (size_t)n;
+    if ((rc = h->w_io.ensure(in_bytes + out_bytes)) || (rc = h->h_io.ensure(in_bytes + out_bytes)) ||
         (ltot_out && (rc = h->w_curves.ensure((size_t)n * ng))) || (rc = ensure_scratch(h, n)))
         return rc;
     hipStream_t st = h->stream;
-    HIP_TRY(hipMemcpyAsync(h->w_pars.p, pars, sizeof(double) * (size_t)n * ndim, hipMemcpyHostToDevice, st));
-    if (ds_id) HIP_TRY(hipMemcpyAsync(h->w_dsid.p, ds_id, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, st));
+    std::memcpy(h->h_io.p, pars, in_pars);
+    if (ds_id) std::memcpy(h->h_io.p + in_pars, ds_id, in_ids);
+    HIP_TRY(hipMemcpyAsync(h->w_io.p, h->h_io.p, in_pars + in_ids, hipMemcpyHostToDevice, st));
     if (ltot_out) HIP_TRY(hipMemsetAsync(h->w_curves.p, 0xFF, sizeof(double) * (size_t)n * ng, st));  // NaN fill
+    unsigned char *d_out = h->w_io.p + in_bytes, *h_out = h->h_io.p + in_bytes;
     mp::LaunchArgs a{};
-    a.pars = h->w_pars.p;
-    a.ds_id = ds_id ? h->w_dsid.p : nullptr;
+    a.pars = (const double *)h->w_io.p;
+    a.ds_id = ds_id ? (const int32_t *)(h->w_io.p + in_pars) : nullptr;
     a.n = n;
     a.ndim = ndim;
     a.physical = 0;
     a.want_chi2 = 1;
-    a.lnprob = h->w_lnprob.p;
-    a.status = h->w_status.p;
-    a.sweeps = h->w_sweeps.p;
+    a.lnprob = (double *)d_out;
+    a.status = (int32_t *)(d_out + sizeof(double) * (size_t)n);
+    a.sweeps = a.status + n;
     a.ltot = ltot_out ? h->w_curves.p : nullptr;
     const int e = mp::launch_lnprob(h->sh, a, st);
     if (e) return fail(MP_EHIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
-    std::vector<int32_t> sweeps(n), status(n);
-    HIP_TRY(hipMemcpyAsync(lnprob_out, h->w_lnprob.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(status.data(), h->w_status.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(sweeps.data(), h->w_sweeps.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(h_out, d_out, out_bytes, hipMemcpyDeviceToHost, st));
     if (ltot_out)
         HIP_TRY(hipMemcpyAsync(ltot_out, h->w_curves.p, sizeof(double) * (size_t)n * ng, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    if (status_out) std::memcpy(status_out, status.data(), sizeof(int32_t) * (size_t)n);
+    std::memcpy(lnprob_out, h_out, sizeof(double) * (size_t)n);
+    const int32_t *status = (const int32_t *)(h_out + sizeof(double) * (size_t)n), *sweeps = status + n;
+    if (status_out) std::memcpy(status_out, status, sizeof(int32_t) * (size_t)n);
     double tot = 0.0;
     int cnt = 0;
     for (int i = 0; i < n; ++i)
