@@ -1,0 +1,92 @@
+"""Soak parity: every kernel variant against the serial C oracle on thousands of walkers spread over the whole prior
+box, its faces and the neighbourhood of the four truths (flag agreement as a confusion matrix)."""
+import json
+import multiprocessing as mp
+import os
+
+import numpy as np
+import pytest
+
+from conftest import TRUTHS, TYPES
+
+pytestmark = pytest.mark.gpu
+LOG_MASK = 0b111100
+N_SOAK = int(os.environ.get("MAGPROP_SOAK_N", "32768"))
+
+
+def _walkers(rng, n, lo, hi):
+    P = lo + (hi - lo) * rng.random((n, 6))                                   # uniform over the prior box
+    k = n // 4
+    for i, name in enumerate(TYPES):                                          # a quarter near the four truths
+        t = np.array(TRUTHS[name])
+        sl = slice(i * (k // 4), (i + 1) * (k // 4))
+        scale = 10.0 ** rng.uniform(-4, -1, (k // 4, 1))
+        P[sl] = np.clip(t + scale * np.maximum(np.abs(t), 0.5) * rng.standard_normal((k // 4, 6)), lo, hi)
+    f = slice(k, k + n // 10)                                                 # a tenth on the faces of the box
+    m = P[f]
+    j = rng.integers(0, 6, len(m))
+    side = rng.random(len(m)) < 0.5
+    m[np.arange(len(m)), j] = np.where(side, lo[j], hi[j])
+    P[f] = m
+    o = slice(k + n // 10, k + n // 10 + n // 50)                             # 2 %: one ulp outside a face (prior: -inf)
+    m = P[o]
+    j = rng.integers(0, 6, len(m))
+    side = rng.random(len(m)) < 0.5
+    m[np.arange(len(m)), j] = np.where(side, np.nextafter(lo[j], -np.inf), np.nextafter(hi[j], np.inf))
+    P[o] = m
+    return P
+
+
+def test_every_kernel_variant_against_the_c_oracle(gsynth, tarr):
+    from magprop_amd import LogProb
+    rng = np.random.default_rng(20261003)
+    lo, hi = gsynth["prior_lower"], gsynth["prior_upper"]
+    P = _walkers(rng, N_SOAK, lo, hi)
+    ids = rng.integers(0, 4, N_SOAK).astype(np.int32)
+    sets = [(gsynth[n + "_x"], gsynth[n + "_y"], gsynth[n + "_yerr"]) for n in TYPES]
+
+    # oracle: spawned CPU workers (clean interpreters: no fork of a process that has initialised the GPU)
+    from _soak_worker import oracle_slice
+    jobs, where = [], []
+    for d in range(4):
+        idx = np.nonzero(ids == d)[0]
+        for part in np.array_split(idx, 8):
+            jobs.append((P[part], sets[d], tarr, lo, hi, LOG_MASK))
+            where.append(part)
+    ncpu = max(1, min(16, len(os.sched_getaffinity(0))))
+    with mp.get_context("spawn").Pool(ncpu) as pool:
+        res = pool.map(oracle_slice, jobs, chunksize=1)
+    ref = np.empty(N_SOAK)
+    rst = np.empty(N_SOAK, dtype=np.int32)
+    for part, (v, s) in zip(where, res):
+        ref[part], rst[part] = v, s
+
+    lp_ = LogProb(*sets[0])
+    for s in sets[1:]:
+        lp_.add_dataset(*s)
+    summary = {"n": N_SOAK, "oracle_status_counts": np.bincount(rst, minlength=4).tolist(), "variants": {}}
+    for batch, label in ((256, "4 wavefronts per walker"), (1024, "1 wavefront, 4 steps per lane"),
+                         (4096, "1 wavefront, 2 steps per lane")):
+        out = np.empty(N_SOAK)
+        st = np.empty(N_SOAK, dtype=np.int32)
+        for a in range(0, N_SOAK, batch):
+            o, s = lp_.handle.lnprob_batch(P[a:a + batch], ds_id=ids[a:a + batch], want_status=True)
+            out[a:a + batch], st[a:a + batch] = o, s
+        conf = np.zeros((4, 4), dtype=int)
+        np.add.at(conf, (rst, st), 1)
+        both = (rst == 0) & (st == 0)
+        rel = np.abs(out[both] - ref[both]) / np.maximum(np.abs(ref[both]), 1.0)
+        summary["variants"][label] = {"batch": batch, "confusion_oracle_rows_kernel_cols": conf.tolist(),
+                                      "status_mismatches": int(np.sum(rst != st)), "max_rel_diff": float(rel.max()),
+                                      "median_rel_diff": float(np.median(rel)),
+                                      "p999_rel_diff": float(np.quantile(rel, 0.999))}
+        assert not np.any(np.isnan(out))
+        assert np.all(out[st != 0] == -np.inf)
+        assert np.sum(rst != st) <= max(2, N_SOAK // 4000), summary["variants"][label]
+        assert rel.max() <= 1e-9, summary["variants"][label]
+        assert np.quantile(rel, 0.999) <= 1e-10, summary["variants"][label]
+    out_dir = os.path.join(os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(__file__))), "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "soak_parity.json"), "w") as f:
+            json.dump(summary, f, indent=1)
+    print(json.dumps(summary))
