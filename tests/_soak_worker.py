@@ -9,6 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def oracle_slice(job):
     from oracle import c_oracle as co
-    pars, ds, tarr, lower, upper, log_mask = job
+    variant, pars, ds, tarr, lower, upper, log_mask = job
     x, y, yerr = ds
-    return co.lnprob_batch(co.cfg_synth(), pars, tarr, x, y, yerr, lower, upper, log_mask)
+    cfg = co.cfg_synth() if variant == "synth" else co.cfg_lib()
+    return co.lnprob_batch(cfg, pars, tarr, x, y, yerr, lower, upper, log_mask)

@@ -51,7 +51,7 @@ def test_every_kernel_variant_against_the_c_oracle(gsynth, tarr):
     for d in range(4):
         idx = np.nonzero(ids == d)[0]
         for part in np.array_split(idx, 8):
-            jobs.append((P[part], sets[d], tarr, lo, hi, LOG_MASK))
+            jobs.append(("synth", P[part], sets[d], tarr, lo, hi, LOG_MASK))
             where.append(part)
     ncpu = max(1, min(16, len(os.sched_getaffinity(0))))
     with mp.get_context("spawn").Pool(ncpu) as pool:
@@ -90,3 +90,33 @@ def test_every_kernel_variant_against_the_c_oracle(gsynth, tarr):
         with open(os.path.join(out_dir, "soak_parity.json"), "w") as f:
             json.dump(summary, f, indent=1)
     print(json.dumps(summary))
+
+
+def test_library_variant_against_the_c_oracle(glib, tarr):
+    """Same soak for the `magnetar` package variant (I = 0.8 M R^2, n = 1 in the ODE, Lprop == 0; 7-parameter
+    likelihood with f_beam) over its own prior box (magnetar/mcmc_limits.csv)."""
+    from magprop_amd import LogProb, mcmc_eqns
+    from _soak_worker import oracle_slice
+    n = N_SOAK // 4
+    rng = np.random.default_rng(77)
+    lo, hi = mcmc_eqns._bounds(7)
+    P = lo + (hi - lo) * rng.random((n, 7))
+    P[: n // 50, 6] = np.nextafter(hi[6], np.inf)                               # f_beam one ulp above its bound
+    ds = tuple(glib["ds_L"])
+    parts = np.array_split(np.arange(n), 16)
+    ncpu = max(1, min(16, len(os.sched_getaffinity(0))))
+    with mp.get_context("spawn").Pool(ncpu) as pool:
+        res = pool.map(oracle_slice, [("lib", P[p], ds, tarr, lo, hi, mcmc_eqns.LIB_LOG_MASK) for p in parts], chunksize=1)
+    ref = np.concatenate([r[0] for r in res])
+    rst = np.concatenate([r[1] for r in res])
+    lp_ = LogProb(*ds, variant="lib", lower=lo, upper=hi)
+    for batch in (256, 1024, 4096):
+        out = np.empty(n)
+        st = np.empty(n, dtype=np.int32)
+        for a in range(0, n, batch):
+            out[a:a + batch], st[a:a + batch] = lp_.handle.lnprob_batch(P[a:a + batch], want_status=True)
+        assert np.array_equal(st, rst), (batch, np.nonzero(st != rst)[0][:5])
+        both = rst == 0
+        rel = np.abs(out[both] - ref[both]) / np.maximum(np.abs(ref[both]), 1.0)
+        assert both.sum() > 0.9 * n and rel.max() <= 1e-9 and np.quantile(rel, 0.999) <= 1e-10, (batch, rel.max())
+        assert np.all(out[~both] == -np.inf)
