@@ -55,6 +55,11 @@ def glibscan():
 
 
 @pytest.fixture(scope="session")
+def gflag2():
+    return np.load(os.path.join(GOLDEN, "golden_flagscan2.npz"))
+
+
+@pytest.fixture(scope="session")
 def glonglc():
     return np.load(os.path.join(GOLDEN, "golden_longlc.npz"))
 

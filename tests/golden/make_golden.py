@@ -20,7 +20,7 @@ What is called (paths relative to /root/reference):
 `*_tight` arrays: the same reference code with its odeint call given rtol=atol=1e-12 (integrator noise
 removed; see tight_lsoda).
 Outputs: golden_synth.npz, golden_lib.npz, golden_flagscan.npz, golden_corners.npz, golden_libscan.npz, golden_longlc.npz,
-MANIFEST.json.
+golden_flagscan2.npz, MANIFEST.json.
 """
 import argparse
 import contextlib
@@ -189,6 +189,29 @@ def make_flagscan(n):
     np.savez_compressed(os.path.join(HERE, "golden_flagscan.npz"), pars=P, lnprob=lnp, status=st,
                         lnprob_tight=tight)
     print("flag rate", (st == 1).mean())
+
+
+def _scan_one(job):
+    p, x, y, yerr = job
+    return synth_lnprob(p, x, y, yerr)
+
+
+def make_flagscan2(n_each=1500):
+    """The same scan against the other three synthetic datasets (a different posterior surface each), 3 x n_each more
+    reference evaluations over the uniform prior box."""
+    import multiprocessing as mp
+    rng = np.random.default_rng(SEED0 + 177)
+    names = ["Classic", "Sloped", "Stuttering"]
+    P = LOWER + (UPPER - LOWER) * rng.random((3 * n_each, 6))
+    ds = np.repeat(np.arange(3), n_each).astype(np.int32)
+    sets = [synth_dataset(nm, SEED0 + 1 + i)[1:] for i, nm in enumerate(names)]   # seeds as in make_synth: SEED0 + k
+    jobs = [(P[i], *sets[ds[i]]) for i in range(len(P))]
+    with mp.Pool(8) as pool:
+        res = pool.map(_scan_one, jobs, chunksize=20)
+    lnp = np.array([r[0] for r in res])
+    st = np.array([r[1] for r in res], dtype=np.int32)
+    np.savez_compressed(os.path.join(HERE, "golden_flagscan2.npz"), pars=P, ds=ds, ds_names=np.array(names), lnprob=lnp, status=st)
+    print("flagscan2 flag rate", (st == 1).mean(), "n", len(P))
 
 
 def make_corners():
@@ -364,7 +387,7 @@ def make_longlc():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--flag-scan", type=int, default=1500)
-    ap.add_argument("--only", choices=["all", "lib", "corners", "libscan", "longlc"], default="all", help="regenerate only one file")
+    ap.add_argument("--only", choices=["all", "lib", "corners", "libscan", "longlc", "flagscan2"], default="all", help="regenerate only one file")
     a = ap.parse_args()
     import scipy, pandas
     if a.only == "all":
@@ -378,6 +401,8 @@ def main():
         make_libscan()
     if a.only in ("all", "longlc"):
         make_longlc()
+    if a.only in ("all", "flagscan2"):
+        make_flagscan2()
     manifest = {
         "generator": "tests/golden/make_golden.py",
         "reference": "sgibson91/magprop mounted at /root/reference (magnetar v%s)" % lib.__version__

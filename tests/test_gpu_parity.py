@@ -95,6 +95,18 @@ def test_flag_scan(synth_handle, gflag):
     assert 2.0 <= synth_handle.last_mean_sweeps <= 6.0
 
 
+def test_flag_scan_other_datasets(synth_handle, gflag2):
+    """4 500 more prior-wide reference evaluations, against the Classic / Sloped / Stuttering datasets."""
+    ids = (gflag2["ds"] + 1).astype(np.int32)                    # synth_handle slots follow TYPES: Humped = 0
+    assert [str(n) for n in gflag2["ds_names"]] == list(TYPES[1:])
+    out, st = synth_handle.lnprob_batch(gflag2["pars"], ds_id=ids, want_status=True)
+    rst, ref = gflag2["status"], gflag2["lnprob"]
+    assert np.array_equal(st, rst)
+    ok = rst == 0
+    assert np.all(np.abs(out[ok] - ref[ok]) <= REF_ATOL + REF_RTOL * np.abs(ref[ok]))
+    assert np.all(out[~ok] == -np.inf)
+
+
 def test_prior_box_corners(synth_handle, co, gsynth, gcorners, tarr):
     """The 64 prior-box corners: identical verdicts and values to the C oracle; see tests/test_oracle.py for how
     the four corners where the reference's LSODA survives on the break-up limit are treated."""

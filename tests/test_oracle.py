@@ -100,6 +100,22 @@ def test_flag_rule_confusion_matrix(gsynth, gflag, tarr, cfg):
     assert np.all(np.abs(out[m] - tight[m]) <= TIGHT_ATOL + TIGHT_RTOL * np.abs(tight[m]))
 
 
+def test_flag_rule_on_the_other_three_datasets(gsynth, gflag2, tarr, cfg):
+    """4 500 more reference evaluations over the prior box (Classic / Sloped / Stuttering data); every 4th one here,
+    all of them on the GPU (tests/test_gpu_parity.py)."""
+    rst_all, ref_all, ds = gflag2["status"], gflag2["lnprob"], gflag2["ds"]
+    assert (rst_all == 1).sum() >= 10
+    for d, name in enumerate(gflag2["ds_names"]):
+        sel = np.nonzero(ds == d)[0][::4]
+        x, y, yerr = gsynth[str(name) + "_x"], gsynth[str(name) + "_y"], gsynth[str(name) + "_yerr"]
+        out, st = co.lnprob_batch(cfg, gflag2["pars"][sel], tarr, x, y, yerr, gsynth["prior_lower"],
+                                  gsynth["prior_upper"], LOG_MASK)
+        assert np.array_equal(st, rst_all[sel])
+        ok = rst_all[sel] == 0
+        ref = ref_all[sel]
+        assert np.all(np.abs(out[ok] - ref[ok]) <= REF_ATOL + REF_RTOL * np.abs(ref[ok]))
+
+
 def test_prior_box_corners(gsynth, gcorners, tarr, cfg):
     """All 64 corners of the prior box.  Where the reference's trajectory reaches the break-up limit
     (rotation parameter >= 0.27) LSODA either gives up ('flag') or, at default tolerances, survives riding the
