@@ -55,6 +55,11 @@ def glibscan():
 
 
 @pytest.fixture(scope="session")
+def glibscan2():
+    return np.load(os.path.join(GOLDEN, "golden_libscan2.npz"))
+
+
+@pytest.fixture(scope="session")
 def gflag2():
     return np.load(os.path.join(GOLDEN, "golden_flagscan2.npz"))
 

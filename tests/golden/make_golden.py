@@ -20,7 +20,7 @@ What is called (paths relative to /root/reference):
 `*_tight` arrays: the same reference code with its odeint call given rtol=atol=1e-12 (integrator noise
 removed; see tight_lsoda).
 Outputs: golden_synth.npz, golden_lib.npz, golden_flagscan.npz, golden_corners.npz, golden_libscan.npz, golden_longlc.npz,
-golden_flagscan2.npz, MANIFEST.json.
+golden_flagscan2.npz, golden_libscan2.npz, MANIFEST.json.
 """
 import argparse
 import contextlib
@@ -257,6 +257,34 @@ def make_libscan(n=300):
     print("libscan: flags", int((st == 1).sum()), "of", n)
 
 
+def _libscan_one(job):
+    p, x, y, yerr, kind = job
+    mod = quiet(lib.model_lc, p, xdata=x, GRBtype=kind)
+    if isinstance(mod, str):
+        return -np.inf, 1
+    v = -0.5 * np.sum(((y - mod) / yerr) ** 2.0)
+    return (v, 0) if np.isfinite(v) else (-np.inf, 2)
+
+
+def make_libscan2(n=900):
+    """Library variant on the short-GRB grid (GRBtype "S", 1e-3..1e6 s) over its prior box, golden "S" dataset."""
+    import multiprocessing as mp
+    os.chdir(REF)
+    import pandas as pd
+    lims = pd.read_csv(os.path.join(REF, "magnetar/mcmc_limits.csv"), index_col="pars")
+    lo, hi = lims["lower"].values[:6], lims["upper"].values[:6]
+    gl = np.load(os.path.join(HERE, "golden_lib.npz"))
+    x, y, yerr = gl["ds_S"]
+    rng = np.random.default_rng(SEED0 + 404)
+    P = lo + (hi - lo) * rng.random((n, 6))
+    phys = P.copy(); phys[:, 2:] = 10.0 ** phys[:, 2:]
+    with mp.Pool(8) as pool:
+        res = pool.map(_libscan_one, [(p, x, y, yerr, "S") for p in phys], chunksize=10)
+    lnl = np.array([r[0] for r in res]); st = np.array([r[1] for r in res], dtype=np.int32)
+    np.savez_compressed(os.path.join(HERE, "golden_libscan2.npz"), pars_sampler=P, pars_physical=phys, lnlike=lnl, status=st)
+    print("libscan2 (S grid): flags", int((st == 1).sum()), "of", n)
+
+
 def make_lib():
     os.chdir(REF)  # magnetar/mcmc_eqns.py:55 reads a cwd-relative CSV
     import pandas as pd
@@ -387,7 +415,7 @@ def make_longlc():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--flag-scan", type=int, default=1500)
-    ap.add_argument("--only", choices=["all", "lib", "corners", "libscan", "longlc", "flagscan2"], default="all", help="regenerate only one file")
+    ap.add_argument("--only", choices=["all", "lib", "corners", "libscan", "longlc", "flagscan2", "libscan2"], default="all", help="regenerate only one file")
     a = ap.parse_args()
     import scipy, pandas
     if a.only == "all":
@@ -403,6 +431,8 @@ def main():
         make_longlc()
     if a.only in ("all", "flagscan2"):
         make_flagscan2()
+    if a.only in ("all", "libscan2"):
+        make_libscan2()
     manifest = {
         "generator": "tests/golden/make_golden.py",
         "reference": "sgibson91/magprop mounted at /root/reference (magnetar v%s)" % lib.__version__

@@ -230,6 +230,18 @@ def test_lib_prior_wide_scan(mpa, glib, glibscan):
     assert np.all(np.abs(out2 - ref) <= REF_ATOL + REF_RTOL * np.abs(ref))
 
 
+def test_lib_prior_wide_scan_short_grb_grid(mpa, glib, glibscan2):
+    """900 points over the library variant's prior box on the "S" grid, against the reference's model_lc + chi-square."""
+    import pandas as pd
+    x, y, yerr = glib["ds_S"]
+    data = pd.DataFrame({"t": x, "Lum50": y, "Lum50err": yerr})
+    ref, rst = glibscan2["lnlike"], glibscan2["status"]
+    out = mpa.lnprob(glibscan2["pars_sampler"], data, "S")
+    ok = rst == 0
+    assert np.array_equal(np.isfinite(out), ok)
+    assert np.all(np.abs(out[ok] - ref[ok]) <= REF_ATOL + REF_RTOL * np.abs(ref[ok]))
+
+
 def test_lib_lnprob_intent(mpa, glib):
     """lnprob = box prior in log space + un-logged likelihood."""
     import pandas as pd

@@ -237,6 +237,18 @@ def test_c_oracle_long_light_curve_lib_short_grb_grid(glonglc, tarr_S):
         assert abs(ll - ref) <= REF_ATOL + REF_RTOL * abs(ref), (p, ll, ref)
 
 
+def test_lib_prior_wide_scan_short_grb_grid(glib, glibscan2, tarr_S):
+    """900 points uniform in the library variant's prior box on the "S" grid (1e-3..1e6 s); every 3rd one here."""
+    x, y, yerr = glib["ds_S"]
+    ref, rst = glibscan2["lnlike"], glibscan2["status"]
+    sel = np.unique(np.concatenate([np.arange(0, len(ref), 3), np.nonzero(rst != 0)[0]]))
+    for i in sel:
+        ll, st = co.lnlike(co.cfg_lib(), glibscan2["pars_physical"][i], tarr_S, x, y, yerr)
+        assert st == rst[i], (i, st, rst[i])
+        if rst[i] == 0:
+            assert abs(ll - ref[i]) <= REF_ATOL + REF_RTOL * abs(ref[i])
+
+
 # ---------------------------------------------------------------- scipy/LSODA port
 @pytest.mark.parametrize("name", TYPES)
 def test_lsoda_port_matches_reference(gsynth, tarr, name):
