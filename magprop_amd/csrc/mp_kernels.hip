@@ -40,6 +40,7 @@ namespace mp {
 template <bool CURVES, int SPL, bool LONG>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, SPL >= 4 ? 1 : 2))) void lnprob_kernel(const DevShared sh, const LaunchArgs a) {
     __shared__ double Lbuf[2 * (64 * SPL + 1)];
+    ktab_init();
     const int walker = blockIdx.x;
     double par[MP_MAX_NDIM];
     const double *pw = a.pars + (size_t)walker * a.ndim;
@@ -58,6 +59,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, SPL >= 4 
 template <int SPL, int W, bool LONG>
 __global__ __launch_bounds__(64 * W) void lnprob_mw_kernel(const DevShared sh, const LaunchArgs a) {
     __shared__ MwLds<SPL, W> lds;
+    ktab_init();
     const int walker = blockIdx.x;
     double par[MP_MAX_NDIM];
     const double *pw = a.pars + (size_t)walker * a.ndim;
@@ -114,6 +116,7 @@ MP_DEV double u01(uint32_t hi, uint32_t lo) {   // 53-bit uniform in [0, 1)
 template <int SPL, int W, bool LONG>
 __global__ __launch_bounds__(64 * W) void stretch_kernel(const DevShared sh, const StretchArgs g) {
     __shared__ typename std::conditional<(W > 1), MwLds<SPL, W>, double[2 * (64 * SPL + 1)]>::type lds;
+    ktab_init();
     const int w_ens = blockIdx.x / g.n_half;                       // which ensemble
     const int slot = blockIdx.x - w_ens * g.n_half;                // which walker of the active half
     const int32_t *perm = g.perm + (size_t)w_ens * g.n_walkers;    // this step's random split of the ensemble

@@ -94,6 +94,40 @@ MP_DEV void horner(Vd<N> &p, const Vd<N> &x, double c) {
     FORN p[i] = fma3(p[i], x[i], c);
 }
 
+// Polynomial coefficients from a small LDS table, fetched with broadcast ds_read_b128 (two coefficients per
+// instruction).  fp64 VALU operands cannot be literals on gfx950, so every coefficient written as a C++ constant costs
+// two v_mov_b32 per use site (14 % of the Newton-sweep loop).  Measured (tools/ab_run.sh): the table wins 2.6 % where
+// two waves share a SIMD (the 2-steps-per-lane kernels: the other wave covers the LDS latency) and loses 1.5 % with one
+// wave per SIMD (4 steps per lane, and the 4-wavefront kernel with 1 step per lane: +2.4 %), so it is used for N == 2 only.  Layout: [k] = 1/(16-k)! for k = 0..13 (1/16! .. 1/3!), then
+// log2(e), -ln2_hi, -ln2_lo, pad.  Filled by ktab_init() at kernel entry.
+typedef double d2v __attribute__((ext_vector_type(2)));
+template <int N>
+constexpr bool kUseKtab = N == 2;
+constexpr int kKtabN = 18;
+__shared__ __attribute__((aligned(16))) double g_ktab[kKtabN];
+
+__constant__ double kKtabInit[kKtabN] = {
+    1.0 / 20922789888000.0, 1.0 / 1307674368000.0, 1.0 / 87178291200.0, 1.0 / 6227020800.0, 1.0 / 479001600.0,
+    1.0 / 39916800.0, 1.0 / 3628800.0, 1.0 / 362880.0, 1.0 / 40320.0, 1.0 / 5040.0, 1.0 / 720.0, 1.0 / 120.0,
+    1.0 / 24.0, 1.0 / 6.0, 1.4426950408889634074, -6.93147180369123816490e-01, -1.90821492927058770002e-10, 0.0};
+
+MP_DEV void ktab_init() {   // every thread of the workgroup calls this once, before any table read
+    if (threadIdx.x < kKtabN) g_ktab[threadIdx.x] = kKtabInit[threadIdx.x];
+    __syncthreads();
+}
+
+MP_DEV d2v ktab2(int k) {   // entries k, k+1 (k even); volatile: stays where it is written, inside the loops
+    return *(volatile const __attribute__((address_space(3))) d2v *)&g_ktab[k];   // LDS pointer type: ds_read_b128, not flat
+}
+
+// p <- (p*x + c[k])*x + c[k+1] on all N chains
+template <int N>
+MP_DEV void horner2(Vd<N> &p, const Vd<N> &x, int k) {
+    const d2v c = ktab2(k);
+    FORN p[i] = fma3(p[i], x[i], c.x);
+    FORN p[i] = fma3(p[i], x[i], c.y);
+}
+
 // Hand-rolled for this kernel's argument ranges (positive, normal, far from overflow): hardware
 // seed (v_rcp_f64 / v_rsq_f64, ~2^-23) + two Newton steps, without the scaling / fix-up code the
 // general-purpose library versions carry.  All are accurate to ~1-2 ulp.
@@ -126,19 +160,34 @@ MP_DEV Vd<N> rsqrt_fast(const Vd<N> &x) {
 template <int N>
 MP_DEV Vd<N> exp_fast(const Vd<N> &x) {
     Vd<N> k, r, p;
-    FORN k[i] = __builtin_rint(x[i] * 1.4426950408889634074);
-    FORN r[i] = fma(k[i], -6.93147180369123816490e-01, x[i]);
-    FORN r[i] = fma(k[i], -1.90821492927058770002e-10, r[i]);
-    FORN p[i] = 1.0 / 479001600.0;               // Taylor degree 12 on |r| <= ln2/2: 1.7e-16
-    horner(p, r, 1.0 / 39916800.0);
-    horner(p, r, 1.0 / 3628800.0);
-    horner(p, r, 1.0 / 362880.0);
-    horner(p, r, 1.0 / 40320.0);
-    horner(p, r, 1.0 / 5040.0);
-    horner(p, r, 1.0 / 720.0);
-    horner(p, r, 1.0 / 120.0);
-    horner(p, r, 1.0 / 24.0);
-    horner(p, r, 1.0 / 6.0);
+    if constexpr (kUseKtab<N>) {
+        const d2v la = ktab2(14), lb = ktab2(16);    // log2(e), -ln2_hi | -ln2_lo, pad
+        FORN k[i] = __builtin_rint(x[i] * la.x);
+        FORN r[i] = fma(k[i], la.y, x[i]);
+        FORN r[i] = fma(k[i], lb.x, r[i]);
+        {
+            const d2v c = ktab2(4);                  // Taylor degree 12 on |r| <= ln2/2: 1.7e-16
+            FORN p[i] = fma3(r[i], c.x, c.y);        // r/12! + 1/11!
+        }
+        horner2(p, r, 6);                            // 1/10!, 1/9!
+        horner2(p, r, 8);                            // 1/8!, 1/7!
+        horner2(p, r, 10);                           // 1/6!, 1/5!
+        horner2(p, r, 12);                           // 1/4!, 1/3!
+    } else {
+        FORN k[i] = __builtin_rint(x[i] * 1.4426950408889634074);
+        FORN r[i] = fma(k[i], -6.93147180369123816490e-01, x[i]);
+        FORN r[i] = fma(k[i], -1.90821492927058770002e-10, r[i]);
+        FORN p[i] = 1.0 / 479001600.0;               // Taylor degree 12 on |r| <= ln2/2: 1.7e-16
+        horner(p, r, 1.0 / 39916800.0);
+        horner(p, r, 1.0 / 3628800.0);
+        horner(p, r, 1.0 / 362880.0);
+        horner(p, r, 1.0 / 40320.0);
+        horner(p, r, 1.0 / 5040.0);
+        horner(p, r, 1.0 / 720.0);
+        horner(p, r, 1.0 / 120.0);
+        horner(p, r, 1.0 / 24.0);
+        horner(p, r, 1.0 / 6.0);
+    }
     horner(p, r, 0.5);
     horner(p, r, 1.0);
     horner(p, r, 1.0);
@@ -196,7 +245,33 @@ MP_DEV Phi<N> phi1234(const Vd<N> &z) {
     Vd<N> s;
     bool all_tiny = true;
     FORN all_tiny = all_tiny && fabs(z[i]) < 0.03125;
-    if (__all(all_tiny)) {
+    double inv6 = 1.0 / 6.0;
+    if constexpr (kUseKtab<N>) {
+        if (__all(all_tiny)) {
+            {
+                const d2v c = ktab2(6);
+                FORN s[i] = fma3(z[i], c.x, c.y);     // z/10! + 1/9!
+            }
+            horner2(s, z, 8);                         // 1/8!, 1/7!
+            horner2(s, z, 10);                        // 1/6!, 1/5!
+            const d2v c = ktab2(12);
+            FORN s[i] = fma3(s[i], z[i], c.x);        // 1/4!
+            inv6 = c.y;
+        } else {
+            {
+                const d2v c = ktab2(0);
+                FORN s[i] = fma3(z[i], c.x, c.y);     // z/16! + 1/15!
+            }
+            horner2(s, z, 2);
+            horner2(s, z, 4);
+            horner2(s, z, 6);
+            horner2(s, z, 8);
+            horner2(s, z, 10);
+            const d2v c = ktab2(12);
+            FORN s[i] = fma3(s[i], z[i], c.x);        // 1/4!
+            inv6 = c.y;
+        }
+    } else if (__all(all_tiny)) {
         FORN s[i] = 1.0 / 3628800.0;              // 1/10!
         horner(s, z, 1.0 / 362880.0);             // 1/9!
         horner(s, z, 1.0 / 40320.0);              // 1/8!
@@ -221,7 +296,7 @@ MP_DEV Phi<N> phi1234(const Vd<N> &z) {
     }
     Phi<N> r;
     r.p4 = s;
-    FORN r.p3[i] = fma(z[i], s[i], 1.0 / 6.0);
+    FORN r.p3[i] = fma(z[i], s[i], inv6);
     FORN r.p2[i] = fma(z[i], r.p3[i], 0.5);
     FORN r.p1[i] = fma(z[i], r.p2[i], 1.0);
     FORN r.e[i] = fma(z[i], r.p1[i], 1.0);
@@ -238,7 +313,7 @@ MP_DEV Phi<N> phi1234(const Vd<N> &z) {
             const double c1 = (ce[i] - 1.0) * rz[i];
             const double c2 = (c1 - 1.0) * rz[i];
             const double c3 = (c2 - 0.5) * rz[i];
-            const double c4 = (c3 - 1.0 / 6.0) * rz[i];
+            const double c4 = (c3 - inv6) * rz[i];
             r.e[i] = big[i] ? ce[i] : r.e[i];
             r.p1[i] = big[i] ? c1 : r.p1[i];
             r.p2[i] = big[i] ? c2 : r.p2[i];
