@@ -13,13 +13,16 @@
 //      ONCE per sweep at its current guess of omega at its step ends, fetches (omega_dot, omega) of the three
 //      previous grid points, and forms the step maps omega_{j+1} = e^{h lambda} omega_j + h sum_m phi_{m+1}(h lambda) g_m.
 //      A second affine scan propagates the tile's start value through all linearised maps.  This Newton-type sweep
-//      converges quadratically (about 2 sweeps from an extrapolated guess), terminates in any case after at most
-//      tile-length sweeps, and reproduces the serial recurrence to rounding.
-//   3. Each lane evaluates the luminosity at its step ends (reference luminosity stage,
-//      code/synthetic_datasets/funcs.py:175-229, magnetar/funcs.py:157-210); the tile's light curve is staged in LDS,
-//      the observations that fall in the tile are interpolated from LDS (np.interp semantics) and accumulated into
-//      per-lane chi^2 partial sums; optional coalesced stores write the model light curve to HBM.
-//   4. A wavefront reduction gives -0.5*chi^2 (code/synthetic_datasets/mcmc_eqns.py:25).
+//      contracts by 1e-2..1e-3 per pass (about 2 sweeps from an extrapolated guess, the last one being the convergence
+//      check), terminates in any case after at most tile-length sweeps, and reproduces the serial recurrence to ~1e-11.
+//   3. Observations.  np.interp needs the model only at the two grid points bracketing each observed time: when an
+//      observation falls in the tile, the tile's (Mdisc, omega) image goes to LDS and the lane that owns the
+//      observation keeps the two bracketing states (register-resident observations) or parks them in the walker's
+//      scratch rows (light curves of more than 64 points).  The luminosity (reference luminosity stage,
+//      code/synthetic_datasets/funcs.py:175-229, magnetar/funcs.py:157-210) is evaluated after the last tile, once per
+//      64 observations.  When curve outputs are requested (CURVES) it is evaluated at every step end instead, the
+//      tile's light curve is staged in LDS for the interpolation and written to HBM with coalesced stores.
+//   4. A wavefront reduction of the per-lane chi^2 terms gives -0.5*chi^2 (code/synthetic_datasets/mcmc_eqns.py:25).
 //
 // Kernels: lnprob_kernel<CURVES, SPL, LONG> (one wavefront per walker), lnprob_mw_kernel<SPL, W, LONG> (W wavefronts per
 // walker for batches that cannot fill the 1 024 SIMDs), stretch_kernel<SPL, W, LONG> (emcee's stretch move fused around
