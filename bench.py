@@ -86,6 +86,11 @@ def cpu_baseline(grb, budget_s, seed):
 
 
 def main():
+    # The contract is ONE JSON line on stdout.  Native libraries write banners there too (RCCL prints its version block
+    # on stdout when a communicator is created), so everything but the result line is sent to stderr at fd level.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -98,6 +103,10 @@ def main():
     ap.add_argument("--seed", type=int, default=20261003)
     ap.add_argument("--no-mcmc", action="store_true", help="skip the ensemble-sampler leg (N=1 only)")
     ap.add_argument("--mcmc-steps", type=int, default=100)
+    ap.add_argument("--overlap", type=int, default=1, choices=[0, 1],
+                    help="1: the all-gather of one pass overlaps the next pass's kernel (independent batches); 0: serialised")
+    ap.add_argument("--always-gather", action="store_true",
+                    help="diagnostic: run the RCCL all-gather even at N=1 (group of one) to time the collective path")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend; gloo is for rehearsing N>1 on a one-GPU box (ranks share the card, "
                          "lnprob slices are gathered through host memory) and is never a reported configuration")
@@ -149,22 +158,46 @@ def main():
     step_idx = [0]
     stream = torch.cuda.current_stream(dev)
 
-    def eval_local(p):
+    def eval_local(p, out=None):
         i = step_idx[0]
-        out = torch.empty(p.shape[0], dtype=torch.float64, device=dev)
+        if out is None:
+            out = torch.empty(p.shape[0], dtype=torch.float64, device=dev)
         ev0[i].record(stream)
         lp.handle.lnprob_batch_dev(p.data_ptr(), p.shape[0], 6, out.data_ptr(), d_status=status.data_ptr(),
                                    d_ltot=ltot.data_ptr() if ltot is not None else 0, stream=stream.cuda_stream)
         ev1[i].record(stream)
         return out
 
-    sharded = ShardedLnprob(eval_local, via_host=(a.backend == "gloo"))
+    if world == 1 and a.always_gather:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    sharded = ShardedLnprob(eval_local, via_host=(a.backend == "gloo"), writes_out=True, always_gather=a.always_gather)
     checksum = torch.zeros((), dtype=torch.float64, device=dev)
 
-    def run(i):
+    def start(i):
         step_idx[0] = i
-        p = props[i]
-        full = sharded(p if world > 1 else p)                  # shard -> kernel -> all-gather (RCCL) of lnprob
+        return sharded.start(props[i])                         # shard -> kernel -> all-gather (RCCL) of lnprob enqueued
+
+    def loop(first, last):
+        # The passes are independent batches (as the ensembles of BASELINE config 5 are): with --overlap 1 (default)
+        # the all-gather of pass i runs on RCCL's stream while the kernel of pass i+1 runs on the compute stream.
+        # --overlap 0 waits for every gather before the next kernel (what ONE ensemble's dependent half-steps see).
+        full, pending = None, None
+        for i in range(first, last):
+            t = start(i)
+            if pending is not None:
+                full = sharded.finish(pending)
+                checksum.add_(full.sum())
+                pending = None
+            if a.overlap:
+                pending = t
+            else:
+                full = sharded.finish(t)
+                checksum.add_(full.sum())
+        if pending is not None:
+            full = sharded.finish(pending)
+            checksum.add_(full.sum())
         return full
 
     def fence():
@@ -172,14 +205,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for i in range(a.warmup):
-        checksum += run(i).sum()                               # same ops as the timed loop (lazy kernel loads happen here)
+    loop(0, a.warmup)                                          # same ops as the timed loop (lazy kernel loads happen here)
     checksum.zero_()
     fence()
     t0 = time.perf_counter()
-    for i in range(a.warmup, total):
-        full = run(i)
-        checksum += full.sum()
+    full = loop(a.warmup, total)
     t_host = time.perf_counter() - t0                           # host-side enqueue time (diagnostic)
     fence()
     dt = time.perf_counter() - t0
@@ -228,7 +258,7 @@ def main():
                                    f"({n_global} walkers total), walkers at truth+1e-4*randn, 10001-point grid, "
                                    f"mode {'B (lnprob + model light curve written to HBM)' if a.curve else 'A (lnprob only)'}",
                        "n_walk_per_gpu": a.nwalk, "n_walk_total": n_global, "n_grid": 10001, "n_obs": int(x.size),
-                       "variant": "synth", "parallelism": f"walker-shard x{world} + {'RCCL' if a.backend == 'nccl' else 'gloo (rehearsal)'} all-gather(lnprob)"},
+                       "variant": "synth", "parallelism": f"walker-shard x{world} + {'RCCL' if a.backend == 'nccl' else 'gloo (rehearsal)'} all-gather(lnprob)" + (", gather of pass i overlapped with kernel of pass i+1" if (world > 1 and a.overlap) else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "mp::lnprob_kernel", "kernel_ms_avg": 1e3 * kavg, "kernel_ms_min": float(kern_ms.min()),
@@ -250,9 +280,11 @@ def main():
         if cpu is not None:
             out["cpu_baseline"] = cpu
             out["speedup_vs_cpu_baseline"] = value / cpu["value"]
-        print(json.dumps(out), flush=True)
+        json_out.write(json.dumps(out) + "\n")
+        json_out.flush()
     if world > 1:
         dist.barrier()
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

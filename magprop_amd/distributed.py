@@ -20,35 +20,67 @@ def shard_range(n, rank, world):
 class ShardedLnprob:
     """Evaluate lnprob for a full (n, ndim) proposal batch with the work split over the process group.
 
-    eval_local(pars_local) -> lnprob tensor of the local slice, on the same device.  Every rank passes
-    the same full `pars` (replicated proposals: no scatter needed) and gets the full lnprob vector.
+    eval_local(pars_local) -> lnprob tensor of the local slice, on the same device (with `writes_out=True` it is called
+    as eval_local(pars_local, out=slice_of_the_send_buffer) and writes there: no copy).  Every rank passes the same full
+    `pars` (replicated proposals: no scatter needed) and gets the full lnprob vector.
+
+    `sharded(pars)` is the blocking form.  `t = sharded.start(pars)` ... `full = sharded.finish(t)` is the pipelined
+    form: start() launches this rank's block on the current stream and enqueues the all-gather on RCCL's own stream
+    without making the compute stream wait for it, so the next independent batch's kernel overlaps the collective
+    (two batches in flight, double-buffered; the tensor returned by finish() stays valid until the second start() after
+    it).  Dependent batches (the two half-steps of one stretch move) have nothing to overlap and use the blocking form.
     """
 
-    def __init__(self, eval_local, group=None, via_host=False):
+    def __init__(self, eval_local, group=None, via_host=False, writes_out=False, always_gather=False):
         self.eval_local = eval_local
         self.group = group
         self.via_host = via_host      # gather through host memory (gloo rehearsal of the multi-GPU path)
+        self.writes_out = writes_out
+        self.always_gather = always_gather   # run the collective even in a group of one (exercises RCCL on a 1-GPU box)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        self._buf = None
+        self._slots = [None, None]    # per slot: (key, send buffer [per], receive buffer [per * world])
+        self._k = 0
 
-    def __call__(self, pars):
+    def _buffers(self, n, per, device):
+        k = self._k
+        self._k ^= 1
+        key = (n, per, str(device))
+        slot = self._slots[k]
+        if slot is None or slot[0] != key:
+            local = torch.full((per,), float("-inf"), dtype=torch.float64, device=device)   # a short tail block stays -inf
+            slot = (key, local, torch.empty(per * self.world, dtype=torch.float64, device=device))
+            self._slots[k] = slot
+        return slot[1], slot[2]
+
+    def start(self, pars):
         n = pars.shape[0]
+        if self.world == 1 and not self.always_gather:
+            return None, self.eval_local(pars), n
         lo, hi, per = shard_range(n, self.rank, self.world)
-        if self.world == 1:
-            return self.eval_local(pars)
-        local = torch.full((per,), float("-inf"), dtype=torch.float64, device=pars.device)
+        local, buf = self._buffers(n, per, pars.device)
         if hi > lo:
-            local[: hi - lo] = self.eval_local(pars[lo:hi])
-        if self._buf is None or self._buf.numel() != per * self.world or self._buf.device != pars.device:
-            self._buf = torch.empty(per * self.world, dtype=torch.float64, device=pars.device)
+            if self.writes_out:
+                self.eval_local(pars[lo:hi], out=local[: hi - lo])
+            else:
+                local[: hi - lo] = self.eval_local(pars[lo:hi])
         if self.via_host:
             hbuf = torch.empty(per * self.world, dtype=torch.float64)
             dist.all_gather_into_tensor(hbuf, local.cpu(), group=self.group)
-            self._buf.copy_(hbuf)
-        else:
-            dist.all_gather_into_tensor(self._buf, local, group=self.group)
-        return self._buf[:n]
+            buf.copy_(hbuf)
+            return None, buf, n
+        work = dist.all_gather_into_tensor(buf, local, group=self.group, async_op=True)
+        return work, buf, n
+
+    @staticmethod
+    def finish(ticket):
+        work, buf, n = ticket
+        if work is not None:
+            work.wait()               # the current stream waits for the collective; the host does not
+        return buf[:n]
+
+    def __call__(self, pars):
+        return self.finish(self.start(pars))
 
 
 class DistributedStretchSampler:

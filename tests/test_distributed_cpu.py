@@ -39,8 +39,23 @@ def _worker(rank, world, port, n, q):
         calls.append(p.shape[0])
         return _fake_lnprob(p)
 
-    full = ShardedLnprob(eval_local)(pars)
-    q.put((rank, full.numpy().copy(), calls))
+    sh = ShardedLnprob(eval_local)
+    full = sh(pars).clone()
+    # pipelined form: three independent batches, two in flight, results identical to the blocking form
+    batches = [pars, pars * 0.5, pars + 1.0]
+    tickets, outs = [], []
+    for b in batches:
+        tickets.append(sh.start(b))
+        if len(tickets) == 2:
+            outs.append(sh.finish(tickets.pop(0)).clone())
+    outs.append(sh.finish(tickets.pop(0)).clone())
+    for b, o in zip(batches, outs):
+        assert torch.equal(o, _fake_lnprob(b)), rank
+    # eval_local writing straight into the send buffer
+    def eval_out(p, out):
+        out.copy_(_fake_lnprob(p))
+    assert torch.equal(ShardedLnprob(eval_out, writes_out=True)(pars), full)
+    q.put((rank, full.numpy().copy(), calls[:1]))
     dist.barrier()
     dist.destroy_process_group()
 

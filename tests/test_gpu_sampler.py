@@ -186,3 +186,39 @@ def test_sharded_stretch_sampler_on_device(gsynth):
     assert np.array_equal(lp(c[-1]), l[-1])            # stored values are the kernel's values at the stored positions
     assert 0.15 < float(s.acceptance_fraction.mean()) < 0.8
     assert np.std(c[-1][:, 0]) > 1e-4
+
+
+def test_sharded_lnprob_pipelined_over_rccl(gsynth):
+    """ShardedLnprob.start/finish with the real collective (RCCL, a process group of one on this 1-GPU box): the
+    asynchronous all_gather_into_tensor of batch i overlaps the kernel of batch i+1; results equal the direct call."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from magprop_amd import LogProb
+    from magprop_amd.distributed import ShardedLnprob
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29800 + os.getpid() % 100))
+    x, y, yerr = gsynth["Humped_x"], gsynth["Humped_y"], gsynth["Humped_yerr"]
+    lp = LogProb(x, y, yerr, device=0)
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        sh = ShardedLnprob(lambda p, out: lp.lnprob_device(p, out=out), writes_out=True, always_gather=True)
+        gen = torch.Generator(device=dev).manual_seed(3)
+        truth = torch.tensor(TRUTHS["Humped"], dtype=torch.float64, device=dev)
+        batches = [truth + 1.0e-3 * torch.randn(1024, 6, dtype=torch.float64, device=dev, generator=gen) for _ in range(5)]
+        want = [lp.lnprob_device(b).clone() for b in batches]
+        got, pending = [], None
+        for b in batches:
+            t = sh.start(b)
+            if pending is not None:
+                got.append(sh.finish(pending).clone())
+            pending = t
+        got.append(sh.finish(pending).clone())
+        torch.cuda.synchronize()
+        for w, g_ in zip(want, got):
+            assert torch.equal(w, g_)
+        assert torch.equal(sh(batches[0]), want[0])              # blocking form
+    finally:
+        dist.destroy_process_group()
