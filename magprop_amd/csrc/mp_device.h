@@ -41,7 +41,7 @@ struct DevShared {
     // bracketing observation j >= 64 in column j - 64 (written tile by tile, read by the luminosity stage)
     double *obs_scratch;
     int32_t scratch_stride;   // max over datasets of (n_obs - 64), rounded up to 64; 0 = no long light curve
-    int32_t pad2;
+    int32_t force_pc;         // experiments: 1 = producer/consumer two-wavefront kernel, -1 = never, 0 = automatic
     // prior
     double lower[MP_MAX_NDIM];
     double upper[MP_MAX_NDIM];
@@ -103,6 +103,9 @@ struct StretchArgs {
 inline int kernel_spl(int n) { return n <= 1024 ? 4 : 2; }   // 1 024 SIMDs: beyond one wave each, two resident waves win (tools/spl_scan.sh)
 // Wavefronts that cooperate on one walker: small batches cannot give every SIMD (256 CUs x 4) a walker of its own.
 inline int waves_per_walker(int n) { return n <= 256 ? 4 : 1; }
+
+// Producer/consumer pair of wavefronts per walker: pays when every wavefront still gets a SIMD of its own.
+inline bool two_wave_pair(int n) { return n > 256 && n <= 512; }
 
 // implemented in mp_kernels.hip; returns hipError_t as int
 int launch_lnprob(const DevShared &sh, const LaunchArgs &a, void *stream);

@@ -33,11 +33,19 @@ struct DiscPt {
     Vd<N> qu;    // rmu^1.5/sqrt(GM): uncapped fastness = omega*qu
 };
 
+// (Mdisc/tvisc)^(-1/7): the one expensive ingredient of disc_point (the producer wavefront of the two-wavefront
+// kernel computes it and hands it over together with Mdisc)
 template <int N>
-MP_DEV DiscPt<N> disc_point(const DevShared &sh, const Walker &w, const Vd<N> &Mdisc) {
+MP_DEV Vd<N> disc_power(const Walker &w, const Vd<N> &Mdisc) {
+    Vd<N> mdot;
+    FORN mdot[i] = Mdisc[i] * w.inv_tau;
+    return pow_m1_7_fast(mdot);                                     // mdot^(-1/7)
+}
+
+template <int N>
+MP_DEV DiscPt<N> disc_from_power(const Walker &w, const Vd<N> &Mdisc, const Vd<N> &t) {
     DiscPt<N> p;
     FORN p.mdot[i] = Mdisc[i] * w.inv_tau;
-    const Vd<N> t = pow_m1_7_fast(p.mdot);                          // mdot^(-1/7)
     FORN {
         const double t2 = t[i] * t[i];
         p.rmu[i] = w.Crm * t2;                                      // Crm * mdot^(-2/7)
@@ -45,6 +53,11 @@ MP_DEV DiscPt<N> disc_point(const DevShared &sh, const Walker &w, const Vd<N> &M
         p.qu[i] = w.Crm15 * (t2 * t[i]);                            // rmu^1.5 / sqrt(GM)
     }
     return p;
+}
+
+template <int N>
+MP_DEV DiscPt<N> disc_point(const DevShared &sh, const Walker &w, const Vd<N> &Mdisc) {
+    return disc_from_power(w, Mdisc, disc_power(w, Mdisc));
 }
 
 // fallback accretion rate Mdotfb(t), code/synthetic_datasets/funcs.py:128
@@ -198,6 +211,126 @@ MP_DEV int walker_setup(const DevShared &sh, const LaunchArgs &a, double (&par)[
     return status;
 }
 
+// ---------------------------------------------------------------- producer / consumer pair of wavefronts
+// About half of a walker's work does not depend on omega: the Mdisc recurrence and the powers of Mdisc/tvisc the
+// omega equation reads.  The two-wavefront kernel gives that half to a PRODUCER wavefront, which runs ahead tile by tile
+// and hands (Mdisc, (Mdisc/tvisc)^(-1/7)) at every step end to the CONSUMER wavefront (predictor, Newton sweeps,
+// observations) through a two-slot LDS ring.  No barriers: two counters in LDS (tiles produced / tiles consumed) with
+// workgroup-scope release/acquire; the consumer raises `abort` when it stops early.  The arithmetic is that of the
+// one-wavefront kernel, instruction for instruction, so the results are bit-identical.
+template <int SPL>
+struct PcRing {
+    static constexpr int R = 2;
+    double M[R][SPL][64];      // Mdisc at step end lane*SPL + s of the tile in slot r: [r][s][lane] (conflict-free)
+    double T[R][SPL][64];      // (Mdisc/tvisc)^(-1/7) there
+    int produced;              // tiles published by the producer
+    int consumed;              // tiles taken over by the consumer
+    int abort;                 // consumer -> producer: stop
+};
+
+constexpr int kSpinLimit = 1 << 20;   // x s_sleep(2): far beyond any legitimate wait; a hang becomes a failed walker
+
+MP_DEV int ring_load(const int *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+MP_DEV void ring_store(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+// wait until *counter >= need; false if the partner raised abort or never came
+MP_DEV bool ring_wait(const int *counter, int need, const int *abort) {
+    for (int spin = 0; spin < kSpinLimit; ++spin) {
+        if (ring_load(counter) >= need) return true;
+        if (ring_load(abort)) return false;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    return false;
+}
+
+// orders this wavefront's own LDS writes before its later LDS reads (all 64 lanes run in lockstep)
+MP_DEV void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// The producer wavefront: the Mdisc phase of walker_eval (same statements), tile after tile.
+template <int SPL>
+MP_DEV void walker_produce(const DevShared &sh, const LaunchArgs &a, double (&par)[MP_MAX_NDIM], PcRing<SPL> &ring) {
+    constexpr int kSPL = SPL, kTile = 64 * SPL, R = PcRing<SPL>::R;
+    const int n_tiles = (sh.n_grid - 1 + kTile - 1) / kTile;
+    const int lane = threadIdx.x & 63;
+    const int nsteps = sh.n_grid - 1;
+    Walker w;
+    (void)walker_setup(sh, a, par, w);
+    const double t0 = sh.tgrid[0];
+    double t_s = t0;
+    double M_s = par[2] * kMsol;
+    double cS0, cS1, cS2;
+    {
+        const Vd<3> tg{{t0, t0 * sh.inv_q, t0 * sh.inv_q * sh.inv_q}};
+        const Vd<3> Sg = mdot_fb(w, tg);
+        cS0 = Sg[0]; cS1 = Sg[1]; cS2 = Sg[2];
+    }
+    double tb_next[kSPL];
+#pragma unroll
+    for (int s = 0; s < kSPL; ++s) tb_next[s] = sh.tgrid[min(lane * kSPL + s + 1, nsteps)];
+    for (int tile = 0; tile < n_tiles; ++tile) {
+        const int i0 = tile * kTile + lane * kSPL;
+        Vd<kSPL> tb, h;
+#pragma unroll
+        for (int s = 0; s < kSPL; ++s) {
+            tb[s] = tb_next[s];
+            tb_next[s] = sh.tgrid[min(i0 + kTile + s + 1, nsteps)];
+        }
+        {
+            const double ta0 = lane_prev(tb[kSPL - 1], t_s);
+#pragma unroll
+            for (int s = 0; s < kSPL; ++s) h[s] = tb[s] - (s == 0 ? ta0 : tb[s - 1]);
+        }
+        Vd<kSPL> M1;
+        double ES[kSPL + 3];
+        {
+            const Vd<kSPL> S1 = mdot_fb(w, tb);
+#pragma unroll
+            for (int s = 0; s < kSPL; ++s) ES[3 + s] = S1[s];
+            ES[2] = lane_prev(ES[kSPL + 2], cS0);
+            ES[1] = lane_prev(ES[kSPL + 1], cS1);
+            ES[0] = lane_prev(ES[kSPL + 0], cS2);
+            Vd<kSPL> zm, v0, v1, v2, v3;
+#pragma unroll
+            for (int s = 0; s < kSPL; ++s) {
+                zm[s] = -h[s] * w.inv_tau;
+                v0[s] = ES[3 + s]; v1[s] = ES[2 + s]; v2[s] = ES[1 + s]; v3[s] = ES[s];
+            }
+            const Phi<kSPL> pm = phi1234(zm);
+            const Vd<kSPL> inc = eam4_increment(sh, pm, h, v0, v1, v2, v3);
+            Vd<kSPL> am, bm;
+            double A = 1.0, B = 0.0;
+#pragma unroll
+            for (int s = 0; s < kSPL; ++s) {
+                am[s] = pm.e[s];
+                bm[s] = inc[s];
+                B = fma(am[s], B, bm[s]);
+                A = A * am[s];
+            }
+            scan_affine(A, B);
+            const double Ax = lane_prev(A, 1.0), Bx = lane_prev(B, 0.0);
+            double Mc = fma(Ax, M_s, Bx);
+#pragma unroll
+            for (int s = 0; s < kSPL; ++s) { Mc = fma(am[s], Mc, bm[s]); M1[s] = Mc; }
+        }
+        const Vd<kSPL> tp = disc_power(w, M1);
+        // publish: the slot must have been taken over by the consumer first
+        if (tile >= R && !ring_wait(&ring.consumed, tile - R + 1, &ring.abort)) return;
+        if (ring_load(&ring.abort)) return;
+        const int slot = tile % R;
+#pragma unroll
+        for (int s = 0; s < kSPL; ++s) { ring.M[slot][s][lane] = M1[s]; ring.T[slot][s][lane] = tp[s]; }
+        ring_store(&ring.produced, tile + 1);            // release: the slot's contents are visible before the counter
+        if (tile + 1 < n_tiles) {
+            constexpr int e1 = kTile - 2, e2 = kTile - 3;
+            cS0 = lane_bcast(ES[3 + kSPL - 1], 63);
+            cS1 = lane_bcast(ES[3 + e1 % kSPL], e1 / kSPL);
+            cS2 = lane_bcast(ES[3 + e2 % kSPL], e2 / kSPL);
+            t_s = lane_bcast(tb[kSPL - 1], 63);
+            M_s = lane_bcast(M1[kSPL - 1], 63);
+        }
+    }
+}
+
 constexpr int kMaxSweepsMargin = 16;  // sweeps allowed beyond the tile length (after which every step is exact)
 
 // ---------------------------------------------------------------- the kernel
@@ -205,9 +338,11 @@ constexpr int kMaxSweepsMargin = 16;  // sweeps allowed beyond the tile length (
 // SPL = consecutive steps owned by one lane; a tile is 64*SPL steps.  par[] holds the sampler coordinates
 // (prior checked and log-masked coordinates un-logged here unless a.physical); walker indexes ds_id and the
 // optional curve outputs; Lbuf is the wave's LDS staging area [2*(64*SPL + 1)].
-template <bool CURVES, int SPL, bool LONG>
+// ROLE 0: the whole evaluation on this wavefront.  ROLE 1: consumer of a PcRing (the Mdisc phase runs on the partner
+// wavefront, walker_produce); the wavefront must then be the only user of Lbuf and must not meet workgroup barriers.
+template <bool CURVES, int SPL, bool LONG, int ROLE = 0>
 MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, double (&par)[MP_MAX_NDIM], double *Lbuf,
-                        double &lnp_out, int &status_out, int &sweeps_out) {
+                        double &lnp_out, int &status_out, int &sweeps_out, PcRing<SPL> *ring = nullptr) {
     constexpr int kSPL = SPL, kTile = 64 * SPL, kMaxSweeps = kTile + kMaxSweepsMargin;
     const int n_tiles = (sh.n_grid - 1 + kTile - 1) / kTile;
     const int lane = threadIdx.x & 63;
@@ -308,7 +443,20 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
             // E*[k]: values at the three grid points before this lane's first step (k = 0,1,2) and at its step ends (k = 3+s).
             Vd<kSPL> M1;
             double ES[kSPL + 3];
-            {
+            DiscPt<kSPL> d1;
+            if constexpr (ROLE == 1) {
+                // the partner wavefront has done this phase: take the tile over from the ring
+                if (!ring_wait(&ring->produced, tile + 1, &ring->abort)) { status = MP_STATUS_NONFINITE; break; }
+                const int slot = tile % PcRing<SPL>::R;
+                Vd<kSPL> tp;
+#pragma unroll
+                for (int s = 0; s < kSPL; ++s) { M1[s] = ring->M[slot][s][lane]; tp[s] = ring->T[slot][s][lane]; }
+                wave_lds_fence();                                 // the values are in registers ...
+                ring_store(&ring->consumed, tile + 1);            // ... before the slot is handed back
+                d1 = disc_from_power(w, M1, tp);
+#pragma unroll
+                for (int s = 0; s < kSPL + 3; ++s) ES[s] = 0.0;
+            } else {
                 const Vd<kSPL> S1 = mdot_fb(w, tb);
 #pragma unroll
                 for (int s = 0; s < kSPL; ++s) ES[3 + s] = S1[s];
@@ -337,8 +485,8 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 double Mc = fma(Ax, M_s, Bx);            // Mdisc at this lane's first step start
 #pragma unroll
                 for (int s = 0; s < kSPL; ++s) { Mc = fma(am[s], Mc, bm[s]); M1[s] = Mc; }
+                d1 = disc_point(sh, w, M1);
             }
-            const DiscPt<kSPL> d1 = disc_point(sh, w, M1);
 
             // ---------------- omega: predictor = extrapolation of the last five grid values in the step index
             // (the grid is logarithmic, so power laws are smooth in the index) ...
@@ -466,7 +614,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
 #pragma unroll
                     for (int s = 0; s < kSPL; ++s) { Mbuf[lane * kSPL + s + 1] = M1[s]; Wbuf[lane * kSPL + s + 1] = wg[s]; }
                     if (lane == 0) { Mbuf[0] = M_s; Wbuf[0] = om_s; }
-                    __syncthreads();
+                    if constexpr (ROLE == 1) wave_lds_fence(); else __syncthreads();
                     if (mine) {
                         const int g = ob_g - tile * kTile;
                         obM[0] = Mbuf[g]; obM[1] = Mbuf[g + 1];
@@ -478,7 +626,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                         p[0] = Mbuf[g]; p[sc_stride] = Mbuf[g + 1];
                         p[2 * sc_stride] = Wbuf[g]; p[3 * sc_stride] = Wbuf[g + 1];
                     }
-                    __syncthreads();
+                    if constexpr (ROLE == 1) wave_lds_fence(); else __syncthreads();
                 }
             } else {   // curve outputs requested: the whole light curve is formed anyway
                 int j0 = 0, j1 = 0;
@@ -559,7 +707,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 chi = res * res;
             }
             if (long_lc) {
-                __syncthreads();   // scratch rows written by other lanes
+                if constexpr (ROLE == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else __syncthreads();   // scratch rows written by other lanes
                 for (int jb = 64; jb < dsd.n_obs; jb += 64) {
                     const bool valid = jb + lane < dsd.n_obs;
                     const int j = valid ? jb + lane : dsd.n_obs - 1;
@@ -576,6 +724,8 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
             }
         }
     }
+
+    if constexpr (ROLE == 1) ring_store(&ring->abort, 1);   // done (or failed): release the producer
 
     double lnp = -INFINITY;
     if (status == MP_STATUS_OK) {

@@ -59,6 +59,33 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, SPL >= 4 
     }
 }
 
+// Two wavefronts per walker, producer (Mdisc phase) and consumer (omega, observations): mp_eval.hpp, PcRing.
+template <int SPL, bool LONG>
+__global__ __launch_bounds__(128) void lnprob_pc_kernel(const DevShared sh, const LaunchArgs a) {
+    __shared__ double Lbuf[2 * (64 * SPL + 1)];
+    __shared__ PcRing<SPL> ring;
+    ktab_init();
+    const int walker = blockIdx.x;
+    double par[MP_MAX_NDIM];
+    const double *pw = a.pars + (size_t)walker * a.ndim;
+#pragma unroll
+    for (int i = 0; i < MP_MAX_NDIM; ++i) par[i] = i < a.ndim ? pw[i] : 0.0;
+    if (threadIdx.x == 0) { ring.produced = 0; ring.consumed = 0; ring.abort = 0; }
+    __syncthreads();
+    if (threadIdx.x >= 64) {
+        walker_produce<SPL>(sh, a, par, ring);
+        return;
+    }
+    double lnp;
+    int status, sweeps;
+    walker_eval<false, SPL, LONG, 1>(sh, a, walker, par, Lbuf, lnp, status, sweeps, &ring);
+    if (threadIdx.x == 0) {
+        a.lnprob[walker] = lnp;
+        if (a.status) a.status[walker] = status;
+        if (a.sweeps) a.sweeps[walker] = sweeps;
+    }
+}
+
 template <int SPL, int W, bool LONG>
 __global__ __launch_bounds__(64 * W) void lnprob_mw_kernel(const DevShared sh, const LaunchArgs a) {
     __shared__ MwLds<SPL, W> lds;
@@ -116,9 +143,12 @@ MP_DEV double u01(uint32_t hi, uint32_t lo) {   // 53-bit uniform in [0, 1)
 // proposal (emcee's StretchMove.get_proposal), evaluate its log-posterior with walker_eval, accept or
 // reject against the walker's current value, update position / lnprob / counters in place and write the
 // step's row of the chain.  Walkers of the complementary half are only read, so the update is race-free.
-template <int SPL, int W, bool LONG>
-__global__ __launch_bounds__(64 * W) void stretch_kernel(const DevShared sh, const StretchArgs g) {
+// PC: producer/consumer pair of wavefronts (W = 1, 128 threads), see lnprob_pc_kernel.
+struct NoRing {};
+template <int SPL, int W, bool LONG, bool PC = false>
+__global__ __launch_bounds__(PC ? 128 : 64 * W) void stretch_kernel(const DevShared sh, const StretchArgs g) {
     __shared__ typename std::conditional<(W > 1), MwLds<SPL, W>, double[2 * (64 * SPL + 1)]>::type lds;
+    __shared__ typename std::conditional<PC, PcRing<SPL>, NoRing>::type ring;
     ktab_init();
     const int w_ens = blockIdx.x / g.n_half;                       // which ensemble
     const int slot = blockIdx.x - w_ens * g.n_half;                // which walker of the active half
@@ -149,6 +179,16 @@ __global__ __launch_bounds__(64 * W) void stretch_kernel(const DevShared sh, con
     a.ndim = g.ndim;
     a.physical = 0;
     a.want_chi2 = 1;
+    if constexpr (PC) {
+        // both wavefronts hold the same proposal; the barrier also keeps the producer's reads of pos[] ahead of the
+        // consumer's update of it at the very end
+        if (threadIdx.x == 0) { ring.produced = 0; ring.consumed = 0; ring.abort = 0; }
+        __syncthreads();
+        if (threadIdx.x >= 64) {
+            if (g.target != 1) walker_produce<SPL>(sh, a, par, ring);
+            return;
+        }
+    }
     double lnp;
     int status, sweeps;
     if (g.target == 1) {   // isotropic unit Gaussian: exercises the move itself (tests)
@@ -158,6 +198,7 @@ __global__ __launch_bounds__(64 * W) void stretch_kernel(const DevShared sh, con
         status = MP_STATUS_OK;
     } else {
         if constexpr (W > 1) walker_eval_mw<SPL, W, LONG>(sh, a, k, par, lds, lnp, status, sweeps);
+        else if constexpr (PC) walker_eval<false, SPL, LONG, 1>(sh, a, k, par, lds, lnp, status, sweeps, &ring);
         else walker_eval<false, SPL, LONG>(sh, a, k, par, lds, lnp, status, sweeps);
     }
     if (threadIdx.x == 0) {
@@ -183,6 +224,8 @@ int launch_lnprob(const DevShared &sh, const LaunchArgs &a, void *stream) {
     dim3 grid((unsigned)a.n), block(64);
     // Variants (results agree to rounding):
     //  - batches that leave most SIMDs idle (256 CUs x 4 SIMDs; n <= 256) put 4 wavefronts on every walker;
+    //  - 257..512 walkers: a producer/consumer pair of wavefronts per walker (the omega-independent Mdisc phase runs
+    //    ahead on the second wavefront; bit-identical to the one-wavefront kernel, 17 % sooner);
     //  - up to 1024 walkers (one wave per SIMD): one wavefront per walker, four steps per lane (256-step tiles
     //    amortise the wavefront scans best; needs the whole register file of a SIMD);
     //  - beyond: two steps per lane, which keeps two waves resident per SIMD (they fill each other's issue gaps).
@@ -191,7 +234,12 @@ int launch_lnprob(const DevShared &sh, const LaunchArgs &a, void *stream) {
     const bool lng = sh.scratch_stride > 0;
     hipStream_t st = (hipStream_t)stream;
     const int wpw = curves ? 1 : (sh.force_wpw ? sh.force_wpw : waves_per_walker(a.n));
-    if (wpw == 4) {
+    const bool pc = !curves && sh.force_pc >= 0 && !sh.force_wpw && !sh.force_spl &&
+                    (sh.force_pc == 1 || two_wave_pair(a.n));
+    if (pc) {
+        if (lng) hipLaunchKernelGGL((lnprob_pc_kernel<4, true>), grid, dim3(128), 0, st, sh, a);
+        else hipLaunchKernelGGL((lnprob_pc_kernel<4, false>), grid, dim3(128), 0, st, sh, a);
+    } else if (wpw == 4) {
         if (lng) hipLaunchKernelGGL((lnprob_mw_kernel<1, 4, true>), grid, dim3(256), 0, st, sh, a);
         else hipLaunchKernelGGL((lnprob_mw_kernel<1, 4, false>), grid, dim3(256), 0, st, sh, a);
     } else if (wpw == 2) {
@@ -216,7 +264,12 @@ int launch_stretch(const DevShared &sh, const StretchArgs &g, void *stream) {
     dim3 grid((unsigned)n_blocks);
     const int wpw = g.target == 1 ? 1 : (sh.force_wpw ? sh.force_wpw : waves_per_walker(n_blocks));
     const bool lng = sh.scratch_stride > 0;
-    if (wpw == 4) {
+    const bool pc = g.target != 1 && sh.force_pc >= 0 && !sh.force_wpw && !sh.force_spl &&
+                    (sh.force_pc == 1 || two_wave_pair(n_blocks));
+    if (pc) {
+        if (lng) hipLaunchKernelGGL((stretch_kernel<4, 1, true, true>), grid, dim3(128), 0, st, sh, g);
+        else hipLaunchKernelGGL((stretch_kernel<4, 1, false, true>), grid, dim3(128), 0, st, sh, g);
+    } else if (wpw == 4) {
         if (lng) hipLaunchKernelGGL((stretch_kernel<1, 4, true>), grid, dim3(256), 0, st, sh, g);
         else hipLaunchKernelGGL((stretch_kernel<1, 4, false>), grid, dim3(256), 0, st, sh, g);
     } else if (wpw == 2) {

@@ -16,7 +16,8 @@ GPU_VS_C_RTOL = 1e-10   # HIP kernel vs serial C oracle: same scheme, different 
 
 def kernel_variant(n):
     """(wavefronts per walker, steps per lane) the library picks for a batch of n (mp_device.h): batches of different
-    variants agree to rounding, batches of the same variant bit for bit."""
+    variants agree to rounding, batches of the same variant bit for bit.  257..512 walkers run the producer/consumer
+    pair of wavefronts, which executes the statements of the (1, 4) kernel and is bit-identical to it."""
     return (4, 1) if n <= 256 else (1, 4) if n <= 1024 else (1, 2)
 LOG_MASK = 0b111100
 
@@ -290,11 +291,11 @@ def test_mixed_datasets_and_lengths(mpa, co, gsynth, tarr):
         lp_(P, ds_id=np.full(nw, 40, np.int32))     # unset dataset
 
 
-@pytest.mark.parametrize("nw", [40, 700, 1700])
+@pytest.mark.parametrize("nw", [40, 400, 700, 1700])
 def test_long_light_curves_every_kernel_variant(mpa, co, gsynth, tarr, nw):
     """Real GRB light curves have up to 1 944 points (data/real_data/): observations beyond the register-resident
-    ones go through the per-walker scratch rows.  40 / 700 / 1 700 walkers select the 4-wavefront, 4-steps-per-lane
-    and 2-steps-per-lane kernels; a few walkers are checked against the C oracle, all against each other."""
+    ones go through the per-walker scratch rows.  40 / 400 / 700 / 1 700 walkers select the 4-wavefront, the
+    producer/consumer, the 4-steps-per-lane and the 2-steps-per-lane kernels; a few walkers are checked against the C oracle, all against each other."""
     from magprop_amd import LogProb
     rng = np.random.default_rng(19)
     base = mpa.model_lum(CANON["Classic"])
@@ -382,6 +383,23 @@ def test_library_first_then_torch_in_one_process(gsynth):
         "print('one-runtime-ok', a[0])\n")
     r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "one-runtime-ok" in r.stdout, r.stderr[-2000:]
+
+
+def test_producer_consumer_pair_is_bit_identical(synth_handle, gsynth):
+    """257..512 walkers run on a producer/consumer pair of wavefronts (lnprob_pc_kernel): the statements of the
+    one-wavefront kernel split over two wavefronts, so the same walkers in a batch of 1 024 give the same bits -
+    values, statuses (prior / flag / non-finite walkers make the consumer stop early and release the producer)."""
+    rng = np.random.default_rng(5)
+    P = np.array(TRUTHS["Stuttering"]) + 1.0e-3 * rng.standard_normal((1024, 6))
+    P[::7] = synth_handle_prior_sample(rng, len(P[::7]))           # prior-wide walkers, some of them flag
+    P[5] = gsynth["prior_upper"] + 0.5                                 # outside the prior
+    P[6, 0] = np.nan
+    P[9] = [1.8171068, 3.68147895, -2.61786801, 1.99840102, -0.33083576, 2.95613803]   # SURVEY.md 8(c): flags
+    big, st_big = synth_handle.lnprob_batch(P, ds_id=3, want_status=True)
+    assert st_big[5] == 3 and st_big[9] == 1 and big[6] == -np.inf
+    for lo, hi in ((0, 512), (512, 1024), (100, 400)):
+        out, st = synth_handle.lnprob_batch(P[lo:hi], ds_id=3, want_status=True)
+        assert np.array_equal(out, big[lo:hi]) and np.array_equal(st, st_big[lo:hi])
 
 
 def test_edge_cases(mpa, synth_handle, gsynth):
