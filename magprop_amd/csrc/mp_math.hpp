@@ -144,15 +144,15 @@ MP_DEV Vd<N> rcp_fast(const Vd<N> &x) {
 
 template <int N>
 MP_DEV Vd<N> rsqrt_fast(const Vd<N> &x) {
-    Vd<N> y, hx, t;
+    // one third-order step from the hardware seed (relative error e0 ~ 2^-23 -> ~0.3 e0^3):
+    // e = 1 - x y^2,  y <- y (1 + e/2 + 3 e^2/8)
+    Vd<N> y, t, e, p;
     FORN y[i] = __builtin_amdgcn_rsq(x[i]);
-    FORN hx[i] = 0.5 * x[i];
-    FORN t[i] = hx[i] * y[i];
-    FORN t[i] = fma(-t[i], y[i], 0.5);
-    FORN y[i] = fma(y[i], t[i], y[i]);
-    FORN t[i] = hx[i] * y[i];
-    FORN t[i] = fma(-t[i], y[i], 0.5);
-    FORN y[i] = fma(y[i], t[i], y[i]);
+    FORN t[i] = x[i] * y[i];
+    FORN e[i] = fma(-t[i], y[i], 1.0);
+    FORN p[i] = fma(e[i], 0.375, 0.5);
+    FORN t[i] = y[i] * e[i];
+    FORN y[i] = fma(t[i], p[i], y[i]);
     return y;
 }
 
@@ -199,16 +199,17 @@ MP_DEV Vd<N> exp_fast(const Vd<N> &x) {
 // y <- y (4 - x y^3)/3 (error -> 2 e^2): ~1 ulp.
 template <int N>
 MP_DEV Vd<N> rcbrt_fast(const Vd<N> &x) {
-    Vd<N> y, x3, y3;
+    // one fourth-order step: e = 1 - x y^3,  y <- y (1 - e)^(-1/3) = y (1 + e/3 + 2 e^2/9 + 14 e^3/81 + ...)
+    // (the f32 log/exp seed is good to ~4e-6 for arguments up to 1e30, so e <~ 1.2e-5 and the e^4 term is < 1e-19)
+    Vd<N> y, y3, e, p;
     FORN y[i] = (double)__builtin_amdgcn_exp2f(-0.33333333f * __builtin_amdgcn_logf((float)x[i]));
-    FORN x3[i] = x[i] * (1.0 / 3.0);
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        FORN y3[i] = y[i] * y[i];
-        FORN y3[i] = y3[i] * y[i];
-        FORN y3[i] = fma(-x3[i], y3[i], 4.0 / 3.0);
-        FORN y[i] = y[i] * y3[i];
-    }
+    FORN y3[i] = y[i] * y[i];
+    FORN y3[i] = y3[i] * y[i];
+    FORN e[i] = fma(-x[i], y3[i], 1.0);
+    FORN p[i] = fma(e[i], 14.0 / 81.0, 2.0 / 9.0);
+    FORN p[i] = fma(e[i], p[i], 1.0 / 3.0);
+    FORN y3[i] = y[i] * e[i];
+    FORN y[i] = fma(y3[i], p[i], y[i]);
     return y;
 }
 
@@ -216,18 +217,19 @@ MP_DEV Vd<N> rcbrt_fast(const Vd<N> &x) {
 // v_log_f32/v_exp_f32 seed (~1e-6): ~1 ulp after two steps.
 template <int N>
 MP_DEV Vd<N> pow_m1_7_fast(const Vd<N> &x) {
-    Vd<N> y, x7, y2, y4, y7;
+    // one fourth-order step: e = 1 - x y^7,  y <- y (1 - e)^(-1/7) = y (1 + e/7 + 4 e^2/49 + 20 e^3/343 + ...)
+    // (seed good to ~4e-6, e <~ 3e-5: the e^4 term is < 1e-18)
+    Vd<N> y, y2, y4, y7, e, p;
     FORN y[i] = (double)__builtin_amdgcn_exp2f(-0.14285715f * __builtin_amdgcn_logf((float)x[i]));
-    FORN x7[i] = x[i] * (1.0 / 7.0);
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        FORN y2[i] = y[i] * y[i];
-        FORN y4[i] = y2[i] * y2[i];
-        FORN y7[i] = y4[i] * y2[i];
-        FORN y7[i] = y7[i] * y[i];
-        FORN y7[i] = fma(-x7[i], y7[i], 8.0 / 7.0);
-        FORN y[i] = y[i] * y7[i];
-    }
+    FORN y2[i] = y[i] * y[i];
+    FORN y4[i] = y2[i] * y2[i];
+    FORN y7[i] = y4[i] * y2[i];
+    FORN y7[i] = y7[i] * y[i];
+    FORN e[i] = fma(-x[i], y7[i], 1.0);
+    FORN p[i] = fma(e[i], 20.0 / 343.0, 4.0 / 49.0);
+    FORN p[i] = fma(e[i], p[i], 1.0 / 7.0);
+    FORN y7[i] = y[i] * e[i];
+    FORN y[i] = fma(y7[i], p[i], y[i]);
     return y;
 }
 
