@@ -129,16 +129,16 @@ MP_DEV void horner2(Vd<N> &p, const Vd<N> &x, int k) {
 }
 
 // Hand-rolled for this kernel's argument ranges (positive, normal, far from overflow): hardware
-// seed (v_rcp_f64 / v_rsq_f64, ~2^-23) + two Newton steps, without the scaling / fix-up code the
+// seed (v_rcp_f64 / v_rsq_f64, ~2^-23) + ONE third-order correction step, without the scaling / fix-up code the
 // general-purpose library versions carry.  All are accurate to ~1-2 ulp.
 template <int N>
 MP_DEV Vd<N> rcp_fast(const Vd<N> &x) {
+    // one third-order step from the hardware seed: e = 1 - x r,  r <- r (1 + e + e^2)
     Vd<N> r, e;
     FORN r[i] = __builtin_amdgcn_rcp(x[i]);
     FORN e[i] = fma(-x[i], r[i], 1.0);
-    FORN r[i] = fma(e[i], r[i], r[i]);
-    FORN e[i] = fma(-x[i], r[i], 1.0);
-    FORN r[i] = fma(e[i], r[i], r[i]);
+    FORN e[i] = fma(e[i], e[i], e[i]);
+    FORN r[i] = fma(r[i], e[i], r[i]);
     return r;
 }
 
@@ -195,8 +195,7 @@ MP_DEV Vd<N> exp_fast(const Vd<N> &x) {
     return p;
 }
 
-// x^(-1/3) for positive normal x within float range: v_log_f32/v_exp_f32 seed (~1e-6) + two Newton steps
-// y <- y (4 - x y^3)/3 (error -> 2 e^2): ~1 ulp.
+// x^(-1/3) for positive normal x within float range: v_log_f32/v_exp_f32 seed (~1e-6) + one fourth-order step
 template <int N>
 MP_DEV Vd<N> rcbrt_fast(const Vd<N> &x) {
     // one fourth-order step: e = 1 - x y^3,  y <- y (1 - e)^(-1/3) = y (1 + e/3 + 2 e^2/9 + 14 e^3/81 + ...)
@@ -213,8 +212,7 @@ MP_DEV Vd<N> rcbrt_fast(const Vd<N> &x) {
     return y;
 }
 
-// x^(-1/7) for positive normal x within float range: Newton y <- y (8 - x y^7)/7 (error -> 4 e^2) from a
-// v_log_f32/v_exp_f32 seed (~1e-6): ~1 ulp after two steps.
+// x^(-1/7) for positive normal x within float range, same construction
 template <int N>
 MP_DEV Vd<N> pow_m1_7_fast(const Vd<N> &x) {
     // one fourth-order step: e = 1 - x y^7,  y <- y (1 - e)^(-1/7) = y (1 + e/7 + 4 e^2/49 + 20 e^3/343 + ...)
