@@ -141,6 +141,17 @@ int mp_lnprob_batch_dev(mp_handle *h, const double *d_pars, const int32_t *d_ds_
 int mp_model_lc(mp_handle *h, const double *pars, int ndim, double *out, double *traj, int32_t *status);
 
 /*
+ * The ODE right-hand side itself, batched: replaces calls of `odes(y, t, B, MdiscI, RdiscI, epsilon, delta, ...)`
+ * (magnetar/funcs.py:33-101) / `ODEs(...)` (code/synthetic_datasets/funcs.py:75-142).  For point i:
+ * pars[i][ndim] PHYSICAL parameters (B, P, MdiscI, RdiscI, epsilon, delta[, ...]; P is not used by the RHS),
+ * t[i], y[i] = (Mdisc [g], omega [rad/s])  ->  dydt[i] = (dMdisc/dt, domega/dt).  lam (optional, [n]) receives
+ * d(omega_dot)/d(omega), the Jacobian entry the time-parallel solver linearises with.  Host buffers; evaluated by
+ * the same device functions as the log-posterior kernels (one point per lane).
+ */
+int mp_rhs_batch(mp_handle *h, const double *pars, int ndim, const double *t, const double *y, int n, double *dydt,
+                 double *lam);
+
+/*
  * Ensemble sampler: emcee's affine-invariant stretch move (Goodman & Weare 2010) with a random red/blue
  * split per step, as driven by code/synthetic_datasets/synth_mcmc.py:175-185
  * (em.EnsembleSampler(Nwalk, Npars, lnprob, ...).run_mcmc(pos, Nstep)).  Positions, log-posteriors,

@@ -11,7 +11,7 @@ from .ensemble import EnsembleSampler  # noqa: F401
 from .logprob import LogProb  # noqa: F401
 from ._capi import MagpropAmdError  # noqa: F401
 from .fit_stats import aicc, redchisq  # noqa: F401
-from .funcs import init_conds, model_lc, model_lum  # noqa: F401
+from .funcs import ODEs, init_conds, model_lc, model_lum, odes  # noqa: F401
 from .mcmc_eqns import lnlike, lnprior, lnprob  # noqa: F401
 
 __version__ = "0.1.0"

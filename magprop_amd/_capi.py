@@ -20,7 +20,7 @@ MAX_DATASETS = 64
 
 EXPORTS = (
     "mp_abi_version", "mp_last_error", "mp_cfg_synth", "mp_cfg_lib", "mp_create", "mp_destroy",
-    "mp_set_dataset", "mp_set_prior", "mp_lnprob_batch", "mp_lnprob_batch_dev", "mp_model_lc",
+    "mp_set_dataset", "mp_set_prior", "mp_lnprob_batch", "mp_lnprob_batch_dev", "mp_model_lc", "mp_rhs_batch",
     "mp_synchronize", "mp_device", "mp_stream", "mp_n_grid", "mp_last_mean_sweeps",
     "mp_sampler_create", "mp_sampler_destroy", "mp_sampler_set_positions", "mp_sampler_run", "mp_sampler_get_state",
 )
@@ -106,6 +106,7 @@ def lib():
     L.mp_lnprob_batch.argtypes = [vp, dp, ip, C.c_int, C.c_int, dp, ip, dp]
     L.mp_lnprob_batch_dev.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]
     L.mp_model_lc.argtypes = [vp, dp, C.c_int, dp, dp, ip]
+    L.mp_rhs_batch.argtypes = [vp, dp, C.c_int, dp, dp, C.c_int, dp, dp]
     L.mp_synchronize.argtypes = [vp]
     L.mp_device.argtypes = [vp]
     L.mp_stream.argtypes = [vp]
@@ -121,7 +122,7 @@ def lib():
     L.mp_last_mean_sweeps.argtypes = [vp]
     L.mp_last_mean_sweeps.restype = C.c_double
     for name in ("mp_destroy", "mp_set_dataset", "mp_set_prior", "mp_lnprob_batch", "mp_lnprob_batch_dev",
-                 "mp_model_lc", "mp_synchronize", "mp_device", "mp_n_grid", "mp_sampler_destroy",
+                 "mp_model_lc", "mp_rhs_batch", "mp_synchronize", "mp_device", "mp_n_grid", "mp_sampler_destroy",
                  "mp_sampler_set_positions", "mp_sampler_run", "mp_sampler_get_state"):
         getattr(L, name).restype = C.c_int
     _lib = L
@@ -250,6 +251,20 @@ class Handle:
         check(self._L.mp_model_lc(self._h, _dptr(p), int(p.size), _dptr(out), _dptr(traj), C.byref(st)),
               "mp_model_lc")
         return (st.value, out, traj) if want_traj else (st.value, out)
+
+    def rhs_batch(self, pars, t, y, want_lam=False):
+        """(dMdisc/dt, domega/dt) at n states: pars (n, ndim) physical, t (n,), y (n, 2) = (Mdisc, omega)."""
+        p = np.ascontiguousarray(pars, dtype=np.float64)
+        tt = np.ascontiguousarray(t, dtype=np.float64).ravel()
+        yy = np.ascontiguousarray(y, dtype=np.float64)
+        if p.ndim != 2 or yy.shape != (p.shape[0], 2) or tt.shape != (p.shape[0],):
+            raise ValueError("pars (n, ndim), t (n,), y (n, 2) expected")
+        n = p.shape[0]
+        out = np.empty((n, 2), dtype=np.float64)
+        lam = np.empty(n, dtype=np.float64)
+        check(self._L.mp_rhs_batch(self._h, _dptr(p), int(p.shape[1]), _dptr(tt), _dptr(yy), n, _dptr(out), _dptr(lam)),
+              "mp_rhs_batch")
+        return (out, lam) if want_lam else out
 
     def synchronize(self):
         check(self._L.mp_synchronize(self._h), "mp_synchronize")

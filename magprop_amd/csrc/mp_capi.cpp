@@ -507,6 +507,38 @@ int mp_model_lc(mp_handle *h, const double *pars, int ndim, double *out, double 
     return MP_OK;
 }
 
+int mp_rhs_batch(mp_handle *h, const double *pars, int ndim, const double *t, const double *y, int n, double *dydt,
+                 double *lam) {
+    if (!h || !pars || !t || !y || !dydt) return fail(MP_EINVAL, "mp_rhs_batch: NULL argument");
+    if (ndim < 6 || ndim > MP_MAX_NDIM) return fail(MP_EINVAL, "mp_rhs_batch: ndim must be 6..9, got %d", ndim);
+    if (n < 0) return fail(MP_EINVAL, "mp_rhs_batch: negative n");
+    if (n == 0) return MP_OK;
+    DeviceScope scope(h->device);
+    // one device block: [pars n*ndim | t n | y 2n] in, [dydt 2n | lam n] out
+    const size_t n_in = (size_t)n * (ndim + 3), n_out = (size_t)n * 3;
+    int rc;
+    if ((rc = h->w_curves.ensure(n_in + n_out))) return rc;
+    double *d = h->w_curves.p;
+    hipStream_t st = h->stream;
+    HIP_TRY(hipMemcpyAsync(d, pars, sizeof(double) * (size_t)n * ndim, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d + (size_t)n * ndim, t, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d + (size_t)n * (ndim + 1), y, sizeof(double) * 2 * (size_t)n, hipMemcpyHostToDevice, st));
+    mp::RhsArgs r{};
+    r.pars = d;
+    r.t = d + (size_t)n * ndim;
+    r.y = d + (size_t)n * (ndim + 1);
+    r.dydt = d + n_in;
+    r.lam = d + n_in + 2 * (size_t)n;
+    r.n = n;
+    r.ndim = ndim;
+    const int e = mp::launch_rhs(h->sh, r, st);
+    if (e) return fail(MP_EHIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+    HIP_TRY(hipMemcpyAsync(dydt, r.dydt, sizeof(double) * 2 * (size_t)n, hipMemcpyDeviceToHost, st));
+    if (lam) HIP_TRY(hipMemcpyAsync(lam, r.lam, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return MP_OK;
+}
+
 int mp_synchronize(mp_handle *h) {
     if (!h) return fail(MP_EINVAL, "mp_synchronize: NULL handle");
     DeviceScope scope(h->device);

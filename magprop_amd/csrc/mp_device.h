@@ -107,7 +107,19 @@ inline int waves_per_walker(int n) { return n <= 256 ? 4 : 1; }
 // Producer/consumer pair of wavefronts per walker: pays when every wavefront still gets a SIMD of its own.
 inline bool two_wave_pair(int n) { return n > 256 && n <= 512; }
 
+// Arguments of the batched right-hand-side evaluation (mp_kernels.hip: rhs_kernel), device pointers.
+struct RhsArgs {
+    const double *pars;     // [n][ndim], physical units
+    const double *t;        // [n]
+    const double *y;        // [n][2] = (Mdisc, omega)
+    double *dydt;           // [n][2]
+    double *lam;            // [n] or nullptr
+    int32_t n;
+    int32_t ndim;
+};
+
 // implemented in mp_kernels.hip; returns hipError_t as int
+int launch_rhs(const DevShared &sh, const RhsArgs &r, void *stream);
 int launch_lnprob(const DevShared &sh, const LaunchArgs &a, void *stream);
 int launch_stretch(const DevShared &sh, const StretchArgs &g, void *stream);
 

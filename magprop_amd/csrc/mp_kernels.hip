@@ -218,6 +218,40 @@ __global__ __launch_bounds__(PC ? 128 : 64 * W) void stretch_kernel(const DevSha
     }
 }
 
+// ---------------------------------------------------------------- the right-hand side at arbitrary states
+// One state per lane, evaluated by the device functions the solver kernels use (mdot_fb, disc_point, omega_rhs):
+// dMdisc/dt = Mdotfb - Mdisc/tvisc (eta1 + eta2 = 1, code/synthetic_datasets/funcs.py:122-129) and domega/dt
+// (funcs.py:119,131-140).  Serves `odes`/`ODEs` of the Python front end and pins the simplified algebra of the kernels
+// against the reference's literal formulas point by point.
+__global__ __launch_bounds__(64) void rhs_kernel(const DevShared sh, const RhsArgs r) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    const int ii = min(i, r.n - 1);                       // idle lanes repeat the last point (wave-wide votes inside)
+    double par[MP_MAX_NDIM];
+#pragma unroll
+    for (int k = 0; k < MP_MAX_NDIM; ++k) par[k] = k < r.ndim ? r.pars[(size_t)ii * r.ndim + k] : 0.0;
+    LaunchArgs a{};
+    a.ndim = r.ndim;
+    a.physical = 1;
+    Walker w;
+    (void)walker_setup(sh, a, par, w);
+    const Vd<1> tv{{r.t[ii]}}, Mv{{r.y[2 * (size_t)ii]}}, ov{{r.y[2 * (size_t)ii + 1]}};
+    const Vd<1> S = mdot_fb(w, tv);
+    const DiscPt<1> d = disc_point(sh, w, Mv);
+    Vd<1> rot, lam;
+    const Vd<1> f = omega_rhs<true>(sh, w, d, ov, rot, lam);
+    if (i < r.n) {
+        r.dydt[2 * (size_t)i] = S[0] - Mv[0] * w.inv_tau;
+        r.dydt[2 * (size_t)i + 1] = f[0];
+        if (r.lam) r.lam[i] = lam[0];
+    }
+}
+
+int launch_rhs(const DevShared &sh, const RhsArgs &r, void *stream) {
+    if (r.n <= 0) return 0;
+    hipLaunchKernelGGL(rhs_kernel, dim3((unsigned)((r.n + 63) / 64)), dim3(64), 0, (hipStream_t)stream, sh, r);
+    return (int)hipGetLastError();
+}
+
 int launch_lnprob(const DevShared &sh, const LaunchArgs &a, void *stream) {
     if (a.n <= 0) return 0;
     const bool curves = a.ltot || a.lprop || a.ldip || a.mdisc || a.omega;

@@ -55,3 +55,33 @@ def model_lum(pars, xdata=None, n=10.0, alpha=0.1, cs7=1.0, k=0.9, dipeff=1.0, p
     cfg = _capi.cfg_synth(n_ode=n, n_lum=n, alpha=alpha, cs7=cs7, k=k, dipeff=dipeff, propeff=propeff,
                           f_beam=f_beam)
     return _curve(cfg, pars, xdata, None, device)
+
+
+def _rhs(cfg, y, t, B, MdiscI, RdiscI, epsilon, delta, device):
+    y = np.asarray(y, dtype=np.float64)
+    t = np.asarray(t, dtype=np.float64)
+    single = y.ndim == 1
+    yy = np.atleast_2d(y)
+    n = yy.shape[0]
+    tt = np.broadcast_to(t, (n,))
+    cols = [np.broadcast_to(np.asarray(v, dtype=np.float64), (n,)) for v in (B, 1.0, MdiscI, RdiscI, epsilon, delta)]
+    pars = np.stack(cols, axis=1)                      # P (column 1) does not enter the right-hand side
+    eng = engine.engine(cfg, None, device)
+    with eng.lock:
+        out = eng.handle.rhs_batch(pars, tt, yy)
+    return out[0] if single else out
+
+
+def odes(y, t, B, MdiscI, RdiscI, epsilon, delta, n=1.0, alpha=0.1, cs7=1.0, k=0.9, device=-1):
+    """magnetar/funcs.py:33-101: time derivatives (dMdisc/dt, domega/dt) at state y = (Mdisc, omega) and time t,
+    evaluated on the GPU by the device functions of the log-posterior kernels.  Usable as the right-hand-side callable
+    of an ODE integrator exactly like the reference's (one launch per call), and batched: y (n, 2), t (n,) or scalar,
+    parameters scalar or (n,)."""
+    cfg = _capi.cfg_lib(n_ode=n, alpha=alpha, cs7=cs7, k=k)
+    return _rhs(cfg, y, t, B, MdiscI, RdiscI, epsilon, delta, device)
+
+
+def ODEs(y, t, B, MdiscI, RdiscI, epsilon, delta, n, alpha, cs7, k, device=-1):
+    """code/synthetic_datasets/funcs.py:75-142 (I = 0.35 M R^2, factor 3 in the Alfven radius)."""
+    cfg = _capi.cfg_synth(n_ode=n, alpha=alpha, cs7=cs7, k=k)
+    return _rhs(cfg, y, t, B, MdiscI, RdiscI, epsilon, delta, device)

@@ -62,6 +62,8 @@ def lib():
         L.mpo_trajectory_etd4rk.argtypes = L.mpo_trajectory.argtypes
         L.mpo_model_lc.restype = C.c_int
         L.mpo_model_lc.argtypes = [C.POINTER(Cfg), dp, C.c_int, dp, C.c_int, C.c_int, dp, dp]
+        L.mpo_rhs.restype = None
+        L.mpo_rhs.argtypes = [C.POINTER(Cfg), dp, C.c_int, C.c_double, C.c_double, C.c_double, dp, dp]
         L.mpo_lnlike.restype = C.c_double
         L.mpo_lnlike.argtypes = [C.POINTER(Cfg), dp, C.c_int, dp, C.c_int, dp, dp, dp, C.c_int,
                                  C.POINTER(C.c_int)]
@@ -89,6 +91,16 @@ def trajectory(cfg, pars, tgrid, nsub=1, scheme="eam4"):
     st = fn(C.byref(cfg), pp, p.size, tp, t.size, nsub,
                               M.ctypes.data_as(C.POINTER(C.c_double)), W.ctypes.data_as(C.POINTER(C.c_double)))
     return st, M, W
+
+
+def rhs(cfg, pars, t, Mdisc, omega):
+    """((dMdisc/dt, domega/dt), d(omega_dot)/d(omega)) at one state; PHYSICAL parameters."""
+    p, pp = _d(pars)
+    out = np.empty(2)
+    lam = C.c_double(0.0)
+    lib().mpo_rhs(C.byref(cfg), pp, p.size, float(t), float(Mdisc), float(omega),
+                  out.ctypes.data_as(C.POINTER(C.c_double)), C.byref(lam))
+    return out, lam.value
 
 
 def model_lc(cfg, pars, tgrid, nsub=1, want_traj=False):

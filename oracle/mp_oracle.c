@@ -156,6 +156,21 @@ static double omega_dot(const mpo_cfg *c, const wk *w, double Mdisc, double omeg
     return (Nacc + Ndip) / w->I;
 }
 
+/*
+ * The right-hand side itself at one state: out = (dMdisc/dt, domega/dt), magnetar/funcs.py:33-101,
+ * code/synthetic_datasets/funcs.py:75-142 (PHYSICAL parameters).  *lam (optional) = d(omega_dot)/d(omega).
+ */
+void mpo_rhs(const mpo_cfg *c, const double *pars, int ndim, double t, double Mdisc, double omega, double *out,
+             double *lam) {
+    wk w;
+    walker_setup(c, pars, ndim, &w);
+    flow f;
+    flow_state(c, &w, c->n_ode, Mdisc, omega, &f);
+    out[0] = mdot_fb(&w, t) - f.Mdotprop - f.Mdotacc;          /* funcs.py:129 */
+    double rot;
+    out[1] = omega_dot(c, &w, Mdisc, omega, &rot, lam);
+}
+
 /* phi_1..3(z) = sum_k z^k/(k+j)!  (phi_1 = (e^z-1)/z ...): Taylor below |z| = 0.5, closed forms above */
 static void phi123(double z, double *ez, double *p1, double *p2, double *p3) {
     if (fabs(z) < 0.5) {

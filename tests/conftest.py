@@ -55,6 +55,11 @@ def glibscan():
 
 
 @pytest.fixture(scope="session")
+def grhs():
+    return np.load(os.path.join(GOLDEN, "golden_rhs.npz"))
+
+
+@pytest.fixture(scope="session")
 def glibscan2():
     return np.load(os.path.join(GOLDEN, "golden_libscan2.npz"))
 

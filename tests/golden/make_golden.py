@@ -20,7 +20,7 @@ What is called (paths relative to /root/reference):
 `*_tight` arrays: the same reference code with its odeint call given rtol=atol=1e-12 (integrator noise
 removed; see tight_lsoda).
 Outputs: golden_synth.npz, golden_lib.npz, golden_flagscan.npz, golden_corners.npz, golden_libscan.npz, golden_longlc.npz,
-golden_flagscan2.npz, golden_libscan2.npz, MANIFEST.json.
+golden_flagscan2.npz, golden_libscan2.npz, golden_rhs.npz, MANIFEST.json.
 """
 import argparse
 import contextlib
@@ -285,6 +285,30 @@ def make_libscan2(n=900):
     print("libscan2 (S grid): flags", int((st == 1).sum()), "of", n)
 
 
+def make_rhs(n=1500):
+    """The right-hand sides themselves at random states: ODEs (synth, code/synthetic_datasets/funcs.py:75-142) and odes
+    (lib, magnetar/funcs.py:33-101) over the prior box, all branches (capped Alfven radius, Rm < R, beyond break-up)."""
+    rng = np.random.default_rng(SEED0 + 909)
+    lo = np.array([1.0e-3, 0.69, 1.0e-6, 50.0, 1.0e-2, 1.0e-1])
+    hi = np.array([10.0, 10.0, 1.0e-2, 2000.0, 1.0e2, 1.0e3])
+    g = {}
+    for name, fn, nn in (("synth", sf.ODEs, 10.0), ("lib", lib.odes, 1.0)):
+        P = np.exp(np.log(lo) + (np.log(hi) - np.log(lo)) * rng.random((n, 6)))        # log-uniform, physical units
+        t = 10.0 ** rng.uniform(-3.0 if name == "lib" else 0.0, 6.0, n)
+        Md = 10.0 ** rng.uniform(17.0, 34.0, n)
+        om = 10.0 ** rng.uniform(-1.2, 4.25, n)                                          # up to 1.8e4 rad/s: beyond break-up
+        k = 0.9 * np.ones(n)
+        k[: n // 5] = rng.uniform(0.3, 1.0, n // 5)                                      # other capping fractions
+        al = 0.1 * np.ones(n)
+        al[n // 5: 2 * n // 5] = rng.uniform(0.01, 0.5, n // 5)
+        out = np.array([fn(np.array([Md[i], om[i]]), t[i], P[i, 0], P[i, 2], P[i, 3], P[i, 4], P[i, 5], nn, al[i], 1.0, k[i])
+                        for i in range(n)])
+        g[name + "_pars"], g[name + "_t"], g[name + "_y"] = P, t, np.stack([Md, om], axis=1)
+        g[name + "_k"], g[name + "_alpha"], g[name + "_dydt"] = k, al, out
+    np.savez_compressed(os.path.join(HERE, "golden_rhs.npz"), **g)
+    print("rhs:", g["synth_dydt"][:2], g["lib_dydt"][:2])
+
+
 def make_lib():
     os.chdir(REF)  # magnetar/mcmc_eqns.py:55 reads a cwd-relative CSV
     import pandas as pd
@@ -415,7 +439,7 @@ def make_longlc():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--flag-scan", type=int, default=1500)
-    ap.add_argument("--only", choices=["all", "lib", "corners", "libscan", "longlc", "flagscan2", "libscan2"], default="all", help="regenerate only one file")
+    ap.add_argument("--only", choices=["all", "lib", "corners", "libscan", "longlc", "flagscan2", "libscan2", "rhs"], default="all", help="regenerate only one file")
     a = ap.parse_args()
     import scipy, pandas
     if a.only == "all":
@@ -433,6 +457,8 @@ def main():
         make_flagscan2()
     if a.only in ("all", "libscan2"):
         make_libscan2()
+    if a.only in ("all", "rhs"):
+        make_rhs()
     manifest = {
         "generator": "tests/golden/make_golden.py",
         "reference": "sgibson91/magprop mounted at /root/reference (magnetar v%s)" % lib.__version__

@@ -362,6 +362,51 @@ def test_long_light_curve_lib_short_grb_grid(mpa, glonglc):
     assert np.all(np.abs(out - ref) <= REF_ATOL + REF_RTOL * np.abs(ref))
 
 
+@pytest.mark.parametrize("name", ["synth", "lib"])
+def test_rhs_vs_reference(mpa, co, grhs, name):
+    """`ODEs` / `odes` evaluated by the device functions of the kernels (simplified algebra, hand-rolled elementary
+    functions) against the reference's right-hand sides at 1 500 random states per variant, all branches."""
+    from magprop_amd import engine
+    P, t, y, ref = grhs[name + "_pars"], grhs[name + "_t"], grhs[name + "_y"], grhs[name + "_dydt"]
+    kk, al = grhs[name + "_k"], grhs[name + "_alpha"]
+    fn = (lambda yy, tt, p, k_, a_: mpa.ODEs(yy, tt, p[..., 0], p[..., 2], p[..., 3], p[..., 4], p[..., 5], 10.0, a_, 1.0, k_)) \
+        if name == "synth" else \
+        (lambda yy, tt, p, k_, a_: mpa.odes(yy, tt, p[..., 0], p[..., 2], p[..., 3], p[..., 4], p[..., 5], n=1.0, alpha=a_, cs7=1.0, k=k_))
+    std = (kk == 0.9) & (al == 0.1)
+    out = np.full_like(ref, np.nan)
+    out[std] = fn(y[std], t[std], P[std], 0.9, 0.1)                       # one batched launch
+    odd = np.nonzero(~std)[0][::12]                                       # other k / alpha: one scalar call each
+    for i in odd:
+        out[i] = fn(y[i], t[i], P[i], float(kk[i]), float(al[i]))
+    sel = np.nonzero(std)[0].tolist() + odd.tolist()
+    tvisc = P[:, 3] * 1.0e5 / (al * 1.0e7)
+    for i in sel:
+        scale0 = max(abs(ref[i, 0]), y[i, 0] / tvisc[i])                  # dMdisc/dt cancels: scale of its larger term
+        assert abs(out[i, 0] - ref[i, 0]) <= 1e-12 * scale0, (i, out[i], ref[i])
+        assert abs(out[i, 1] - ref[i, 1]) <= 2e-11 * abs(ref[i, 1]), (i, out[i], ref[i])
+    # Jacobian entry used by the Newton sweeps: against the C oracle's analytic one
+    cfg = _capi_cfg(name)
+    h = engine.engine(cfg, None, -1).handle
+    _, lam = h.rhs_batch(P[std][:200], t[std][:200], y[std][:200], want_lam=True)
+    for j, i in enumerate(np.nonzero(std)[0][:200]):
+        ocfg = co.cfg_synth() if name == "synth" else co.cfg_lib()
+        _, lref = co.rhs(ocfg, P[i], t[i], y[i, 0], y[i, 1])
+        assert abs(lam[j] - lref) <= 1e-9 * abs(lref) + 1e-12 * abs(ref[i, 1] / y[i, 1]), (i, lam[j], lref)
+    # usable as odeint's callable, like the reference's (tests/test_funcs.py:28-48), on a short stretch
+    if name == "lib":
+        from scipy.integrate import odeint
+        tt = np.logspace(0.0, 1.0, 12)
+        y0 = mpa.init_conds(0.001, 1.0)
+        sol = odeint(mpa.odes, y0, tt, args=(1.0, 0.001, 100.0, 1.0, 10.0))
+        assert sol.shape == (12, 2) and np.all(np.isfinite(sol)) and sol[-1, 0] != y0[0]
+    engine.clear()
+
+
+def _capi_cfg(name):
+    from magprop_amd import _capi
+    return _capi.cfg_synth() if name == "synth" else _capi.cfg_lib()
+
+
 def test_library_first_then_torch_in_one_process(gsynth):
     """The library and PyTorch must end up on ONE HIP runtime whichever is loaded first (torch wheels bundle their
     own libamdhip64; a second runtime in the process sees no GPU).  Fresh interpreter: magprop_amd first, torch after."""

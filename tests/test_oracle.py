@@ -249,6 +249,30 @@ def test_lib_prior_wide_scan_short_grb_grid(glib, glibscan2, tarr_S):
             assert abs(ll - ref[i]) <= REF_ATOL + REF_RTOL * abs(ref[i])
 
 
+@pytest.mark.parametrize("name", ["synth", "lib"])
+def test_c_oracle_rhs_vs_reference(grhs, name):
+    """The right-hand side itself, point by point, against the reference's ODEs / odes at 1 500 random states per
+    variant (all branches: capped Alfven radius, Rm < R, beyond break-up; other k and alpha)."""
+    P, t, y, ref = grhs[name + "_pars"], grhs[name + "_t"], grhs[name + "_y"], grhs[name + "_dydt"]
+    worst = 0.0
+    for i in range(len(P)):
+        cfg = (co.cfg_synth if name == "synth" else co.cfg_lib)(k=float(grhs[name + "_k"][i]), alpha=float(grhs[name + "_alpha"][i]))
+        out, lam = co.rhs(cfg, P[i], t[i], y[i, 0], y[i, 1])
+        # dMdisc/dt = Mdotfb - Mdisc/tvisc cancels: compare on the scale of its larger term
+        scale0 = max(abs(ref[i, 0]), y[i, 0] / (P[i, 3] * 1.0e5 / (float(grhs[name + "_alpha"][i]) * 1.0e7)))
+        assert abs(out[0] - ref[i, 0]) <= 1e-12 * scale0, (i, out, ref[i])
+        assert abs(out[1] - ref[i, 1]) <= 1e-11 * abs(ref[i, 1]) + 1e-300, (i, out, ref[i])
+        worst = max(worst, abs(out[1] - ref[i, 1]) / abs(ref[i, 1]))
+        # the Jacobian entry the solver linearises with: central difference of the oracle's own omega_dot
+        if i % 25 == 0:
+            h = 1e-6 * y[i, 1]
+            fp, _ = co.rhs(cfg, P[i], t[i], y[i, 0], y[i, 1] + h)
+            fm, _ = co.rhs(cfg, P[i], t[i], y[i, 0], y[i, 1] - h)
+            fd = (fp[1] - fm[1]) / (2 * h)
+            assert abs(lam - fd) <= 2e-4 * abs(fd) + 1e-6 * abs(out[1] / y[i, 1]), (i, lam, fd)
+    assert worst < 1e-11
+
+
 # ---------------------------------------------------------------- scipy/LSODA port
 @pytest.mark.parametrize("name", TYPES)
 def test_lsoda_port_matches_reference(gsynth, tarr, name):
