@@ -53,12 +53,19 @@ class ShardedLnprob:
             self._slots[k] = slot
         return slot[1], slot[2]
 
-    def start(self, pars):
+    def start(self, pars, recv=None):
+        """recv: optional caller-owned float64 tensor that receives the full lnprob vector (at least
+        ceil(n/world)*world elements; n when the group has one rank) instead of the internal double buffer."""
         n = pars.shape[0]
         if self.world == 1 and not self.always_gather:
+            if recv is not None and self.writes_out:
+                self.eval_local(pars, out=recv[:n])
+                return None, recv, n
             return None, self.eval_local(pars), n
         lo, hi, per = shard_range(n, self.rank, self.world)
         local, buf = self._buffers(n, per, pars.device)
+        if recv is not None:
+            buf = recv[: per * self.world]
         if hi > lo:
             if self.writes_out:
                 self.eval_local(pars[lo:hi], out=local[: hi - lo])
