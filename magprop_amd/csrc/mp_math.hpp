@@ -344,4 +344,37 @@ MP_DEV Vd<N> eam4_increment(const DevShared &sh, const Phi<N> &p, const Vd<N> &h
     return acc;
 }
 
+// The same quadrature in node form: c_k = sum_m W[k][m] phi_{m+1}(z), increment = h * sum_k c_k v_k.  The Newton sweeps
+// use this form because the weights depend on z = h*lambda only: a sweep that keeps lambda keeps them too.
+template <int N>
+struct EamW {
+    Vd<N> c0, c1, c2, c3;
+};
+
+template <int N>
+MP_DEV EamW<N> eam4_node_weights(const DevShared &sh, const Phi<N> &p) {
+    EamW<N> w;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        Vd<N> &c = k == 0 ? w.c0 : k == 1 ? w.c1 : k == 2 ? w.c2 : w.c3;
+        FORN c[i] = sh.eamW[k][3] * p.p4[i];
+        FORN c[i] = fma(sh.eamW[k][2], p.p3[i], c[i]);
+        FORN c[i] = fma(sh.eamW[k][1], p.p2[i], c[i]);
+        FORN c[i] = fma(sh.eamW[k][0], p.p1[i], c[i]);
+    }
+    return w;
+}
+
+template <int N>
+MP_DEV Vd<N> eam4_increment_nodes(const EamW<N> &w, const Vd<N> &h, const Vd<N> &v0, const Vd<N> &v1, const Vd<N> &v2,
+                                  const Vd<N> &v3) {
+    Vd<N> acc;
+    FORN acc[i] = w.c3[i] * v3[i];
+    FORN acc[i] = fma(w.c2[i], v2[i], acc[i]);
+    FORN acc[i] = fma(w.c1[i], v1[i], acc[i]);
+    FORN acc[i] = fma(w.c0[i], v0[i], acc[i]);
+    FORN acc[i] = h[i] * acc[i];
+    return acc;
+}
+
 }  // namespace mp
