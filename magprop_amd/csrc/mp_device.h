@@ -101,11 +101,13 @@ struct StretchArgs {
 
 // Steps per lane of the kernel variant used for a batch of n walkers (tiles are 64*spl steps): see launch_lnprob.
 inline int kernel_spl(int n) { return n <= 1024 ? 4 : 2; }   // 1 024 SIMDs: beyond one wave each, two resident waves win (tools/spl_scan.sh)
-// Wavefronts that cooperate on one walker: small batches cannot give every SIMD (256 CUs x 4) a walker of its own.
-inline int waves_per_walker(int n) { return n <= 256 ? 4 : 1; }
+// Barrier-coupled wavefronts per walker (walker_eval_mw).  Superseded by the producer/consumer pair, which is 5 % faster
+// at every batch size that leaves SIMDs idle; still built and selectable with MAGPROP_AMD_WPW=4 (tests keep it honest).
+inline int waves_per_walker(int) { return 1; }
 
-// Producer/consumer pair of wavefronts per walker: pays when every wavefront still gets a SIMD of its own.
-inline bool two_wave_pair(int n) { return n > 256 && n <= 512; }
+// Producer/consumer pair of wavefronts per walker: pays when every wavefront still gets a SIMD of its own
+// (1 024 SIMDs: up to 512 walkers).
+inline bool two_wave_pair(int n) { return n <= 512; }
 
 // Arguments of the batched right-hand-side evaluation (mp_kernels.hip: rhs_kernel), device pointers.
 struct RhsArgs {

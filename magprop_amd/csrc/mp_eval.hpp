@@ -923,6 +923,9 @@ MP_DEV void walker_eval_mw(const DevShared &sh, const LaunchArgs &a, int walker,
             bool flagged = false, pending = true, not_ok = false, settled = false;
             int sweep = 0;
             double w_guard = om_s;
+            Vd<kSPL> lam, ez;          // light sweeps as in walker_eval; decided per wavefront (a step's linearisation
+            EamW<kSPL> cw;             // point is its own business, nothing has to agree across wavefronts)
+            bool light = false;
             while (true) {
                 {
                     bool wild = false;
@@ -934,8 +937,13 @@ MP_DEV void walker_eval_mw(const DevShared &sh, const LaunchArgs &a, int walker,
                             if (!(wg[s] > 0.0)) wg[s] = w_guard > 0.0 ? w_guard : om_s;
                     }
                 }
-                Vd<kSPL> rot, lam;
-                f1 = omega_rhs<true>(sh, w, d1, wg, rot, lam);
+                Vd<kSPL> rot;
+                if (light) {
+                    Vd<kSPL> unused;
+                    f1 = omega_rhs<false>(sh, w, d1, wg, rot, unused);
+                } else {
+                    f1 = omega_rhs<true>(sh, w, d1, wg, rot, lam);
+                }
                 bool flg = false;
 #pragma unroll
                 for (int s = 0; s < kSPL; ++s) {
@@ -973,36 +981,44 @@ MP_DEV void walker_eval_mw(const DevShared &sh, const LaunchArgs &a, int walker,
                 Ef[2] = lds.f[e0 + 2]; Ef[1] = lds.f[e0 + 1]; Ef[0] = lds.f[e0];
                 Ew[2] = lds.w[e0 + 2]; Ew[1] = lds.w[e0 + 1]; Ew[0] = lds.w[e0];
                 w_guard = Ew[2];
-                Vd<kSPL> zw, n0, n1, n2, n3;
+                Vd<kSPL> n0, n1, n2, n3;
 #pragma unroll
                 for (int s = 0; s < kSPL; ++s) {
-                    zw[s] = h[s] * lam[s];
                     n0[s] = fma(-lam[s], Ew[3 + s], Ef[3 + s]);
                     n1[s] = fma(-lam[s], Ew[2 + s], Ef[2 + s]);
                     n2[s] = fma(-lam[s], Ew[1 + s], Ef[1 + s]);
                     n3[s] = fma(-lam[s], Ew[s], Ef[s]);
                 }
-                const Phi<kSPL> pw_ = phi1234(zw);
-                const Vd<kSPL> inc = eam4_increment(sh, pw_, h, n0, n1, n2, n3);
+                if (!light) {
+                    Vd<kSPL> zw;
+#pragma unroll
+                    for (int s = 0; s < kSPL; ++s) zw[s] = h[s] * lam[s];
+                    const Phi<kSPL> pw_ = phi1234(zw);
+                    ez = pw_.e;
+                    cw = eam4_node_weights(sh, pw_);
+                }
+                const Vd<kSPL> inc = eam4_increment_nodes(cw, h, n0, n1, n2, n3);
                 double A = 1.0, B = 0.0;
 #pragma unroll
-                for (int s = 0; s < kSPL; ++s) { B = fma(pw_.e[s], B, inc[s]); A = A * pw_.e[s]; }
+                for (int s = 0; s < kSPL; ++s) { B = fma(ez[s], B, inc[s]); A = A * ez[s]; }
                 double om_wave;
                 scan_affine_block<W>(A, B, lds.tot[tp], wave, lane, om_s, om_wave);   // barrier: also orders the LDS image reads
                 tp ^= 1;                                                              // before the next pass overwrites it
                 const double Ax = lane_prev(A, 1.0), Bx = lane_prev(B, 0.0);
                 double wc = fma(Ax, om_wave, Bx);
-                bool all_ok = true, all_settled = true;
+                bool all_ok = true, all_settled = true, all_small = true;
 #pragma unroll
                 for (int s = 0; s < kSPL; ++s) {
-                    wc = fma(pw_.e[s], wc, inc[s]);
+                    wc = fma(ez[s], wc, inc[s]);
                     const double dw = fabs(wc - wg[s]), mag = fabs(wc);
                     all_settled = all_settled && (dw <= 1.0e-3 * mag);
+                    all_small = all_small && (dw <= 1.0e-4 * mag);
                     all_ok = all_ok && dw <= sh.sweep_tol * mag;
                     wg[s] = wc;
                 }
                 settled = all_settled;
                 not_ok = !all_ok;
+                light = __all(all_small);
             }
             sweeps_total += sweep;
 

@@ -257,9 +257,9 @@ int launch_lnprob(const DevShared &sh, const LaunchArgs &a, void *stream) {
     const bool curves = a.ltot || a.lprop || a.ldip || a.mdisc || a.omega;
     dim3 grid((unsigned)a.n), block(64);
     // Variants (results agree to rounding):
-    //  - batches that leave most SIMDs idle (256 CUs x 4 SIMDs; n <= 256) put 4 wavefronts on every walker;
-    //  - 257..512 walkers: a producer/consumer pair of wavefronts per walker (the omega-independent Mdisc phase runs
-    //    ahead on the second wavefront; bit-identical to the one-wavefront kernel, 17 % sooner);
+    //  - up to 512 walkers (SIMDs to spare): a producer/consumer pair of wavefronts per walker (the omega-independent
+    //    Mdisc phase runs ahead on the second wavefront; bit-identical to the one-wavefront kernel, 17-20 % sooner);
+    //    the older 4-barrier-coupled-wavefronts kernel is kept behind MAGPROP_AMD_WPW=4;
     //  - up to 1024 walkers (one wave per SIMD): one wavefront per walker, four steps per lane (256-step tiles
     //    amortise the wavefront scans best; needs the whole register file of a SIMD);
     //  - beyond: two steps per lane, which keeps two waves resident per SIMD (they fill each other's issue gaps).

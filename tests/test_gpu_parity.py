@@ -16,9 +16,9 @@ GPU_VS_C_RTOL = 1e-10   # HIP kernel vs serial C oracle: same scheme, different 
 
 def kernel_variant(n):
     """(wavefronts per walker, steps per lane) the library picks for a batch of n (mp_device.h): batches of different
-    variants agree to rounding, batches of the same variant bit for bit.  257..512 walkers run the producer/consumer
+    variants agree to rounding, batches of the same variant bit for bit.  Up to 512 walkers run the producer/consumer
     pair of wavefronts, which executes the statements of the (1, 4) kernel and is bit-identical to it."""
-    return (4, 1) if n <= 256 else (1, 4) if n <= 1024 else (1, 2)
+    return (1, 4) if n <= 1024 else (1, 2)
 LOG_MASK = 0b111100
 
 
@@ -294,8 +294,8 @@ def test_mixed_datasets_and_lengths(mpa, co, gsynth, tarr):
 @pytest.mark.parametrize("nw", [40, 400, 700, 1700])
 def test_long_light_curves_every_kernel_variant(mpa, co, gsynth, tarr, nw):
     """Real GRB light curves have up to 1 944 points (data/real_data/): observations beyond the register-resident
-    ones go through the per-walker scratch rows.  40 / 400 / 700 / 1 700 walkers select the 4-wavefront, the
-    producer/consumer, the 4-steps-per-lane and the 2-steps-per-lane kernels; a few walkers are checked against the C oracle, all against each other."""
+    ones go through the per-walker scratch rows.  40 / 400 walkers run on the producer/consumer pair of wavefronts,
+    700 on the 4-steps-per-lane and 1 700 on the 2-steps-per-lane kernel; a few walkers are checked against the C oracle, all against each other."""
     from magprop_amd import LogProb
     rng = np.random.default_rng(19)
     base = mpa.model_lum(CANON["Classic"])
@@ -324,10 +324,20 @@ def test_long_light_curves_every_kernel_variant(mpa, co, gsynth, tarr, nw):
         ref, _ = co.lnprob_batch(co.cfg_synth(), P[i], tarr, x, y, yerr, gsynth["prior_lower"],
                                  gsynth["prior_upper"], LOG_MASK)
         assert abs(out[i] - ref[0]) <= GPU_VS_C_RTOL * abs(ref[0]) * 10 + 1e-9, (i, ids[i], out[i], ref[0])
-    # the same walkers through another kernel variant (a batch of 8 -> 4 wavefronts per walker) agree to rounding
+    # the same walkers in a batch of 8 (producer/consumer pair) agree to rounding
     sub = np.r_[0:3, 4:9]
     small = lp_(P[sub], ds_id=ids[sub])
     assert np.allclose(small, out[sub], rtol=1e-10, atol=1e-9)
+    # ... and through the 4-barrier-coupled-wavefronts kernel (MAGPROP_AMD_WPW=4, read when a handle is created)
+    import os
+    os.environ["MAGPROP_AMD_WPW"] = "4"
+    try:
+        lp4 = LogProb(*sets[0])
+    finally:
+        del os.environ["MAGPROP_AMD_WPW"]
+    for s_ in sets[1:]:
+        lp4.add_dataset(*s_)
+    assert np.allclose(lp4(P[sub], ds_id=ids[sub]), out[sub], rtol=1e-10, atol=1e-9)
     # repeatable bit for bit (the scratch rows carry nothing over from one launch to the next)
     assert np.array_equal(lp_(P, ds_id=ids), out)
 

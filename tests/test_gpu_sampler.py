@@ -124,9 +124,17 @@ def test_sampler_on_a_long_light_curve(gsynth):
     y0 = model_lum(phys, xdata=x)
     yerr = 0.2 * y0
     y = y0 + rng.normal(0, yerr)
-    for nwalk in (32, 640):                                    # 4 wavefronts per walker / one wavefront per walker
+    import os
+    for nwalk, env in ((32, {}), (640, {}), (2600, {}), (32, {"MAGPROP_AMD_WPW": "4"})):
+        # producer/consumer pair (half-steps of 16 and 320 proposals), one wavefront per walker (1 300), and the
+        # 4-barrier-coupled-wavefronts kernel behind its environment switch (read when the sampler's handle is created)
         pos = truth + 1.0e-4 * rng.standard_normal((nwalk, 6))
-        s = EnsembleSampler(nwalk, 6, x, y, yerr, seed=77)
+        os.environ.update(env)
+        try:
+            s = EnsembleSampler(nwalk, 6, x, y, yerr, seed=77)
+        finally:
+            for k_ in env:
+                del os.environ[k_]
         s.run_mcmc(pos, 20)
         chain, lnp = s.get_chain(), s.get_log_prob()
         assert np.all(np.isfinite(lnp))

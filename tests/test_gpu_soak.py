@@ -61,12 +61,19 @@ def test_every_kernel_variant_against_the_c_oracle(gsynth, tarr):
     for part, (v, s) in zip(where, res):
         ref[part], rst[part] = v, s
 
-    lp_ = LogProb(*sets[0])
-    for s in sets[1:]:
-        lp_.add_dataset(*s)
     summary = {"n": N_SOAK, "oracle_status_counts": np.bincount(rst, minlength=4).tolist(), "variants": {}}
-    for batch, label in ((256, "4 wavefronts per walker"), (1024, "1 wavefront, 4 steps per lane"),
-                         (4096, "1 wavefront, 2 steps per lane")):
+    for batch, label, env in ((256, "producer/consumer pair of wavefronts", {}),
+                              (1024, "1 wavefront, 4 steps per lane", {}),
+                              (4096, "1 wavefront, 2 steps per lane", {}),
+                              (256, "4 barrier-coupled wavefronts (MAGPROP_AMD_WPW=4)", {"MAGPROP_AMD_WPW": "4"})):
+        os.environ.update(env)                                    # read when the handle is created
+        try:
+            lp_ = LogProb(*sets[0])
+        finally:
+            for k_ in env:
+                del os.environ[k_]
+        for s in sets[1:]:
+            lp_.add_dataset(*s)
         out = np.empty(N_SOAK)
         st = np.empty(N_SOAK, dtype=np.int32)
         for a in range(0, N_SOAK, batch):
