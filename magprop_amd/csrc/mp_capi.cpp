@@ -569,6 +569,7 @@ struct mp_sampler {
     DevBuf<double> d_pos, d_lnprob, d_chain, d_chain_lnp;
     DevBuf<int64_t> d_acc;
     DevBuf<int32_t> d_perm, d_dsid, d_status;
+    PinnedBuf h_perm;   // page-locked staging of the random splits: their upload overlaps the running half-steps
 };
 
 mp_sampler *mp_sampler_create(mp_handle *h, int n_walkers, int n_ensembles, int ndim, const int32_t *ens_ds_id,
@@ -613,7 +614,7 @@ int mp_sampler_destroy(mp_sampler *s) {
     DeviceScope scope(s->h->device);
     (void)hipStreamSynchronize(s->h->stream);
     s->d_pos.release(); s->d_lnprob.release(); s->d_chain.release(); s->d_chain_lnp.release();
-    s->d_acc.release(); s->d_perm.release(); s->d_dsid.release(); s->d_status.release();
+    s->d_acc.release(); s->d_perm.release(); s->d_dsid.release(); s->d_status.release(); s->h_perm.release();
     delete s;
     return MP_OK;
 }
@@ -653,46 +654,53 @@ int mp_sampler_run(mp_sampler *s, int n_steps, double *chain, double *chain_lnpr
     mp_handle *h = s->h;
     DeviceScope scope(h->device);
     const size_t nt = (size_t)s->n_total, row = nt * s->ndim;
-    // chunks of steps so that the device-resident chain slab stays below ~256 MB
-    const int chunk_max = chain ? std::max<int>(1, (int)std::min<size_t>((size_t)n_steps, (256u << 20) / (row * sizeof(double)))) : n_steps;
-    std::vector<int32_t> perm;
+    // chunks of steps so that the device-resident chain slab stays below ~256 MB (and the splits below ~64 MB)
+    const size_t perm_cap = std::max<size_t>(1, ((size_t)16 << 20) / nt);
+    const int chunk_max = (int)std::min<size_t>(
+        (size_t)std::max(n_steps, 1),
+        chain ? std::max<size_t>(1, std::min<size_t>(perm_cap, (256u << 20) / (row * sizeof(double)))) : perm_cap);
+    constexpr int kSub = 8;   // steps per batch of splits: the host draws the next batch while the GPU runs this one
     int rc;
     if ((rc = ensure_scratch(h, s->n_total))) return rc;
     for (int done = 0; done < n_steps;) {
         const int chunk = std::min(chunk_max, n_steps - done);
-        // random split of every ensemble for every step of the chunk (emcee's randomize_split)
-        perm.resize((size_t)chunk * nt);
-        for (int st = 0; st < chunk; ++st)
-            for (int e = 0; e < s->n_ensembles; ++e) {
-                int32_t *p = perm.data() + (size_t)st * nt + (size_t)e * s->n_walkers;
-                std::iota(p, p + s->n_walkers, 0);
-                const uint32_t step = (uint32_t)(s->steps_done + (uint64_t)st);
-                for (int i = s->n_walkers - 1; i > 0; --i) {   // Fisher-Yates, counter (step, ensemble, i, 'split')
-                    uint32_t r[4];
-                    philox4x32_10((uint32_t)s->seed, (uint32_t)(s->seed >> 32), step, (uint32_t)e, (uint32_t)i, 0x5117u, r);
-                    const uint64_t r64 = ((uint64_t)r[0] << 32) | r[1];
-                    std::swap(p[i], p[(size_t)(r64 % (uint64_t)(i + 1))]);
-                }
-            }
-        if ((rc = s->d_perm.ensure(perm.size()))) return rc;
-        HIP_TRY(hipMemcpyAsync(s->d_perm.p, perm.data(), perm.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+        if ((rc = s->h_perm.ensure((size_t)chunk * nt * sizeof(int32_t))) || (rc = s->d_perm.ensure((size_t)chunk * nt))) return rc;
+        int32_t *perm = (int32_t *)s->h_perm.p;
         if (chain) {
             if ((rc = s->d_chain.ensure((size_t)chunk * row)) || (rc = s->d_chain_lnp.ensure((size_t)chunk * nt))) return rc;
         }
-        for (int st = 0; st < chunk; ++st) {
-            for (int half = 0; half < 2; ++half) {
-                mp::StretchArgs g{};
-                g.pos = s->d_pos.p; g.lnprob = s->d_lnprob.p; g.n_accepted = s->d_acc.p;
-                g.perm = s->d_perm.p + (size_t)st * nt;
-                g.ds_id = s->d_dsid.p;
-                g.chain = chain ? s->d_chain.p : nullptr;
-                g.chain_lnp = chain ? s->d_chain_lnp.p : nullptr;
-                g.chain_row = st;
-                g.n_walkers = s->n_walkers; g.n_half = s->n_walkers / 2; g.n_ensembles = s->n_ensembles;
-                g.n_total = s->n_total; g.ndim = s->ndim; g.half = half; g.target = s->target;
-                g.step = (uint32_t)(s->steps_done + (uint64_t)st); g.seed = s->seed; g.a = s->a;
-                const int e = mp::launch_stretch(h->sh, g, h->stream);
-                if (e) return fail(MP_EHIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+        for (int sub = 0; sub < chunk; sub += kSub) {
+            const int sub_end = std::min(chunk, sub + kSub);
+            // random split of every ensemble for these steps (emcee's randomize_split)
+            for (int st = sub; st < sub_end; ++st)
+                for (int e = 0; e < s->n_ensembles; ++e) {
+                    int32_t *p = perm + (size_t)st * nt + (size_t)e * s->n_walkers;
+                    std::iota(p, p + s->n_walkers, 0);
+                    const uint32_t step = (uint32_t)(s->steps_done + (uint64_t)st);
+                    for (int i = s->n_walkers - 1; i > 0; --i) {   // Fisher-Yates, counter (step, ensemble, i, 'split')
+                        uint32_t r[4];
+                        philox4x32_10((uint32_t)s->seed, (uint32_t)(s->seed >> 32), step, (uint32_t)e, (uint32_t)i, 0x5117u, r);
+                        const uint64_t r64 = ((uint64_t)r[0] << 32) | r[1];
+                        std::swap(p[i], p[(size_t)(r64 % (uint64_t)(i + 1))]);
+                    }
+                }
+            HIP_TRY(hipMemcpyAsync(s->d_perm.p + (size_t)sub * nt, perm + (size_t)sub * nt,
+                                   (size_t)(sub_end - sub) * nt * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+            for (int st = sub; st < sub_end; ++st) {
+                for (int half = 0; half < 2; ++half) {
+                    mp::StretchArgs g{};
+                    g.pos = s->d_pos.p; g.lnprob = s->d_lnprob.p; g.n_accepted = s->d_acc.p;
+                    g.perm = s->d_perm.p + (size_t)st * nt;
+                    g.ds_id = s->d_dsid.p;
+                    g.chain = chain ? s->d_chain.p : nullptr;
+                    g.chain_lnp = chain ? s->d_chain_lnp.p : nullptr;
+                    g.chain_row = st;
+                    g.n_walkers = s->n_walkers; g.n_half = s->n_walkers / 2; g.n_ensembles = s->n_ensembles;
+                    g.n_total = s->n_total; g.ndim = s->ndim; g.half = half; g.target = s->target;
+                    g.step = (uint32_t)(s->steps_done + (uint64_t)st); g.seed = s->seed; g.a = s->a;
+                    const int e = mp::launch_stretch(h->sh, g, h->stream);
+                    if (e) return fail(MP_EHIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+                }
             }
         }
         if (chain) {
