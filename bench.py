@@ -1,25 +1,36 @@
 #!/usr/bin/env python3
 """bench.py — walker-lnprob evaluations/sec of the HIP hot path (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus 1 --steps K --warmup W [--config 2|3|4|5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path over one ensemble of proposals: every walker's lnprior + ODE
-integration over the 10 001-point grid + luminosity curve + interpolation + chi^2.  Workload at N=1:
-BASELINE.json configs[1] — Humped synthetic dataset, N_walk = 1024, fp64.  With N GPUs the ensemble is
-N x 1024 walkers (weak scaling; N=8 is configs[3], 8192 walkers), sharded contiguously over the ranks,
-followed by ONE RCCL all-gather of the lnprob slices so every rank sees the full ensemble (what the
-stretch move needs).  Proposals are resident in HBM before the timed region (they are generated on
-device, replicated on every rank from a common seed, like a replicated-RNG sampler would).
+A "step" is one pass of the hot path over one ensemble of proposals: every walker's lnprior + ODE integration over
+the 10 001-point grid + luminosity + interpolation + chi^2.  Workloads (BASELINE.json configs; --config):
 
-Prints one JSON line on rank 0 (contract in the task description) with two extra objects:
-  roofline     — the lnprob kernel's algorithmic HBM bytes / measured kernel time vs the 8 TB/s peak.
-                 This path is NOT HBM-bound (and has no MFMA work): it is a latency-bound fp64 VALU
-                 recurrence, so the HBM fraction is tiny by construction; "valu" prices the same kernel
-                 against the fp64 vector peak with the flop-equivalent convention of SURVEY.md 8(d).
-  cpu_baseline — oracle/lsoda_port.py (scipy odeint + Python RHS: the reference's cost structure) timed
-                 on this box's host cores over a bounded sample of the same walkers (rank 0, N=1 only).
+  2 (default)  Humped synthetic dataset, N_walk = 1024 per GPU, fp64 (configs[1]); with N GPUs the ensemble is
+               N x 1024 walkers (weak scaling; N = 8 is configs[3], 8 192 walkers)
+  3            Classic synthetic dataset, N_walk = 4096 per GPU (configs[2])
+  4            Humped, 8 192 walkers in total, sharded over the N GPUs (configs[3]; strong scaling)
+  5            all four GRB types, 1 024 walkers each, light curves of mixed lengths (8 ... 1 944 points) selected per
+               walker, 4 096 walkers in total sharded over the N GPUs (configs[4]; strong scaling)
+
+Every rank evaluates its contiguous block of the replicated proposal batch; ONE RCCL all-gather of the lnprob slices
+follows so every rank sees the full ensemble (what the stretch move needs).  Proposals are resident in HBM before the
+timed region (generated on device, replicated on every rank from a common seed).
+
+Prints one JSON line on rank 0 (contract in the task description) with extra objects:
+  roofline         the lnprob kernel's algorithmic HBM bytes / measured kernel time vs the 8 TB/s peak.  This path is
+                   NOT HBM-bound (and has no MFMA work): it is a latency-bound fp64 VALU recurrence; "valu" prices the
+                   same kernel against the fp64 vector peak with the flops the PMC counters saw (profiles/).
+  kernel_ms        the same kernel on harder inputs (N = 1): walkers uniform over the prior box, and a burnt-in ensemble
+                   (positions after 500 sampler steps), each with its Newton sweeps per tile.
+  check            the reference's own golden walkers (tests/golden/golden_synth.npz) evaluated in this run: max
+                   deviation from the reference run with a tight integrator.
+  ensemble_sampler the same metric through the device-resident stretch move (N = 1: fused single-GPU sampler;
+                   N > 1: walker-sharded half-steps with one all-gather each — dependent launches, nothing overlapped).
+  cpu_baseline     oracle/lsoda_port.py (scipy odeint + Python RHS: the reference's cost structure) timed on this box's
+                   host cores over a bounded sample of the same walkers (rank 0, N = 1 only).
 """
 import argparse
 import json
@@ -27,18 +38,26 @@ import os
 import sys
 import time
 
-import numpy as np
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # before anything loads a HIP runtime (dmabuf IPC for RCCL)
+
+import numpy as np  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+TYPES = ("Humped", "Classic", "Sloped", "Stuttering")
 TRUTH = {"Humped": [1.0, 5.0, -3.0, 2.0, -1.0, 0.0], "Classic": [1.0, 5.0, -3.0, 3.0, -1.0, 0.0],
          "Sloped": [1.0, 1.0, -3.0, 2.0, 1.0, 1.0], "Stuttering": [1.0, 5.0, -5.0, 2.0, -1.0, 2.0]}
+CANON = {"Humped": [1.0, 5.0, 1.0e-3, 100.0, 0.1, 1.0], "Classic": [1.0, 5.0, 1.0e-3, 1000.0, 0.1, 1.0],
+         "Sloped": [1.0, 1.0, 1.0e-3, 100.0, 10.0, 10.0], "Stuttering": [1.0, 5.0, 1.0e-5, 100.0, 0.1, 100.0]}
+PRIOR_LOWER = np.array([1.0e-3, 0.69, -6.0, np.log10(50.0), -2.0, -1.0])
+PRIOR_UPPER = np.array([10.0, 10.0, -2.0, np.log10(2000.0), 2.0, 3.0])
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X fp64 vector peak (spec)
 BYTES_PER_EVAL_A = 48 + 8 + 4  # mode A: 6 fp64 parameters in, lnprob + status out
 BYTES_LTOT = 10001 * 8         # mode B adds the model light curve
+EVENT_EVERY = 4                # kernel duration is sampled with HIP events on every 4th launch of the timed region
 
 
 def usable_cores():
@@ -81,11 +100,27 @@ def cpu_baseline(grb, budget_s, seed):
     return {"value": done / t_used, "unit": "evals/s", "cores": cores, "kind": "port",
             "sample": f"{done} of the step-0 style walkers ({grb}, truth+1e-4*randn) through oracle/lsoda_port.py "
                       f"(scipy {__import__('scipy').__version__} odeint/LSODA + Python RHS, multiprocessing.Pool({cores}))"
-                      f" in {t_used:.1f} s",
+                      f" in {t_used:.1f} s; the reference itself costs 1.45x this per evaluation (DESIGN.md section 5)",
             "ms_per_eval_per_core": 1e3 * t_used * cores / done, "check_lnprob0": float(vals[0])}
 
 
-EVENT_EVERY = 4      # kernel duration is sampled with HIP events on every 4th launch of the timed region
+def config5_datasets(g):
+    """Eleven light curves of 8 ... 1 944 points: the four seeded synthetic sets (50 points), the three long sets of
+    tests/golden/golden_longlc.npz (112 / 410 / 1 944: real SGRB lengths) and four short ones (8 / 63 / 64 /
+    65 points) drawn around the four types' model curves."""
+    from magprop_amd import model_lum
+    gl = np.load(os.path.join(ROOT, "tests", "golden", "golden_longlc.npz"))
+    sets = [(g[t + "_x"], g[t + "_y"], g[t + "_yerr"]) for t in TYPES]
+    sets += [tuple(gl[f"synth{m}_ds"]) for m in (112, 410, 1944)]
+    rng = np.random.default_rng(55)
+    tarr = np.logspace(0.0, 6.0, 10001)
+    for t, m in zip(TYPES, (8, 63, 64, 65)):
+        lc = model_lum(CANON[t])[1]
+        x = np.sort(10.0 ** rng.uniform(0.0, 6.0, m))
+        x[0], x[-1] = tarr[0], tarr[-1]
+        y0 = np.interp(x, tarr, lc)
+        sets.append((x, y0 + rng.normal(0, 0.2 * y0), 0.2 * y0))
+    return sets
 
 
 def main():
@@ -98,13 +133,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--nwalk", type=int, default=1024, help="walkers per GPU")
-    ap.add_argument("--grb", default="Humped", choices=list(TRUTH))
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5], help="BASELINE.json workload (see the docstring)")
+    ap.add_argument("--nwalk", type=int, default=None, help="walkers per GPU (overrides the preset; weak scaling)")
+    ap.add_argument("--grb", default=None, choices=list(TRUTH))
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
+                    help="strong: the preset's walkers are the TOTAL (8 192 for --config 2) and are sharded over the GPUs")
     ap.add_argument("--curve", action="store_true", help="mode B: also write the model light curve to HBM")
+    ap.add_argument("--spread", type=float, default=1.0e-4, help="walkers at truth + spread*randn (synth_mcmc.py:175-176)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=20261003)
-    ap.add_argument("--no-mcmc", action="store_true", help="skip the ensemble-sampler leg (N=1 only)")
+    ap.add_argument("--no-mcmc", action="store_true", help="skip the ensemble-sampler leg")
+    ap.add_argument("--no-extra", action="store_true", help="skip the prior-wide / burnt-in kernel timings and the golden check")
     ap.add_argument("--mcmc-steps", type=int, default=100)
     ap.add_argument("--overlap", type=int, default=1, choices=[0, 1],
                     help="1: the all-gather of one pass overlaps the next pass's kernel (independent batches); 0: serialised")
@@ -112,7 +152,7 @@ def main():
                     help="diagnostic: run the RCCL all-gather even at N=1 (group of one) to time the collective path")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend; gloo is for rehearsing N>1 on a one-GPU box (ranks share the card, "
-                         "lnprob slices are gathered through host memory) and is never a reported configuration")
+                         "rows are gathered through host memory) and is never a reported configuration")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -123,9 +163,20 @@ def main():
             sys.exit("bench.py --gpus N>1 must be launched through torch.distributed.run (see the docstring)")
         a.gpus = world
 
+    # ---- workload
+    grb = a.grb or {2: "Humped", 3: "Classic", 4: "Humped", 5: "Humped"}[a.config]
+    preset_walkers = {2: 1024, 3: 4096, 4: 8192, 5: 4096}[a.config]
+    scaling = a.scaling or ("strong" if a.config in (4, 5) else "weak")
+    if a.nwalk is not None:
+        n_global = a.nwalk * world if scaling == "weak" else a.nwalk
+    elif scaling == "weak":
+        n_global = preset_walkers * world
+    else:
+        n_global = 8192 if a.config == 2 else preset_walkers
+
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        cpu = cpu_baseline(a.grb, a.cpu_seconds, a.seed)        # before any GPU initialisation (forks)
+        cpu = cpu_baseline(grb, a.cpu_seconds, a.seed)          # before any GPU initialisation (forks)
 
     import torch
     import torch.distributed as dist
@@ -135,31 +186,51 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if a.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)       # RCCL over xGMI
         else:
             dist.init_process_group("gloo")
 
-    from magprop_amd import LogProb
-    from magprop_amd.distributed import ShardedLnprob, shard_range
+    from magprop_amd import EnsembleSampler, LogProb
+    from magprop_amd.distributed import DistributedEnsembleSampler, HipShardEngine, ShardedLnprob, shard_range
     g = np.load(os.path.join(ROOT, "tests", "golden", "golden_synth.npz"))
-    x, y, yerr = g[a.grb + "_x"], g[a.grb + "_y"], g[a.grb + "_yerr"]
-    lp = LogProb(x, y, yerr, device=dev_index)
-
-    n_global = a.nwalk * world
+    x, y, yerr = g[grb + "_x"], g[grb + "_y"], g[grb + "_yerr"]
     total = a.warmup + a.steps
     gen = torch.Generator(device=dev).manual_seed(a.seed)        # same seed on every rank: replicated proposals
-    truth = torch.tensor(TRUTH[a.grb], dtype=torch.float64, device=dev)
-    props = truth + 1.0e-4 * torch.randn(total, n_global, 6, dtype=torch.float64, device=dev, generator=gen)
+    ds_global = None
+    if a.config == 5:
+        sets = config5_datasets(g)
+        lp = LogProb(*sets[0], device=dev_index)
+        for s_ in sets[1:]:
+            lp.add_dataset(*s_)
+        nw = n_global // 4
+        truth = torch.tensor([TRUTH[t] for t in TYPES], dtype=torch.float64, device=dev).repeat_interleave(nw, dim=0)
+        rng5 = np.random.default_rng(a.seed)
+        ids = np.empty(n_global, dtype=np.int32)
+        for k in range(4):   # half of every type's walkers on its own seeded set, the others over the seven further sets
+            ids[k * nw:(k + 1) * nw] = np.where(np.arange(nw) < nw // 2, k, rng5.integers(4, len(sets), nw))
+        ds_global = torch.from_numpy(ids).to(dev)
+        n_obs_desc = sorted(len(s_[0]) for s_ in sets)
+    else:
+        lp = LogProb(x, y, yerr, device=dev_index)
+        truth = torch.tensor(TRUTH[grb], dtype=torch.float64, device=dev)
+        n_obs_desc = int(x.size)
+    props = truth + a.spread * torch.randn(total, n_global, 6, dtype=torch.float64, device=dev, generator=gen)
     lo, hi, per = shard_range(n_global, rank, world)
     n_local = hi - lo
+    ds_local = ds_global[lo:hi].contiguous() if ds_global is not None else None
     ltot = torch.empty(n_local, 10001, dtype=torch.float64, device=dev) if a.curve else None
-    status = torch.zeros(n_local, dtype=torch.int32, device=dev)
+    status = torch.zeros(max(n_local, 1), dtype=torch.int32, device=dev)
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(total)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(total)]
     step_idx = [0]
     stream = torch.cuda.current_stream(dev)
+
+    def launch(p, out, ids=None, st=None):
+        lp.handle.lnprob_batch_dev(p.data_ptr(), p.shape[0], 6, out.data_ptr(),
+                                   d_ds_id=ids.data_ptr() if ids is not None else 0,
+                                   d_status=st.data_ptr() if st is not None else 0,
+                                   d_ltot=ltot.data_ptr() if ltot is not None else 0, stream=stream.cuda_stream)
 
     def eval_local(p, out=None):
         i = step_idx[0]
@@ -168,8 +239,7 @@ def main():
         timed = i % EVENT_EVERY == 0 or i == a.warmup      # HIP events around every 4th launch: each pair costs ~2 us of stream time
         if timed:
             ev0[i].record(stream)
-        lp.handle.lnprob_batch_dev(p.data_ptr(), p.shape[0], 6, out.data_ptr(), d_status=status.data_ptr(),
-                                   d_ltot=ltot.data_ptr() if ltot is not None else 0, stream=stream.cuda_stream)
+        launch(p, out, ds_local, status)
         if timed:
             ev1[i].record(stream)
         return out
@@ -224,25 +294,77 @@ def main():
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
+    kern_ms = np.array([ev0[i].elapsed_time(ev1[i]) for i in range(a.warmup, total) if i % EVENT_EVERY == 0 or i == a.warmup])
+    n_flag = int((status[:n_local] != 0).sum().item())
+    first = float(full[0].item())
 
+    # ---- the same metric through the device-resident ensemble sampler: walkers x steps / s
     mcmc = None
-    if world == 1 and not a.no_mcmc:
-        # the same metric through the device-resident ensemble sampler (fused stretch-move half-steps): walkers x steps / s
-        from magprop_amd import EnsembleSampler
-        es = EnsembleSampler(a.nwalk, 6, x, y, yerr, seed=a.seed, device=dev_index)
-        p0 = (truth + 1.0e-4 * torch.randn(a.nwalk, 6, dtype=torch.float64, device=dev, generator=gen)).cpu().numpy()
-        es.run_mcmc(p0, 5, store=False)
-        tm = time.perf_counter()
-        es.run_mcmc(None, a.mcmc_steps, store=False)
-        tm = time.perf_counter() - tm
-        mcmc = {"walkers": a.nwalk, "steps": a.mcmc_steps, "walker_steps_per_sec": a.nwalk * a.mcmc_steps / tm,
-                "ms_per_step": 1e3 * tm / a.mcmc_steps, "acceptance_fraction": float(es.acceptance_fraction.mean()),
-                "note": "emcee-style stretch move, 2 fused kernel launches per step (propose+lnprob+accept+store)"}
+    if not a.no_mcmc and a.config != 5 and n_global % 2 == 0:
+        p0 = (truth + 1.0e-4 * torch.randn(n_global, 6, dtype=torch.float64, device=dev, generator=gen)).cpu().numpy()
+        es = EnsembleSampler(n_global, 6, x, y, yerr, seed=a.seed, device=dev_index)
+        if world == 1:
+            es.run_mcmc(p0, 5, store=False)
+            tm = time.perf_counter()
+            es.run_mcmc(None, a.mcmc_steps, store=False)
+            tm = time.perf_counter() - tm
+            note = "emcee-style stretch move, 2 fused kernel launches per step (propose+lnprob+accept+store)"
+            acc = float(es.acceptance_fraction.mean())
+        else:
+            dsam = DistributedEnsembleSampler(HipShardEngine(es, dev), via_host=(a.backend == "gloo"))
+            dsam.run_mcmc(p0, 5, store=False)
+            fence()
+            tm = time.perf_counter()
+            dsam.run_mcmc(None, a.mcmc_steps, store=False)
+            fence()
+            tm = time.perf_counter() - tm
+            tt = torch.tensor([tm], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            tm = float(tt.item())
+            note = (f"walker-sharded stretch move: per half-step every rank runs the fused kernel over its {dsam.hi - dsam.lo} "
+                    f"of the {es.n_slots} proposals, ONE all-gather of the outcome rows ({es.row_doubles * 8} B each), commit "
+                    "on every rank; dependent launches, nothing overlapped")
+            acc = float(np.mean(dsam.acceptance_fraction))
+        mcmc = {"walkers": n_global, "steps": a.mcmc_steps, "walker_steps_per_sec": n_global * a.mcmc_steps / tm,
+                "ms_per_step": 1e3 * tm / a.mcmc_steps, "acceptance_fraction": acc, "note": note}
         es.close()
 
-    kern_ms = np.array([ev0[i].elapsed_time(ev1[i]) for i in range(a.warmup, total) if i % EVENT_EVERY == 0 or i == a.warmup])
-    n_flag = int((status != 0).sum().item())
-    first = float(full[0].item())
+    # ---- N = 1 extras: harder inputs for the same kernel, and the reference's golden walkers
+    extra = None
+    if world == 1 and not a.no_extra and a.config != 5 and not a.curve:
+        def time_kernel(P_np, reps=24):
+            P = torch.from_numpy(np.ascontiguousarray(P_np)).to(dev)
+            out = torch.empty(P.shape[0], dtype=torch.float64, device=dev)
+            st = torch.empty(P.shape[0], dtype=torch.int32, device=dev)
+            e0 = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
+            e1 = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
+            for _ in range(3):
+                launch(P, out, None, st)
+            for r in range(reps):
+                e0[r].record(stream)
+                launch(P, out, None, st)
+                e1[r].record(stream)
+            torch.cuda.synchronize(dev)
+            ms = float(np.mean([e0[r].elapsed_time(e1[r]) for r in range(reps)]))
+            lp.handle.lnprob_batch(P_np)                                        # host entry: records the sweeps per tile
+            return {"kernel_ms": ms, "evals_per_sec": P.shape[0] / ms * 1e3, "sweeps_per_tile": lp.handle.last_mean_sweeps,
+                    "not_ok": int((st != 0).sum().item())}
+        rngx = np.random.default_rng(a.seed + 1)
+        wide = PRIOR_LOWER + (PRIOR_UPPER - PRIOR_LOWER) * rngx.random((n_global, 6))
+        es = EnsembleSampler(n_global, 6, x, y, yerr, seed=a.seed + 2, device=dev_index)
+        burnt = es.run_mcmc(np.array(TRUTH[grb]) + 1.0e-4 * rngx.standard_normal((n_global, 6)), 500, store=False)
+        es.close()
+        near = props[a.warmup].cpu().numpy()
+        extra = {"near_truth": time_kernel(near), "prior_wide": time_kernel(wide), "burnt_in_500_steps": time_kernel(burnt)}
+        Pg, tight, ref = g[grb + "_pars"], g[grb + "_lnprob_tight"], g[grb + "_lnprob"]
+        og = lp(Pg)
+        fin = np.isfinite(tight)
+        golden = {"walkers": int(len(Pg)), "status_agrees": bool(np.array_equal(np.isfinite(og), np.isfinite(ref))),
+                  "max_rel_dev_vs_reference_tight_lsoda": float(np.max(np.abs(og[fin] - tight[fin]) / np.abs(tight[fin]))),
+                  "max_rel_dev_vs_reference_default_lsoda": float(np.max(np.abs(og[fin] - ref[fin]) / np.abs(ref[fin]))),
+                  "tolerance": "1e-7 + 1e-7|ref| (tight), 1e-5 + 2e-5|ref| (default LSODA noise)",
+                  "pass": bool(np.all(np.abs(og[fin] - tight[fin]) <= 1e-7 + 1e-7 * np.abs(tight[fin])))}
+
     if rank == 0:
         evals = n_global * a.steps
         value = evals / dt
@@ -250,28 +372,39 @@ def main():
         bytes_eval = BYTES_PER_EVAL_A + (BYTES_LTOT if a.curve else 0)
         achieved = bytes_eval * n_local / kavg / 1e9
         traffic = flops_launch = None
-        tf = os.path.join(ROOT, "profiles", "pmc_figures.json")     # from the committed rocprofv3 PMC summary
+        fig_key = "curve" if a.curve else ("config5" if a.config == 5 else "lnprob")
+        tf = os.path.join(ROOT, "profiles", "pmc_figures.json")     # from the committed rocprofv3 PMC summaries
         if os.path.exists(tf):
             try:
-                fig = json.load(open(tf)).get("curve" if a.curve else "lnprob", {}).get(str(n_local), {})
+                fig = json.load(open(tf)).get(fig_key, {}).get(str(n_local), {})
                 traffic, flops_launch = fig.get("traffic_bytes"), fig.get("fp64_flops")
             except Exception:  # noqa: BLE001
                 traffic = flops_launch = None
+        n_simd = lp.handle.n_simd
+        variant = ("curve kernel, " if a.curve else "") + ("producer/consumer pair of wavefronts" if (2 * n_local <= n_simd and not a.curve)
+                                                            else "4 steps per lane" if n_local <= n_simd else "2 steps per lane")
+        if a.config == 5:
+            workload = (f"BASELINE config 5: four GRB types x {n_global // 4} walkers at truth+{a.spread:g}*randn, eleven light curves "
+                        f"of {n_obs_desc} points selected per walker, {n_global} walkers in one launch per pass")
+        else:
+            workload = (f"BASELINE config {a.config}: {grb} synthetic dataset (N_obs=50), {n_local} walkers per GPU "
+                        f"({n_global} walkers total), walkers at truth+{a.spread:g}*randn")
+        workload += f", 10001-point grid, mode {'B (lnprob + model light curve written to HBM)' if a.curve else 'A (lnprob only)'}"
         out = {
             "metric": "walker_lnprob_evals_per_sec", "value": value, "unit": "evals/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{a.grb} synthetic dataset (N_obs=50), N_walk={a.nwalk} per GPU "
-                                   f"({n_global} walkers total), walkers at truth+1e-4*randn, 10001-point grid, "
-                                   f"mode {'B (lnprob + model light curve written to HBM)' if a.curve else 'A (lnprob only)'}",
-                       "n_walk_per_gpu": a.nwalk, "n_walk_total": n_global, "n_grid": 10001, "n_obs": int(x.size),
-                       "variant": "synth", "parallelism": f"walker-shard x{world} + {'RCCL' if a.backend == 'nccl' else 'gloo (rehearsal)'} all-gather(lnprob)" + (", gather of pass i overlapped with kernel of pass i+1" if (world > 1 and a.overlap) else "")},
+            "scaling": scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": workload, "baseline_config": a.config,
+                       "n_walk_per_gpu": n_local, "n_walk_total": n_global, "n_grid": 10001, "n_obs": n_obs_desc,
+                       "variant": "synth", "kernel_variant": variant, "sweep_tol": lp.handle.sweep_tol,
+                       "parallelism": f"walker-shard x{world} + {'RCCL' if a.backend == 'nccl' else 'gloo (rehearsal)'} all-gather(lnprob)" + (", gather of pass i overlapped with kernel of pass i+1" if (world > 1 and a.overlap) else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "mp::lnprob_kernel", "kernel_ms_avg": 1e3 * kavg, "kernel_ms_min": float(kern_ms.min()),
+                         "kernel": "mp::lnprob_kernel" if (a.curve or 2 * n_local > n_simd) else "mp::lnprob_pc_kernel",
+                         "kernel_ms_avg": 1e3 * kavg, "kernel_ms_min": float(kern_ms.min()),
                          "algorithmic_bytes_per_eval": bytes_eval, "evals_per_launch": n_local,
                          "note": "latency-bound fp64 VALU recurrence: neither HBM nor MFMA binds; see valu"},
-            "valu": {"bound": "fp64 VALU issue, one wave per SIMD", "unit": "TFLOP/s",
+            "valu": {"bound": "fp64 VALU issue", "unit": "TFLOP/s",
                      "fp64_flops_per_launch_pmc": flops_launch,
                      "achieved": None if flops_launch is None else flops_launch / kavg / 1e12,
                      "peak": FP64_VALU_PEAK_TFLOPS,
@@ -282,6 +415,9 @@ def main():
             "host_enqueue_ms_per_step": 1e3 * t_host / a.steps,
             "check": {"lnprob0": first, "n_not_ok": n_flag, "checksum": float(checksum.item())},
         }
+        if extra is not None:
+            out["kernel_ms"] = extra
+            out["check"]["golden"] = golden
         if mcmc is not None:
             out["ensemble_sampler"] = mcmc
         if cpu is not None:

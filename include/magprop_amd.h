@@ -30,6 +30,19 @@
  *   - per-walker physics failures are NOT errors: lnprob = -inf and a status code
  *     (reference: the string 'flag', magnetar/funcs.py:153-154).
  *   - all floating point is IEEE fp64.
+ *
+ * Threads and streams
+ *   - A handle (and the samplers created on it) may be used from several host threads: every entry point
+ *     that takes one serialises on a mutex inside the handle for the duration of the call.  The host-buffer
+ *     entry points (mp_lnprob_batch, mp_model_lc, mp_rhs_batch, mp_sampler_run ...) run on the handle's own
+ *     stream and return when their results are in the caller's buffers.
+ *   - mp_lnprob_batch_dev and the mp_sampler_halfstep_* calls only enqueue work on the stream they are given.
+ *     Launches on different streams may overlap on the device, with one exception the library orders itself:
+ *     a handle that holds a light curve of more than 64 points owns per-walker scratch rows, and a launch that
+ *     uses them waits (stream-side, through an event) for the previous such launch of the same handle.
+ *   - Buffers passed to an asynchronous call must stay valid until the work has completed on that stream;
+ *     replacing a dataset (mp_set_dataset) waits for the device first.
+ *   - All mp_sampler_halfstep_* calls of one sampler must use one stream.
  */
 #ifndef MAGPROP_AMD_H
 #define MAGPROP_AMD_H
@@ -40,7 +53,7 @@
 extern "C" {
 #endif
 
-#define MP_ABI_VERSION 1
+#define MP_ABI_VERSION 2
 
 /* return codes */
 #define MP_OK 0
@@ -79,7 +92,13 @@ typedef struct mp_model_cfg {
     double nacc_lum_threshold; /* luminosity-stage break-up test: 0.27 (synth funcs.py:206) | 0.0 (magnetar/funcs.py:193) */
     int32_t lprop_gm_term;     /* 1: Lprop includes -(GM/Rm)*eta2*Mdisc/tvisc (synth funcs.py:222-223); 0: lib          */
     int32_t reserved;
+    double sweep_tol;          /* relative change of omega at the step ends that ends the Newton sweeps of a tile of the   */
+                               /* time-parallel solver; 0 = MP_SWEEP_TOL_DEFAULT.  What it buys and costs: DESIGN.md 3     */
 } mp_model_cfg;
+
+/* The reference integrates with LSODA at rtol = atol ~ 1.5e-8 and its lnprob carries up to 1.4e-5 relative integrator
+ * noise.  Default here: sweeps contract by 1e-2..1e-3 per pass, so stopping at 1e-9 leaves <= 4e-11 relative in lnprob. */
+#define MP_SWEEP_TOL_DEFAULT 1.0e-9
 
 typedef struct mp_handle mp_handle;
 
@@ -127,7 +146,8 @@ int mp_lnprob_batch(mp_handle *h, const double *pars, const int32_t *ds_id, int 
  * Same, every pointer a DEVICE pointer on the handle's device; the kernel is
  * enqueued on `stream` (a hipStream_t passed as void*; NULL is HIP's default
  * stream, mp_stream(h) the handle's own) and the call returns without
- * synchronising.
+ * synchronising.  Rows of d_ltot whose walker did not finish (status != MP_STATUS_OK)
+ * are filled with NaN by the kernel, as in the host-buffer form.
  */
 int mp_lnprob_batch_dev(mp_handle *h, const double *d_pars, const int32_t *d_ds_id, int n, int ndim,
                         double *d_lnprob, int32_t *d_status, double *d_ltot, void *stream);
@@ -175,6 +195,37 @@ int mp_sampler_set_positions(mp_sampler *s, const double *pos);
 int mp_sampler_run(mp_sampler *s, int n_steps, double *chain, double *chain_lnprob);
 /* any of the outputs may be NULL */
 int mp_sampler_get_state(mp_sampler *s, double *pos, double *lnprob, int64_t *n_accepted, int64_t *steps_done);
+/*
+ * Proposals inside the prior whose model evaluation failed ('flag' / non-finite): what the reference's lnprob appends
+ * to its `fbad` file (code/synthetic_datasets/mcmc_eqns.py:72-79).  *n_bad = how many there were since the sampler was
+ * created; up to max_rows of the first 4096 are copied to pars[max_rows][ndim] (sampler coordinates).  Returns the
+ * number of rows copied (>= 0) or a negative MP_E* code.
+ */
+int mp_sampler_get_bad(mp_sampler *s, double *pars, int max_rows, int64_t *n_bad);
+
+/*
+ * Walker-sharded ensembles (one process per GPU; the reference's counterpart is emcee's pool.map over
+ * walkers, code/synthetic_datasets/synth_mcmc.py:178-185).  Every process holds a sampler with the same seed and the
+ * full ensemble state.  A half-step has n_slots = mp_sampler_n_slots() proposals (the active half of every ensemble);
+ * the process that owns slots [slot_lo, slot_hi) runs
+ *     mp_sampler_halfstep_shard(s, half, slot_lo, slot_hi, d_rows + slot_lo*R, stream)    R = mp_sampler_row_doubles()
+ * which draws, evaluates and accept-tests exactly what the single-GPU launch would for those walkers (the random numbers
+ * are keyed by (seed; step, half, walker)) and writes one outcome row per slot: proposal[ndim], its lnprob, accepted
+ * (0/1), status.  After the rows of all processes have been gathered (ONE all-gather per half-step; RCCL through
+ * torch.distributed in magprop_amd/distributed.py) every process commits them with
+ *     mp_sampler_halfstep_apply(s, half, d_rows, d_chain_row, d_chain_lnp_row, stream)
+ * (d_rows[n_slots][R]; the optional d_chain_row[n_total][ndim] / d_chain_lnp_row[n_total] receive this step's entries of
+ * the walkers that moved; both NULL or both set).  half = 0 then 1; the apply of half 1 ends the step.  All pointers
+ * are device pointers; nothing synchronises with the host.  The resulting chain is the one mp_sampler_run produces
+ * (bit for bit while both run the same kernel variant).
+ */
+int mp_sampler_n_slots(const mp_sampler *s);
+int mp_sampler_row_doubles(const mp_sampler *s);
+int mp_sampler_halfstep_shard(mp_sampler *s, int half, int slot_lo, int slot_hi, double *d_rows, void *stream);
+int mp_sampler_halfstep_apply(mp_sampler *s, int half, const double *d_rows, double *d_chain_row,
+                              double *d_chain_lnp_row, void *stream);
+/* device pointers of the resident state: pos[n_total][ndim], lnprob[n_total] (read-only for the caller) */
+int mp_sampler_state_ptrs(mp_sampler *s, double **d_pos, double **d_lnprob);
 
 /* wait for everything enqueued on the handle's own stream */
 int mp_synchronize(mp_handle *h);
@@ -183,8 +234,10 @@ int mp_synchronize(mp_handle *h);
 int mp_device(const mp_handle *h);
 void *mp_stream(const mp_handle *h); /* the handle's own hipStream_t */
 int mp_n_grid(const mp_handle *h);
-/* mean Picard sweeps per 64-step tile of the most recent host-buffer batch (diagnostic) */
+/* mean Newton sweeps per tile of the most recent host-buffer batch (diagnostic) */
 double mp_last_mean_sweeps(const mp_handle *h);
+double mp_sweep_tol(const mp_handle *h); /* the tolerance in force (cfg.sweep_tol or the default) */
+int mp_n_simd(const mp_handle *h);       /* SIMDs of the handle's device: batch-size thresholds of the kernel variants */
 
 #ifdef __cplusplus
 }

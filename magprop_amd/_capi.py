@@ -23,7 +23,10 @@ EXPORTS = (
     "mp_set_dataset", "mp_set_prior", "mp_lnprob_batch", "mp_lnprob_batch_dev", "mp_model_lc", "mp_rhs_batch",
     "mp_synchronize", "mp_device", "mp_stream", "mp_n_grid", "mp_last_mean_sweeps",
     "mp_sampler_create", "mp_sampler_destroy", "mp_sampler_set_positions", "mp_sampler_run", "mp_sampler_get_state",
+    "mp_sampler_get_bad", "mp_sampler_n_slots", "mp_sampler_row_doubles", "mp_sampler_halfstep_shard",
+    "mp_sampler_halfstep_apply", "mp_sampler_state_ptrs", "mp_sweep_tol", "mp_n_simd",
 )
+ABI_VERSION = 2
 
 
 class MagpropAmdError(RuntimeError):
@@ -35,7 +38,7 @@ class ModelCfg(C.Structure):
     _fields_ = [(n, C.c_double) for n in (
         "inertia_factor", "rm_massflow_factor", "n_ode", "n_lum", "alpha", "cs7", "k",
         "dipeff", "propeff", "f_beam", "nacc_lum_threshold")] + [
-        ("lprop_gm_term", C.c_int32), ("reserved", C.c_int32)]
+        ("lprop_gm_term", C.c_int32), ("reserved", C.c_int32), ("sweep_tol", C.c_double)]
 
 
 def build(force=False, verbose=False):
@@ -121,9 +124,23 @@ def lib():
     L.mp_sampler_get_state.argtypes = [vp, dp, dp, i64p, i64p]
     L.mp_last_mean_sweeps.argtypes = [vp]
     L.mp_last_mean_sweeps.restype = C.c_double
+    L.mp_sweep_tol.argtypes = [vp]
+    L.mp_sweep_tol.restype = C.c_double
+    L.mp_n_simd.argtypes = [vp]
+    L.mp_sampler_get_bad.argtypes = [vp, dp, C.c_int, i64p]
+    L.mp_sampler_n_slots.argtypes = [vp]
+    L.mp_sampler_row_doubles.argtypes = [vp]
+    L.mp_sampler_halfstep_shard.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp]
+    L.mp_sampler_halfstep_apply.argtypes = [vp, C.c_int, vp, vp, vp, vp]
+    L.mp_sampler_state_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
+    if L.mp_abi_version() != ABI_VERSION:
+        raise MagpropAmdError(f"{LIB_PATH} has ABI version {L.mp_abi_version()}, this binding expects {ABI_VERSION}: "
+                              "rebuild it (python -c 'import __graft_entry__ as g; g.build()')")
     for name in ("mp_destroy", "mp_set_dataset", "mp_set_prior", "mp_lnprob_batch", "mp_lnprob_batch_dev",
                  "mp_model_lc", "mp_rhs_batch", "mp_synchronize", "mp_device", "mp_n_grid", "mp_sampler_destroy",
-                 "mp_sampler_set_positions", "mp_sampler_run", "mp_sampler_get_state"):
+                 "mp_sampler_set_positions", "mp_sampler_run", "mp_sampler_get_state", "mp_sampler_get_bad",
+                 "mp_sampler_n_slots", "mp_sampler_row_doubles", "mp_sampler_halfstep_shard",
+                 "mp_sampler_halfstep_apply", "mp_sampler_state_ptrs", "mp_n_simd"):
         getattr(L, name).restype = C.c_int
     _lib = L
     return L
@@ -272,3 +289,13 @@ class Handle:
     @property
     def last_mean_sweeps(self):
         return self._L.mp_last_mean_sweeps(self._h)
+
+    @property
+    def sweep_tol(self):
+        return self._L.mp_sweep_tol(self._h)
+
+    @property
+    def n_simd(self):
+        """SIMDs of the device: batches up to n_simd/2 walkers run the producer/consumer pair, up to n_simd the
+        4-steps-per-lane kernel, larger ones the 2-steps-per-lane kernel (mp_device.h)."""
+        return self._L.mp_n_simd(self._h)

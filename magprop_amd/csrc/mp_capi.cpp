@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <numeric>
 #include <string>
 #include <vector>
@@ -119,7 +120,34 @@ struct mp_handle {
     PinnedBuf h_io;
     DevBuf<double> w_scratch;   // DevShared::obs_scratch (only allocated once a light curve longer than 64 points is set)
     double last_mean_sweeps = 0.0;
+    // Threading / stream contract (include/magprop_amd.h): every entry point that takes a handle or a sampler holds
+    // `mu` for its duration.  The scratch rows are indexed by walker, so two launches that use them must not overlap:
+    // each records `scratch_done` on its stream and the next one, if it runs on another stream, waits for it there.
+    std::recursive_mutex mu;
+    hipEvent_t scratch_done = nullptr;
+    hipStream_t scratch_stream = nullptr;
+    bool scratch_busy = false;
 };
+
+namespace {
+using Lock = std::lock_guard<std::recursive_mutex>;
+
+// launch_lnprob with the scratch rows ordered across streams (only handles that hold a light curve of more than 64 points
+// have scratch rows; all others launch freely)
+int launch_lnprob_ordered(mp_handle *h, const mp::LaunchArgs &a, hipStream_t st) {
+    const bool uses_scratch = h->sh.scratch_stride > 0;
+    if (uses_scratch && h->scratch_busy && h->scratch_stream != st)
+        HIP_TRY(hipStreamWaitEvent(st, h->scratch_done, 0));
+    const int e = mp::launch_lnprob(h->sh, a, (void *)st);
+    if (e) return fail(MP_EHIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+    if (uses_scratch) {
+        HIP_TRY(hipEventRecord(h->scratch_done, st));
+        h->scratch_stream = st;
+        h->scratch_busy = true;
+    }
+    return MP_OK;
+}
+}  // namespace
 
 static int upload_datasets(mp_handle *h) {
     std::vector<mp::DsDesc> desc(MP_MAX_DATASETS, mp::DsDesc{0, 0, 0, 0});
@@ -196,12 +224,12 @@ const char *mp_last_error(void) { return g_err.c_str(); }
 
 void mp_cfg_synth(mp_model_cfg *c) {
     if (!c) return;
-    *c = mp_model_cfg{0.35, 3.0, 10.0, 10.0, 0.1, 1.0, 0.9, 1.0, 1.0, 1.0, 0.27, 1, 0};
+    *c = mp_model_cfg{0.35, 3.0, 10.0, 10.0, 0.1, 1.0, 0.9, 1.0, 1.0, 1.0, 0.27, 1, 0, 0.0};
 }
 
 void mp_cfg_lib(mp_model_cfg *c) {
     if (!c) return;
-    *c = mp_model_cfg{0.8, 1.0, 1.0, 1.0, 0.1, 1.0, 0.9, 0.05, 0.4, 1.0, 0.0, 0, 0};
+    *c = mp_model_cfg{0.8, 1.0, 1.0, 1.0, 0.1, 1.0, 0.9, 0.05, 0.4, 1.0, 0.0, 0, 0, 0.0};
 }
 
 mp_handle *mp_create(const mp_model_cfg *cfg, const double *tgrid, int n_grid, int device) {
@@ -231,6 +259,10 @@ mp_handle *mp_create(const mp_model_cfg *cfg, const double *tgrid, int n_grid, i
         fail(MP_EINVAL, "mp_create: non-positive model constant in cfg");
         return nullptr;
     }
+    if (!(cfg->sweep_tol >= 0.0) || cfg->sweep_tol > 1.0e-3) {
+        fail(MP_EINVAL, "mp_create: cfg.sweep_tol must be 0 (library default) or in (0, 1e-3]");
+        return nullptr;
+    }
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
         fail(MP_ENODEV, "mp_create: no HIP device visible (this library has no CPU fallback)");
@@ -244,9 +276,12 @@ mp_handle *mp_create(const mp_model_cfg *cfg, const double *tgrid, int n_grid, i
     mp_handle *h = new mp_handle();
     h->device = device;
     DeviceScope scope(device);
-    if (!scope.ok || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+    hipDeviceProp_t prop;
+    if (!scope.ok || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->scratch_done, hipEventDisableTiming) != hipSuccess ||
+        hipGetDeviceProperties(&prop, device) != hipSuccess) {
         fail(MP_EHIP, "mp_create: cannot select device %d / create stream", device);
-        delete h;
+        mp_destroy(h);
         return nullptr;
     }
     h->tgrid.assign(tgrid, tgrid + n_grid);
@@ -276,8 +311,8 @@ mp_handle *mp_create(const mp_model_cfg *cfg, const double *tgrid, int n_grid, i
     s.inv_sqrtGM = 1.0 / s.sqrtGM;
     s.sqrtR = std::sqrt(mp::kR);
     s.q = q;
-    s.sweep_tol = 1.0e-9;
-    s.force_wpw = 0;
+    s.sweep_tol = cfg->sweep_tol > 0.0 ? cfg->sweep_tol : MP_SWEEP_TOL_DEFAULT;
+    s.n_simd = std::max(1, prop.multiProcessorCount) * 4;         // 4 SIMDs per CU (1 024 on MI355X)
     s.force_spl = 0;
     if (const char *e = std::getenv("MAGPROP_AMD_SPL")) {          // experiments only
         const int v = std::atoi(e);
@@ -287,10 +322,6 @@ mp_handle *mp_create(const mp_model_cfg *cfg, const double *tgrid, int n_grid, i
     if (const char *e = std::getenv("MAGPROP_AMD_PC")) {           // experiments only
         const int v = std::atoi(e);
         if (v == 1 || v == -1) s.force_pc = v;
-    }
-    if (const char *e = std::getenv("MAGPROP_AMD_WPW")) {          // experiments only
-        const int v = std::atoi(e);
-        if (v == 1 || v == 2 || v == 4) s.force_wpw = v;
     }
     if (const char *e = std::getenv("MAGPROP_AMD_SWEEP_TOL")) {   // experiments only
         const double v = std::atof(e);
@@ -331,6 +362,7 @@ int mp_destroy(mp_handle *h) {
     h->w_pars.release(); h->w_lnprob.release(); h->w_curves.release();
     h->w_dsid.release(); h->w_status.release(); h->w_sweeps.release(); h->w_scratch.release();
     h->w_io.release(); h->h_io.release();
+    if (h->scratch_done) (void)hipEventDestroy(h->scratch_done);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return MP_OK;
@@ -340,6 +372,7 @@ int mp_set_dataset(mp_handle *h, int ds_id, const double *x, const double *y, co
     if (!h || !x || !y || !yerr) return fail(MP_EINVAL, "mp_set_dataset: NULL argument");
     if (ds_id < 0 || ds_id >= MP_MAX_DATASETS) return fail(MP_EINVAL, "mp_set_dataset: ds_id %d out of range", ds_id);
     if (n_obs <= 0) return fail(MP_EINVAL, "mp_set_dataset: n_obs must be positive");
+    Lock lock(h->mu);
     const std::vector<double> &t = h->tgrid;
     const int n = (int)t.size();
     for (int j = 0; j < n_obs; ++j) {
@@ -374,6 +407,7 @@ int mp_set_prior(mp_handle *h, const double *lower, const double *upper, int ndi
     if (!h) return fail(MP_EINVAL, "mp_set_prior: NULL handle");
     if (ndim < 0 || ndim > MP_MAX_NDIM) return fail(MP_EINVAL, "mp_set_prior: ndim %d out of range", ndim);
     if (ndim > 0 && (!lower || !upper)) return fail(MP_EINVAL, "mp_set_prior: NULL bounds");
+    Lock lock(h->mu);
     for (int i = 0; i < MP_MAX_NDIM; ++i) {
         h->sh.lower[i] = i < ndim ? lower[i] : -INFINITY;
         h->sh.upper[i] = i < ndim ? upper[i] : INFINITY;
@@ -395,6 +429,7 @@ int mp_lnprob_batch_dev(mp_handle *h, const double *d_pars, const int32_t *d_ds_
                         double *d_lnprob, int32_t *d_status, double *d_ltot, void *stream) {
     int rc = check_batch_args(h, d_pars, n, ndim, d_lnprob);
     if (rc) return rc;
+    Lock lock(h->mu);
     if (!d_ds_id && !h->ds[0].set) return fail(MP_ESTATE, "lnprob batch: ds_id is NULL but dataset 0 is not set");
     DeviceScope scope(h->device);
     mp::LaunchArgs a{};
@@ -408,9 +443,7 @@ int mp_lnprob_batch_dev(mp_handle *h, const double *d_pars, const int32_t *d_ds_
     a.status = d_status;
     a.ltot = d_ltot;
     if ((rc = ensure_scratch(h, n))) return rc;
-    const int e = mp::launch_lnprob(h->sh, a, stream);
-    if (e) return fail(MP_EHIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
-    return MP_OK;
+    return launch_lnprob_ordered(h, a, (hipStream_t)stream);
 }
 
 int mp_lnprob_batch(mp_handle *h, const double *pars, const int32_t *ds_id, int n, int ndim, double *lnprob_out,
@@ -418,6 +451,7 @@ int mp_lnprob_batch(mp_handle *h, const double *pars, const int32_t *ds_id, int 
     int rc = check_batch_args(h, pars, n, ndim, lnprob_out);
     if (rc) return rc;
     if (n == 0) return MP_OK;
+    Lock lock(h->mu);
     if (ds_id) {
         for (int i = 0; i < n; ++i)
             if (ds_id[i] < 0 || ds_id[i] >= MP_MAX_DATASETS || !h->ds[ds_id[i]].set)
@@ -438,7 +472,6 @@ int mp_lnprob_batch(mp_handle *h, const double *pars, const int32_t *ds_id, int 
     std::memcpy(h->h_io.p, pars, in_pars);
     if (ds_id) std::memcpy(h->h_io.p + in_pars, ds_id, in_ids);
     HIP_TRY(hipMemcpyAsync(h->w_io.p, h->h_io.p, in_pars + in_ids, hipMemcpyHostToDevice, st));
-    if (ltot_out) HIP_TRY(hipMemsetAsync(h->w_curves.p, 0xFF, sizeof(double) * (size_t)n * ng, st));  // NaN fill
     unsigned char *d_out = h->w_io.p + in_bytes, *h_out = h->h_io.p + in_bytes;
     mp::LaunchArgs a{};
     a.pars = (const double *)h->w_io.p;
@@ -450,9 +483,8 @@ int mp_lnprob_batch(mp_handle *h, const double *pars, const int32_t *ds_id, int 
     a.lnprob = (double *)d_out;
     a.status = (int32_t *)(d_out + sizeof(double) * (size_t)n);
     a.sweeps = a.status + n;
-    a.ltot = ltot_out ? h->w_curves.p : nullptr;
-    const int e = mp::launch_lnprob(h->sh, a, st);
-    if (e) return fail(MP_EHIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+    a.ltot = ltot_out ? h->w_curves.p : nullptr;   // rows of walkers that fail are NaN-filled by the kernel
+    if ((rc = launch_lnprob_ordered(h, a, st))) return rc;
     HIP_TRY(hipMemcpyAsync(h_out, d_out, out_bytes, hipMemcpyDeviceToHost, st));
     if (ltot_out)
         HIP_TRY(hipMemcpyAsync(ltot_out, h->w_curves.p, sizeof(double) * (size_t)n * ng, hipMemcpyDeviceToHost, st));
@@ -464,7 +496,7 @@ int mp_lnprob_batch(mp_handle *h, const double *pars, const int32_t *ds_id, int 
     int cnt = 0;
     for (int i = 0; i < n; ++i)
         if (status[i] == MP_STATUS_OK) { tot += sweeps[i]; ++cnt; }
-    const int ktile = mp::kTile * (h->sh.force_spl ? h->sh.force_spl : mp::kernel_spl(n));
+    const int ktile = mp::kTile * (h->sh.force_spl ? h->sh.force_spl : mp::kernel_spl(h->sh, n));
     const int kernel_tiles = ((int)h->tgrid.size() - 1 + ktile - 1) / ktile;
     h->last_mean_sweeps = cnt ? tot / ((double)cnt * kernel_tiles) : 0.0;
     return MP_OK;
@@ -473,6 +505,7 @@ int mp_lnprob_batch(mp_handle *h, const double *pars, const int32_t *ds_id, int 
 int mp_model_lc(mp_handle *h, const double *pars, int ndim, double *out, double *traj, int32_t *status) {
     if (!h || !pars || !out) return fail(MP_EINVAL, "mp_model_lc: NULL argument");
     if (ndim < 6 || ndim > MP_MAX_NDIM) return fail(MP_EINVAL, "mp_model_lc: ndim must be 6..9, got %d", ndim);
+    Lock lock(h->mu);
     DeviceScope scope(h->device);
     const size_t ng = h->tgrid.size();
     int rc;
@@ -481,7 +514,6 @@ int mp_model_lc(mp_handle *h, const double *pars, int ndim, double *out, double 
         return rc;
     hipStream_t st = h->stream;
     HIP_TRY(hipMemcpyAsync(h->w_pars.p, pars, sizeof(double) * (size_t)ndim, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemsetAsync(h->w_curves.p, 0xFF, sizeof(double) * 5 * ng, st));
     mp::LaunchArgs a{};
     a.pars = h->w_pars.p;
     a.n = 1;
@@ -495,8 +527,7 @@ int mp_model_lc(mp_handle *h, const double *pars, int ndim, double *out, double 
     a.ldip = h->w_curves.p + 2 * ng;
     a.mdisc = h->w_curves.p + 3 * ng;
     a.omega = h->w_curves.p + 4 * ng;
-    const int e = mp::launch_lnprob(h->sh, a, st);
-    if (e) return fail(MP_EHIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+    if ((rc = launch_lnprob_ordered(h, a, st))) return rc;
     int32_t stt = 0;
     std::memcpy(out, h->tgrid.data(), sizeof(double) * ng);
     HIP_TRY(hipMemcpyAsync(out + ng, h->w_curves.p, sizeof(double) * 3 * ng, hipMemcpyDeviceToHost, st));
@@ -513,6 +544,7 @@ int mp_rhs_batch(mp_handle *h, const double *pars, int ndim, const double *t, co
     if (ndim < 6 || ndim > MP_MAX_NDIM) return fail(MP_EINVAL, "mp_rhs_batch: ndim must be 6..9, got %d", ndim);
     if (n < 0) return fail(MP_EINVAL, "mp_rhs_batch: negative n");
     if (n == 0) return MP_OK;
+    Lock lock(h->mu);
     DeviceScope scope(h->device);
     // one device block: [pars n*ndim | t n | y 2n] in, [dydt 2n | lam n] out
     const size_t n_in = (size_t)n * (ndim + 3), n_out = (size_t)n * 3;
@@ -541,6 +573,7 @@ int mp_rhs_batch(mp_handle *h, const double *pars, int ndim, const double *t, co
 
 int mp_synchronize(mp_handle *h) {
     if (!h) return fail(MP_EINVAL, "mp_synchronize: NULL handle");
+    Lock lock(h->mu);
     DeviceScope scope(h->device);
     HIP_TRY(hipStreamSynchronize(h->stream));
     return MP_OK;
@@ -566,11 +599,45 @@ struct mp_sampler {
     double a = 2.0;
     uint64_t steps_done = 0;
     bool have_state = false;
-    DevBuf<double> d_pos, d_lnprob, d_chain, d_chain_lnp;
+    DevBuf<double> d_pos, d_lnprob, d_chain, d_chain_lnp, d_bad;
     DevBuf<int64_t> d_acc;
     DevBuf<int32_t> d_perm, d_dsid, d_status;
+    DevBuf<uint32_t> d_bad_count;
     PinnedBuf h_perm;   // page-locked staging of the random splits: their upload overlaps the running half-steps
+    // walker-sharded driving (mp_sampler_halfstep_shard / _apply): splits of kWin steps at a time, double-buffered
+    static constexpr int kWin = 32;
+    DevBuf<int32_t> d_win[2];
+    PinnedBuf h_win[2];
+    hipEvent_t win_copied[2] = {nullptr, nullptr};
+    int64_t win_id[2] = {-1, -1};
 };
+
+// random split of every ensemble for step `step` (emcee's randomize_split): Fisher-Yates, counter (step, ensemble, i, 'split')
+static void draw_split(const mp_sampler *s, uint64_t step64, int32_t *perm) {
+    const uint32_t step = (uint32_t)step64;
+    for (int e = 0; e < s->n_ensembles; ++e) {
+        int32_t *p = perm + (size_t)e * s->n_walkers;
+        std::iota(p, p + s->n_walkers, 0);
+        for (int i = s->n_walkers - 1; i > 0; --i) {
+            uint32_t r[4];
+            philox4x32_10((uint32_t)s->seed, (uint32_t)(s->seed >> 32), step, (uint32_t)e, (uint32_t)i, 0x5117u, r);
+            const uint64_t r64 = ((uint64_t)r[0] << 32) | r[1];
+            std::swap(p[i], p[(size_t)(r64 % (uint64_t)(i + 1))]);
+        }
+    }
+}
+
+static mp::StretchArgs stretch_args(const mp_sampler *s, const int32_t *d_perm, uint64_t step, int half) {
+    mp::StretchArgs g{};
+    g.pos = s->d_pos.p; g.lnprob = s->d_lnprob.p; g.n_accepted = s->d_acc.p;
+    g.perm = d_perm;
+    g.ds_id = s->d_dsid.p;
+    g.n_walkers = s->n_walkers; g.n_half = s->n_walkers / 2; g.n_ensembles = s->n_ensembles;
+    g.n_total = s->n_total; g.ndim = s->ndim; g.half = half; g.target = s->target;
+    g.step = (uint32_t)step; g.seed = s->seed; g.a = s->a;
+    g.bad_log = s->d_bad.p; g.bad_count = s->d_bad_count.p; g.bad_cap = (uint32_t)(s->d_bad.cap / (size_t)std::max(s->ndim, 1));
+    return g;
+}
 
 mp_sampler *mp_sampler_create(mp_handle *h, int n_walkers, int n_ensembles, int ndim, const int32_t *ens_ds_id,
                               uint64_t seed, double a, int target) {
@@ -581,6 +648,7 @@ mp_sampler *mp_sampler_create(mp_handle *h, int n_walkers, int n_ensembles, int 
         return nullptr;
     }
     if (!(a > 1.0)) { fail(MP_EINVAL, "mp_sampler_create: stretch scale a must exceed 1"); return nullptr; }
+    Lock lock(h->mu);
     if (target == 0) {
         for (int e = 0; e < n_ensembles; ++e) {
             const int d = ens_ds_id ? ens_ds_id[e] : 0;
@@ -598,10 +666,14 @@ mp_sampler *mp_sampler_create(mp_handle *h, int n_walkers, int n_ensembles, int 
     std::vector<int32_t> ds(nt, 0);
     for (int e = 0; e < n_ensembles; ++e)
         for (int k = 0; k < n_walkers; ++k) ds[(size_t)e * n_walkers + k] = ens_ds_id ? ens_ds_id[e] : 0;
+    constexpr size_t kBadRows = 4096;   // failed proposals kept for mp_sampler_get_bad (the count itself is exact)
     if (s->d_pos.ensure(nt * ndim) || s->d_lnprob.ensure(nt) || s->d_acc.ensure(nt) || s->d_dsid.ensure(nt) ||
-        s->d_status.ensure(nt) ||
+        s->d_status.ensure(nt) || s->d_bad.ensure(kBadRows * ndim) || s->d_bad_count.ensure(1) ||
         hipMemcpy(s->d_dsid.p, ds.data(), nt * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemset(s->d_acc.p, 0, nt * sizeof(int64_t)) != hipSuccess) {
+        hipMemset(s->d_acc.p, 0, nt * sizeof(int64_t)) != hipSuccess ||
+        hipMemset(s->d_bad_count.p, 0, sizeof(uint32_t)) != hipSuccess ||
+        hipEventCreateWithFlags(&s->win_copied[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&s->win_copied[1], hipEventDisableTiming) != hipSuccess) {
         fail(MP_EHIP, "mp_sampler_create: device allocation failed");
         mp_sampler_destroy(s);
         return nullptr;
@@ -611,10 +683,16 @@ mp_sampler *mp_sampler_create(mp_handle *h, int n_walkers, int n_ensembles, int 
 
 int mp_sampler_destroy(mp_sampler *s) {
     if (!s) return MP_OK;
+    Lock lock(s->h->mu);
     DeviceScope scope(s->h->device);
-    (void)hipStreamSynchronize(s->h->stream);
+    (void)hipDeviceSynchronize();
     s->d_pos.release(); s->d_lnprob.release(); s->d_chain.release(); s->d_chain_lnp.release();
     s->d_acc.release(); s->d_perm.release(); s->d_dsid.release(); s->d_status.release(); s->h_perm.release();
+    s->d_bad.release(); s->d_bad_count.release();
+    for (int b = 0; b < 2; ++b) {
+        s->d_win[b].release(); s->h_win[b].release();
+        if (s->win_copied[b]) (void)hipEventDestroy(s->win_copied[b]);
+    }
     delete s;
     return MP_OK;
 }
@@ -622,10 +700,12 @@ int mp_sampler_destroy(mp_sampler *s) {
 int mp_sampler_set_positions(mp_sampler *s, const double *pos) {
     if (!s || !pos) return fail(MP_EINVAL, "mp_sampler_set_positions: NULL argument");
     mp_handle *h = s->h;
+    Lock lock(h->mu);
     DeviceScope scope(h->device);
     const size_t nt = (size_t)s->n_total;
     for (size_t i = 0; i < nt * s->ndim; ++i)
         if (!std::isfinite(pos[i])) return fail(MP_EINVAL, "mp_sampler_set_positions: non-finite coordinate");
+    HIP_TRY(hipDeviceSynchronize());   // the sharded entry points may have work in flight on a caller's stream
     HIP_TRY(hipMemcpyAsync(s->d_pos.p, pos, nt * s->ndim * sizeof(double), hipMemcpyHostToDevice, h->stream));
     if (s->target == 1) {
         std::vector<double> lp(nt, 0.0);
@@ -637,10 +717,9 @@ int mp_sampler_set_positions(mp_sampler *s, const double *pos) {
         mp::LaunchArgs a{};
         a.pars = s->d_pos.p; a.ds_id = s->d_dsid.p; a.n = s->n_total; a.ndim = s->ndim; a.want_chi2 = 1;
         a.lnprob = s->d_lnprob.p; a.status = s->d_status.p;
-        const int rc = ensure_scratch(h, s->n_total);
+        int rc = ensure_scratch(h, s->n_total);
         if (rc) return rc;
-        const int e = mp::launch_lnprob(h->sh, a, h->stream);
-        if (e) return fail(MP_EHIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+        if ((rc = launch_lnprob_ordered(h, a, h->stream))) return rc;
         HIP_TRY(hipStreamSynchronize(h->stream));
     }
     s->have_state = true;
@@ -652,6 +731,7 @@ int mp_sampler_run(mp_sampler *s, int n_steps, double *chain, double *chain_lnpr
     if (!s->have_state) return fail(MP_ESTATE, "mp_sampler_run: call mp_sampler_set_positions first");
     if ((chain == nullptr) != (chain_lnprob == nullptr)) return fail(MP_EINVAL, "mp_sampler_run: chain and chain_lnprob go together");
     mp_handle *h = s->h;
+    Lock lock(h->mu);
     DeviceScope scope(h->device);
     const size_t nt = (size_t)s->n_total, row = nt * s->ndim;
     // chunks of steps so that the device-resident chain slab stays below ~256 MB (and the splits below ~64 MB)
@@ -662,6 +742,8 @@ int mp_sampler_run(mp_sampler *s, int n_steps, double *chain, double *chain_lnpr
     constexpr int kSub = 8;   // steps per batch of splits: the host draws the next batch while the GPU runs this one
     int rc;
     if ((rc = ensure_scratch(h, s->n_total))) return rc;
+    if (h->sh.scratch_stride > 0 && h->scratch_busy && h->scratch_stream != h->stream)
+        HIP_TRY(hipStreamWaitEvent(h->stream, h->scratch_done, 0));
     for (int done = 0; done < n_steps;) {
         const int chunk = std::min(chunk_max, n_steps - done);
         if ((rc = s->h_perm.ensure((size_t)chunk * nt * sizeof(int32_t))) || (rc = s->d_perm.ensure((size_t)chunk * nt))) return rc;
@@ -671,34 +753,16 @@ int mp_sampler_run(mp_sampler *s, int n_steps, double *chain, double *chain_lnpr
         }
         for (int sub = 0; sub < chunk; sub += kSub) {
             const int sub_end = std::min(chunk, sub + kSub);
-            // random split of every ensemble for these steps (emcee's randomize_split)
-            for (int st = sub; st < sub_end; ++st)
-                for (int e = 0; e < s->n_ensembles; ++e) {
-                    int32_t *p = perm + (size_t)st * nt + (size_t)e * s->n_walkers;
-                    std::iota(p, p + s->n_walkers, 0);
-                    const uint32_t step = (uint32_t)(s->steps_done + (uint64_t)st);
-                    for (int i = s->n_walkers - 1; i > 0; --i) {   // Fisher-Yates, counter (step, ensemble, i, 'split')
-                        uint32_t r[4];
-                        philox4x32_10((uint32_t)s->seed, (uint32_t)(s->seed >> 32), step, (uint32_t)e, (uint32_t)i, 0x5117u, r);
-                        const uint64_t r64 = ((uint64_t)r[0] << 32) | r[1];
-                        std::swap(p[i], p[(size_t)(r64 % (uint64_t)(i + 1))]);
-                    }
-                }
+            for (int st = sub; st < sub_end; ++st) draw_split(s, s->steps_done + (uint64_t)st, perm + (size_t)st * nt);
             HIP_TRY(hipMemcpyAsync(s->d_perm.p + (size_t)sub * nt, perm + (size_t)sub * nt,
                                    (size_t)(sub_end - sub) * nt * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
             for (int st = sub; st < sub_end; ++st) {
                 for (int half = 0; half < 2; ++half) {
-                    mp::StretchArgs g{};
-                    g.pos = s->d_pos.p; g.lnprob = s->d_lnprob.p; g.n_accepted = s->d_acc.p;
-                    g.perm = s->d_perm.p + (size_t)st * nt;
-                    g.ds_id = s->d_dsid.p;
+                    mp::StretchArgs g = stretch_args(s, s->d_perm.p + (size_t)st * nt, s->steps_done + (uint64_t)st, half);
                     g.chain = chain ? s->d_chain.p : nullptr;
                     g.chain_lnp = chain ? s->d_chain_lnp.p : nullptr;
                     g.chain_row = st;
-                    g.n_walkers = s->n_walkers; g.n_half = s->n_walkers / 2; g.n_ensembles = s->n_ensembles;
-                    g.n_total = s->n_total; g.ndim = s->ndim; g.half = half; g.target = s->target;
-                    g.step = (uint32_t)(s->steps_done + (uint64_t)st); g.seed = s->seed; g.a = s->a;
-                    const int e = mp::launch_stretch(h->sh, g, h->stream);
+                    const int e = mp::launch_stretch(h->sh, g, g.n_half * g.n_ensembles, h->stream);
                     if (e) return fail(MP_EHIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
                 }
             }
@@ -707,6 +771,11 @@ int mp_sampler_run(mp_sampler *s, int n_steps, double *chain, double *chain_lnpr
             HIP_TRY(hipMemcpyAsync(chain + (size_t)done * row, s->d_chain.p, (size_t)chunk * row * sizeof(double), hipMemcpyDeviceToHost, h->stream));
             HIP_TRY(hipMemcpyAsync(chain_lnprob + (size_t)done * nt, s->d_chain_lnp.p, (size_t)chunk * nt * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         }
+        if (h->sh.scratch_stride > 0) {
+            HIP_TRY(hipEventRecord(h->scratch_done, h->stream));
+            h->scratch_stream = h->stream;
+            h->scratch_busy = true;
+        }
         HIP_TRY(hipStreamSynchronize(h->stream));
         s->steps_done += (uint64_t)chunk;
         done += chunk;
@@ -714,12 +783,113 @@ int mp_sampler_run(mp_sampler *s, int n_steps, double *chain, double *chain_lnpr
     return MP_OK;
 }
 
+// ---- walker-sharded driving: the caller (one process per GPU) runs, per half-step,
+//        mp_sampler_halfstep_shard(its block of slots) -> all-gather of the outcome rows -> mp_sampler_halfstep_apply.
+// Device pointer of the split of the current step; uploads the next window of kWin splits when the step enters it.
+static int current_split(mp_sampler *s, hipStream_t st, const int32_t **d_perm) {
+    const size_t nt = (size_t)s->n_total;
+    const int64_t win = (int64_t)(s->steps_done / mp_sampler::kWin);
+    const int b = (int)(win & 1);
+    if (s->win_id[b] != win) {
+        int rc;
+        const size_t bytes = (size_t)mp_sampler::kWin * nt * sizeof(int32_t);
+        if ((rc = s->h_win[b].ensure(bytes)) || (rc = s->d_win[b].ensure((size_t)mp_sampler::kWin * nt))) return rc;
+        if (s->win_id[b] >= 0) HIP_TRY(hipEventSynchronize(s->win_copied[b]));   // staged two windows ago: long done
+        int32_t *perm = (int32_t *)s->h_win[b].p;
+        for (int i = 0; i < mp_sampler::kWin; ++i)
+            draw_split(s, (uint64_t)win * mp_sampler::kWin + (uint64_t)i, perm + (size_t)i * nt);
+        // stream order puts the copy behind every kernel that still reads this buffer's previous contents
+        HIP_TRY(hipMemcpyAsync(s->d_win[b].p, perm, bytes, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipEventRecord(s->win_copied[b], st));
+        s->win_id[b] = win;
+    }
+    *d_perm = s->d_win[b].p + (size_t)(s->steps_done % mp_sampler::kWin) * nt;
+    return MP_OK;
+}
+
+int mp_sampler_row_doubles(const mp_sampler *s) { return s ? s->ndim + 3 : 0; }
+int mp_sampler_n_slots(const mp_sampler *s) { return s ? (s->n_walkers / 2) * s->n_ensembles : 0; }
+
+int mp_sampler_halfstep_shard(mp_sampler *s, int half, int slot_lo, int slot_hi, double *d_rows, void *stream) {
+    if (!s || (half != 0 && half != 1)) return fail(MP_EINVAL, "mp_sampler_halfstep_shard: bad argument");
+    if (!s->have_state) return fail(MP_ESTATE, "mp_sampler_halfstep_shard: call mp_sampler_set_positions first");
+    const int n_slots = (s->n_walkers / 2) * s->n_ensembles;
+    if (slot_lo < 0 || slot_hi > n_slots || slot_lo > slot_hi) return fail(MP_EINVAL, "mp_sampler_halfstep_shard: slots [%d, %d) outside [0, %d)", slot_lo, slot_hi, n_slots);
+    if (slot_hi > slot_lo && !d_rows) return fail(MP_EINVAL, "mp_sampler_halfstep_shard: NULL row buffer");
+    mp_handle *h = s->h;
+    Lock lock(h->mu);
+    DeviceScope scope(h->device);
+    hipStream_t st = (hipStream_t)stream;
+    const int32_t *d_perm = nullptr;
+    int rc;
+    if ((rc = current_split(s, st, &d_perm)) || (rc = ensure_scratch(h, s->n_total))) return rc;
+    if (slot_hi == slot_lo) return MP_OK;
+    const bool uses_scratch = h->sh.scratch_stride > 0;
+    if (uses_scratch && h->scratch_busy && h->scratch_stream != st) HIP_TRY(hipStreamWaitEvent(st, h->scratch_done, 0));
+    mp::StretchArgs g = stretch_args(s, d_perm, s->steps_done, half);
+    g.upd = d_rows;
+    g.slot_lo = slot_lo;
+    const int e = mp::launch_stretch(h->sh, g, slot_hi - slot_lo, stream);
+    if (e) return fail(MP_EHIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+    if (uses_scratch) {
+        HIP_TRY(hipEventRecord(h->scratch_done, st));
+        h->scratch_stream = st;
+        h->scratch_busy = true;
+    }
+    return MP_OK;
+}
+
+int mp_sampler_halfstep_apply(mp_sampler *s, int half, const double *d_rows, double *d_chain_row, double *d_chain_lnp_row,
+                              void *stream) {
+    if (!s || !d_rows || (half != 0 && half != 1)) return fail(MP_EINVAL, "mp_sampler_halfstep_apply: bad argument");
+    if ((d_chain_row == nullptr) != (d_chain_lnp_row == nullptr)) return fail(MP_EINVAL, "mp_sampler_halfstep_apply: chain row and lnprob row go together");
+    if (!s->have_state) return fail(MP_ESTATE, "mp_sampler_halfstep_apply: call mp_sampler_set_positions first");
+    mp_handle *h = s->h;
+    Lock lock(h->mu);
+    DeviceScope scope(h->device);
+    const int32_t *d_perm = nullptr;
+    int rc;
+    if ((rc = current_split(s, (hipStream_t)stream, &d_perm))) return rc;
+    mp::StretchArgs g = stretch_args(s, d_perm, s->steps_done, half);
+    g.upd = const_cast<double *>(d_rows);
+    g.chain = d_chain_row;
+    g.chain_lnp = d_chain_lnp_row;
+    g.chain_row = 0;
+    const int e = mp::launch_stretch_apply(g, stream);
+    if (e) return fail(MP_EHIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+    if (half == 1) s->steps_done += 1;
+    return MP_OK;
+}
+
+int mp_sampler_state_ptrs(mp_sampler *s, double **d_pos, double **d_lnprob) {
+    if (!s) return fail(MP_EINVAL, "mp_sampler_state_ptrs: NULL sampler");
+    if (d_pos) *d_pos = s->d_pos.p;
+    if (d_lnprob) *d_lnprob = s->d_lnprob.p;
+    return MP_OK;
+}
+
+int mp_sampler_get_bad(mp_sampler *s, double *pars, int max_rows, int64_t *n_bad) {
+    if (!s || max_rows < 0 || (max_rows > 0 && !pars)) return fail(MP_EINVAL, "mp_sampler_get_bad: bad argument");
+    mp_handle *h = s->h;
+    Lock lock(h->mu);
+    DeviceScope scope(h->device);
+    HIP_TRY(hipDeviceSynchronize());
+    uint32_t cnt = 0;
+    HIP_TRY(hipMemcpy(&cnt, s->d_bad_count.p, sizeof cnt, hipMemcpyDeviceToHost));
+    if (n_bad) *n_bad = (int64_t)cnt;
+    const size_t cap = s->d_bad.cap / (size_t)s->ndim;
+    const size_t rows = std::min<size_t>(std::min<size_t>(cnt, cap), (size_t)max_rows);
+    if (rows) HIP_TRY(hipMemcpy(pars, s->d_bad.p, rows * s->ndim * sizeof(double), hipMemcpyDeviceToHost));
+    return (int)rows;
+}
+
 int mp_sampler_get_state(mp_sampler *s, double *pos, double *lnprob, int64_t *n_accepted, int64_t *steps_done) {
     if (!s) return fail(MP_EINVAL, "mp_sampler_get_state: NULL sampler");
     mp_handle *h = s->h;
+    Lock lock(h->mu);
     DeviceScope scope(h->device);
     const size_t nt = (size_t)s->n_total;
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipDeviceSynchronize());
     if (pos) HIP_TRY(hipMemcpy(pos, s->d_pos.p, nt * s->ndim * sizeof(double), hipMemcpyDeviceToHost));
     if (lnprob) HIP_TRY(hipMemcpy(lnprob, s->d_lnprob.p, nt * sizeof(double), hipMemcpyDeviceToHost));
     if (n_accepted) HIP_TRY(hipMemcpy(n_accepted, s->d_acc.p, nt * sizeof(int64_t), hipMemcpyDeviceToHost));
@@ -731,5 +901,7 @@ int mp_device(const mp_handle *h) { return h ? h->device : -1; }
 void *mp_stream(const mp_handle *h) { return h ? (void *)h->stream : nullptr; }
 int mp_n_grid(const mp_handle *h) { return h ? (int)h->tgrid.size() : 0; }
 double mp_last_mean_sweeps(const mp_handle *h) { return h ? h->last_mean_sweeps : 0.0; }
+double mp_sweep_tol(const mp_handle *h) { return h ? h->sh.sweep_tol : 0.0; }
+int mp_n_simd(const mp_handle *h) { return h ? h->sh.n_simd : 0; }
 
 }  // extern "C"

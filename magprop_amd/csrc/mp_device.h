@@ -52,7 +52,7 @@ struct DevShared {
     // geometric grid: ratio q = t_{j+1}/t_j and the exponential Adams-Moulton quadrature matrix for it
     double q, inv_q;
     double sweep_tol;     // relative change of the step-end values that ends the Newton sweeps of a tile
-    int32_t force_wpw;    // experiments: 0 = automatic, else wavefronts per walker (1, 2, 4)
+    int32_t n_simd;       // SIMDs of the device (multiProcessorCount x 4): batch sizes up to this get one wave per SIMD
     int32_t force_spl;    // experiments: 0 = automatic, else steps per lane of the one-wavefront kernels (2, 4)
     double eamW[4][4];
     mp_model_cfg cfg;
@@ -85,6 +85,12 @@ struct StretchArgs {
     const int32_t *ds_id;   // [n_total] or nullptr (dataset 0)
     double *chain;          // [n_rows][n_total][ndim] or nullptr
     double *chain_lnp;      // [n_rows][n_total]
+    double *upd;            // nullptr: update in place.  Else outcome rows [slots][ndim + 3] = (proposal, lnprob, accepted,
+                            // status): written by stretch_kernel (row = slot - slot_lo), read by stretch_apply_kernel (row = slot)
+    double *bad_log;        // [bad_cap][ndim] or nullptr: proposals inside the prior whose model failed (the reference's fbad file)
+    uint32_t *bad_count;    // number of such proposals so far (may exceed bad_cap)
+    uint32_t bad_cap;
+    int32_t slot_lo;        // first slot of the active half (all ensembles flattened) covered by this launch
     int32_t chain_row;
     int32_t n_walkers;      // walkers per ensemble (even)
     int32_t n_half;         // n_walkers / 2
@@ -100,14 +106,11 @@ struct StretchArgs {
 };
 
 // Steps per lane of the kernel variant used for a batch of n walkers (tiles are 64*spl steps): see launch_lnprob.
-inline int kernel_spl(int n) { return n <= 1024 ? 4 : 2; }   // 1 024 SIMDs: beyond one wave each, two resident waves win (tools/spl_scan.sh)
-// Barrier-coupled wavefronts per walker (walker_eval_mw).  Superseded by the producer/consumer pair, which is 5 % faster
-// at every batch size that leaves SIMDs idle; still built and selectable with MAGPROP_AMD_WPW=4 (tests keep it honest).
-inline int waves_per_walker(int) { return 1; }
+// Up to one wave per SIMD (256 CUs x 4 on MI355X) four steps per lane; beyond, two resident waves win (tools/spl_scan.sh).
+inline int kernel_spl(const DevShared &sh, int n) { return n <= sh.n_simd ? 4 : 2; }
 
-// Producer/consumer pair of wavefronts per walker: pays when every wavefront still gets a SIMD of its own
-// (1 024 SIMDs: up to 512 walkers).
-inline bool two_wave_pair(int n) { return n <= 512; }
+// Producer/consumer pair of wavefronts per walker: pays while every wavefront still gets a SIMD of its own.
+inline bool two_wave_pair(const DevShared &sh, int n) { return 2 * n <= sh.n_simd; }
 
 // Arguments of the batched right-hand-side evaluation (mp_kernels.hip: rhs_kernel), device pointers.
 struct RhsArgs {
@@ -123,6 +126,7 @@ struct RhsArgs {
 // implemented in mp_kernels.hip; returns hipError_t as int
 int launch_rhs(const DevShared &sh, const RhsArgs &r, void *stream);
 int launch_lnprob(const DevShared &sh, const LaunchArgs &a, void *stream);
-int launch_stretch(const DevShared &sh, const StretchArgs &g, void *stream);
+int launch_stretch(const DevShared &sh, const StretchArgs &g, int n_blocks, void *stream);
+int launch_stretch_apply(const StretchArgs &g, void *stream);
 
 }  // namespace mp

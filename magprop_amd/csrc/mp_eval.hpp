@@ -1,5 +1,5 @@
-// mp_eval.hpp — evaluation of ONE walker's log-posterior on a wavefront (walker_eval) or on the W wavefronts of a
-// workgroup (walker_eval_mw): physics of the reference's RHS / luminosity stage in simplified algebra and the
+// mp_eval.hpp — evaluation of ONE walker's log-posterior on a wavefront (walker_eval; optionally fed by a producer
+// wavefront, walker_produce): physics of the reference's RHS / luminosity stage in simplified algebra and the
 // time-parallel exponential Adams-Moulton solver.  Included by mp_kernels.hip only.
 #pragma once
 #include "mp_math.hpp"
@@ -368,7 +368,6 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
     }
     double cf0, cf1, cf2, cw1 = om_s, cw2 = om_s, cw3 = om_s, cw4 = om_s;   // (omega_dot, omega) history; cw0 == om_s (cw3, cw4: predictor only)
     double L_s, Lp_s, Ld_s;
-    bool L_valid = true;          // L_s holds the luminosity at the current tile start
     {
         const Vd<1> Mv{{M_s}}, ov{{om_s}};
         const DiscPt<1> d_s = disc_point(sh, w, Mv);
@@ -652,31 +651,42 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 if (long_lc) { j0 = max(tptr[tile * kSPL], 64); j1 = tptr[min((tile + 1) * kSPL, sh.n_tiles)]; }   // 64-step buckets
                 const bool tile_has_obs = __any(mine) || j1 > j0;
                 Vd<kSPL> Lt, Lp, Ld;
-                if (CURVES || tile_has_obs) luminosity(sh, w, d1, wg, Lt, Lp, Ld);
+                luminosity(sh, w, d1, wg, Lt, Lp, Ld);
+                // The tile of the light curve is staged in LDS ([e + 1] = step end e, [0] = the tile's start point) for
+                // the interpolation and leaves for HBM from there with lane-contiguous addresses: every store
+                // instruction of the wavefront writes 512 consecutive bytes of the walker's row.
+                const int n_here = min(kTile, nsteps - tile * kTile);          // step ends of this tile that exist
+                const size_t o0 = row + (size_t)tile * kTile + 1;
+                double *S2 = Lbuf + kTile + 1;                                  // second staging area
 #pragma unroll
-                for (int s = 0; s < kSPL; ++s) {
-                    if (CURVES && active[s]) {
-                        const size_t o = row + (size_t)(i0 + s) + 1;
-                        if (a.ltot) a.ltot[o] = Lt[s] / 1.0e50;
-                        if (a.lprop) a.lprop[o] = Lp[s] / 1.0e50;
-                        if (a.ldip) a.ldip[o] = Ld[s] / 1.0e50;
-                        if (a.mdisc) a.mdisc[o] = M1[s];
-                        if (a.omega) a.omega[o] = wg[s];
+                for (int s = 0; s < kSPL; ++s) Lbuf[lane * kSPL + s + 1] = Lt[s];
+                if (lane == 0) Lbuf[0] = L_s;
+                __syncthreads();
+                if (a.ltot) {
+#pragma unroll
+                    for (int c = 0; c < kSPL; ++c) {
+                        const int e = c * 64 + lane;
+                        if (e < n_here) a.ltot[o0 + e] = Lbuf[e + 1] / 1.0e50;
                     }
                 }
-                if (tile_has_obs) {
+                // the other curves (mp_model_lc only) go through the second staging area, one at a time
+                auto put = [&](double *dst, const Vd<kSPL> &v, double div) {
+                    if (!dst) return;                                           // wave-uniform
 #pragma unroll
-                    for (int s = 0; s < kSPL; ++s) Lbuf[lane * kSPL + s + 1] = Lt[s];
-                    if (!L_valid) {   // the previous tile skipped its luminosity stage: evaluate its end point now
-                        const Vd<1> Mv{{M_s}}, ov{{om_s}};
-                        const DiscPt<1> dps = disc_point(sh, w, Mv);
-                        Vd<1> l0, l1, l2;
-                        luminosity(sh, w, dps, ov, l0, l1, l2);
-                        L_s = l0[0];
-                        L_valid = true;
-                    }
-                    if (lane == 0) Lbuf[0] = L_s;
+                    for (int s = 0; s < kSPL; ++s) S2[lane * kSPL + s] = v[s];
                     __syncthreads();
+#pragma unroll
+                    for (int c = 0; c < kSPL; ++c) {
+                        const int e = c * 64 + lane;
+                        if (e < n_here) dst[o0 + e] = S2[e] / div;
+                    }
+                    __syncthreads();
+                };
+                put(a.lprop, Lp, 1.0e50);
+                put(a.ldip, Ld, 1.0e50);
+                put(a.mdisc, M1, 1.0);
+                put(a.omega, wg, 1.0);
+                if (tile_has_obs) {
                     if (mine) {
                         const int g = ob_g - tile * kTile;
                         const double La = Lbuf[g], Lb = Lbuf[g + 1];
@@ -692,10 +702,9 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                         const double res = (sh.obs_y[jj] - mod) / sh.obs_yerr[jj];
                         chi = fma(res, res, chi);
                     }
-                    __syncthreads();
                 }
-                L_valid = CURVES || tile_has_obs;
-                if (L_valid) L_s = lane_bcast(Lt[kSPL - 1], 63);
+                __syncthreads();                                                // the next tile overwrites the staging area
+                L_s = lane_bcast(Lt[kSPL - 1], 63);
             }
 
             // ---------------- carry the tile end (and the history behind it) to the next tile: only full tiles
@@ -746,375 +755,25 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
 
     if constexpr (ROLE == 1) ring_store(&ring->abort, 1);   // done (or failed): release the producer
 
+    if constexpr (CURVES) {
+        // A walker that did not finish (prior, flag, non-finite) leaves NaN in every requested curve: the rows of a
+        // device-pointer call are defined for every status, and the host entry needs no memset of the output.
+        if (status != MP_STATUS_OK) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this wavefront's earlier stores to the row have landed
+            const double qnan = __longlong_as_double(0x7FF8000000000000ll);
+            for (int i = lane; i < n_grid; i += 64) {
+                if (a.ltot) a.ltot[row + i] = qnan;
+                if (a.lprop) a.lprop[row + i] = qnan;
+                if (a.ldip) a.ldip[row + i] = qnan;
+                if (a.mdisc) a.mdisc[row + i] = qnan;
+                if (a.omega) a.omega[row + i] = qnan;
+            }
+        }
+    }
+
     double lnp = -INFINITY;
     if (status == MP_STATUS_OK) {
         lnp = -0.5 * wave_sum(chi);
-        if (!isfinite(lnp)) { lnp = -INFINITY; status = MP_STATUS_NONFINITE; }
-    }
-    lnp_out = lnp;
-    status_out = status;
-    sweeps_out = sweeps_total;
-}
-
-// ---------------------------------------------------------------- W wavefronts per walker
-// Small batches cannot give every SIMD a walker (256 CUs x 4 SIMDs): the stretch move only ever has half an
-// ensemble in flight, and the reference's own configuration has 24 walkers.  walker_eval_mw spreads ONE walker
-// over the W wavefronts of a 64*W-thread workgroup: a tile is 64*W*SPL steps, every lane still owns SPL
-// consecutive steps, the wavefront scans stay in DPP, and what has to cross wavefronts goes through LDS:
-//   - the step history (Mdotfb, omega_dot, omega at the three previous grid points) is read from an LDS image
-//     of the tile instead of the neighbouring lane;
-//   - the affine scan is completed with the per-wavefront totals;
-//   - loop exits are agreed with __syncthreads_or.
-// Same scheme, same arithmetic per step as walker_eval; only the tile length differs (results agree to
-// rounding, like the SPL variants).  lds: [2*(kTile+3) + 2*W + (kTile+1) + 16] doubles, see MwLds.
-template <int SPL, int W>
-struct MwLds {
-    static constexpr int kTile = 64 * W * SPL;
-    double s[kTile + 3];        // Mdotfb at step ends e = -3..kTile-1, stored at [e + 3]
-    double f[kTile + 3];        // omega_dot
-    double w[kTile + 3];        // omega
-    double tot[2][2 * W];       // per-wavefront scan totals (a, b); double-buffered by use
-    int flags[2][W];            // per-wavefront (pending | flagged << 1); double-buffered by sweep
-    double L[2][kTile + 1];     // (Mdisc, omega) at the tile's grid points (start point first), for the observations
-    double carry[2][16];        // tile-end state for the next tile; double-buffered by tile
-    int fail[2][2 * W];         // per-wavefront first non-finite / first over-limit lane; double-buffered by tile
-};
-
-// Complete a wavefront-level affine scan across the W wavefronts of the workgroup: x_wave = value at this
-// wavefront's first step start, given the tile's start value x0.  One barrier.
-template <int W>
-MP_DEV void scan_affine_block(double &A, double &B, double (&tot)[2 * W], int wave, int lane, double x0, double &x_wave) {
-    scan_affine(A, B);
-    if (lane == 63) { tot[2 * wave] = A; tot[2 * wave + 1] = B; }
-    __syncthreads();
-    double xw = x0;
-#pragma unroll
-    for (int v = 0; v < W; ++v)
-        if (v < wave) xw = fma(tot[2 * v], xw, tot[2 * v + 1]);
-    x_wave = xw;
-}
-
-template <int SPL, int W, bool LONG>
-MP_DEV void walker_eval_mw(const DevShared &sh, const LaunchArgs &a, int walker, double (&par)[MP_MAX_NDIM], MwLds<SPL, W> &lds,
-                           double &lnp_out, int &status_out, int &sweeps_out) {
-    constexpr int kSPL = SPL, kTile = 64 * W * SPL, kMaxSweeps = kTile + kMaxSweepsMargin;
-    const int n_tiles = (sh.n_grid - 1 + kTile - 1) / kTile;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, gl = threadIdx.x;
-    const int nsteps = sh.n_grid - 1;
-
-    Walker w;
-    int status = walker_setup(sh, a, par, w);
-
-    const double t0 = sh.tgrid[0];
-    double M_s = par[2] * kMsol;
-    double om_s = (2.0 * M_PI) / (1.0e-3 * par[1]);
-    double cS0, cS1, cS2;
-    {
-        const Vd<3> tg{{t0, t0 * sh.inv_q, t0 * sh.inv_q * sh.inv_q}};
-        const Vd<3> Sg = mdot_fb(w, tg);
-        cS0 = Sg[0]; cS1 = Sg[1]; cS2 = Sg[2];
-    }
-    double cf0, cf1, cf2, cw1 = om_s, cw2 = om_s, cw3 = om_s, cw4 = om_s;
-    {
-        const Vd<1> Mv{{M_s}}, ov{{om_s}};
-        const DiscPt<1> d_s = disc_point(sh, w, Mv);
-        Vd<1> rot0, dummy;
-        cf0 = omega_rhs<false>(sh, w, d_s, ov, rot0, dummy)[0];
-        cf1 = cf2 = cf0;
-        if (status == MP_STATUS_OK) {
-            if (!(isfinite(M_s) && isfinite(om_s)) || M_s <= 0.0 || om_s <= 0.0) status = MP_STATUS_NONFINITE;
-            else if (rot0[0] > 0.27) status = MP_STATUS_FLAG;
-        }
-    }
-
-    const int dsid = a.ds_id ? a.ds_id[walker] : 0;
-    const DsDesc dsd = sh.ds ? sh.ds[(dsid >= 0 && dsid < sh.n_ds) ? dsid : 0] : DsDesc{0, 0, 0, 0};
-    const int32_t *tptr = sh.tile_ptr + dsd.tile_off;
-    constexpr int kRes = 64 * W;                     // observations resident in registers (one per lane of the workgroup)
-    int ob_g = -1;
-    double ob_dx = 0.0, ob_idt = 0.0, ob_y = 0.0, ob_ye = 1.0;
-    if (a.want_chi2 && gl < dsd.n_obs) {
-        const int jj = dsd.obs_off + gl;
-        ob_g = sh.obs_g[jj]; ob_dx = sh.obs_dx[jj]; ob_idt = sh.obs_idt[jj]; ob_y = sh.obs_y[jj]; ob_ye = sh.obs_yerr[jj];
-    }
-    const int ob_tile = ob_g >= 0 ? ob_g / kTile : -1;
-    const bool long_lc = LONG && a.want_chi2 && dsd.n_obs > kRes;
-    const bool deferred = a.want_chi2;                          // see walker_eval: the luminosity stage runs after the last tile
-    const size_t sc_stride = (size_t)sh.scratch_stride;
-    double *sc = sh.obs_scratch + (size_t)walker * 4 * sc_stride;   // [4][stride]: observation j >= kRes at column j - 64
-    double obM[2] = {1.0e30, 1.0e30}, obW[2] = {1.0e3, 1.0e3};
-    double chi = 0.0;
-    int sweeps_total = 0;
-    int tp = 0;      // buffer parity of the scan totals
-    int fp = 0;      // buffer parity of the sweep flags
-
-    if (status == MP_STATUS_OK) {
-        double tb_next[kSPL];
-#pragma unroll
-        for (int s = 0; s < kSPL; ++s) tb_next[s] = sh.tgrid[min(gl * kSPL + s + 1, nsteps)];
-        double ta_next = sh.tgrid[min(gl * kSPL, nsteps)];
-
-        for (int tile = 0; tile < n_tiles; ++tile) {
-            const int i0 = tile * kTile + gl * kSPL;
-            const int e0 = gl * kSPL;                    // index of this lane's first step inside the tile
-            const int tq = tile & 1;                     // buffer parity of the per-tile LDS regions
-            Vd<kSPL> tb, h;
-#pragma unroll
-            for (int s = 0; s < kSPL; ++s) {
-                tb[s] = tb_next[s];
-                tb_next[s] = sh.tgrid[min(i0 + kTile + s + 1, nsteps)];
-            }
-            const double ta0 = ta_next;
-            ta_next = sh.tgrid[min(i0 + kTile, nsteps)];
-#pragma unroll
-            for (int s = 0; s < kSPL; ++s) h[s] = tb[s] - (s == 0 ? ta0 : tb[s - 1]);   // 0 for the padding steps
-
-            // ---------------- Mdisc (2 barriers)
-            Vd<kSPL> M1;
-            double ES[kSPL + 3];
-            {
-                const Vd<kSPL> S1 = mdot_fb(w, tb);
-#pragma unroll
-                for (int s = 0; s < kSPL; ++s) { ES[3 + s] = S1[s]; lds.s[e0 + s + 3] = S1[s]; }
-                if (gl == 0) { lds.s[2] = cS0; lds.s[1] = cS1; lds.s[0] = cS2; }
-                __syncthreads();
-                ES[2] = lds.s[e0 + 2]; ES[1] = lds.s[e0 + 1]; ES[0] = lds.s[e0];
-                Vd<kSPL> zm, v0, v1, v2, v3;
-#pragma unroll
-                for (int s = 0; s < kSPL; ++s) {
-                    zm[s] = -h[s] * w.inv_tau;
-                    v0[s] = ES[3 + s]; v1[s] = ES[2 + s]; v2[s] = ES[1 + s]; v3[s] = ES[s];
-                }
-                const Phi<kSPL> pm = phi1234(zm);
-                const Vd<kSPL> inc = eam4_increment(sh, pm, h, v0, v1, v2, v3);
-                double A = 1.0, B = 0.0;
-#pragma unroll
-                for (int s = 0; s < kSPL; ++s) { B = fma(pm.e[s], B, inc[s]); A = A * pm.e[s]; }
-                double M_wave;
-                scan_affine_block<W>(A, B, lds.tot[tp], wave, lane, M_s, M_wave);
-                tp ^= 1;
-                const double Ax = lane_prev(A, 1.0), Bx = lane_prev(B, 0.0);
-                double Mc = fma(Ax, M_wave, Bx);
-#pragma unroll
-                for (int s = 0; s < kSPL; ++s) { Mc = fma(pm.e[s], Mc, inc[s]); M1[s] = Mc; }
-            }
-            const DiscPt<kSPL> d1 = disc_point(sh, w, M1);
-
-            // ---------------- omega: predictor
-            Vd<kSPL> wg;
-            {
-                const double g1 = om_s - cw1, g2 = g1 - (cw1 - cw2);
-                const double d2b = (cw1 - cw2) - (cw2 - cw3);
-                const double g3 = tile == 0 ? 0.0 : g2 - d2b;
-                const double g4 = tile == 0 ? 0.0 : g3 - (d2b - ((cw2 - cw3) - (cw3 - cw4)));
-#pragma unroll
-                for (int s = 0; s < kSPL; ++s) {
-                    const double k = (double)(e0 + s + 1);
-                    const double c2 = 0.5 * k * (k + 1.0);
-                    const double c3 = c2 * (k + 2.0) * (1.0 / 3.0);
-                    wg[s] = fma(k, g1, fma(c2, g2, fma(c3, g3, fma(c3 * (k + 3.0) * 0.25, g4, om_s))));
-                }
-            }
-            // ---------------- Newton sweeps.  Each pass starts with the right-hand side at the current values and ONE
-            // barrier that publishes (omega_dot, omega) for the neighbours together with every wavefront's verdict on the
-            // previous pass; when nobody is pending those values are final (and omega_dot is exact at them).  A full pass
-            // adds a second barrier for the scan totals.
-            Vd<kSPL> f1;
-            bool flagged = false, pending = true, not_ok = false, settled = false;
-            int sweep = 0;
-            double w_guard = om_s;
-            Vd<kSPL> lam, ez;          // light sweeps as in walker_eval; decided per wavefront (a step's linearisation
-            EamW<kSPL> cw;             // point is its own business, nothing has to agree across wavefronts)
-            bool light = false;
-            while (true) {
-                {
-                    bool wild = false;
-#pragma unroll
-                    for (int s = 0; s < kSPL; ++s) wild = wild || !(wg[s] > 0.0);
-                    if (__any(wild)) {
-#pragma unroll
-                        for (int s = 0; s < kSPL; ++s)
-                            if (!(wg[s] > 0.0)) wg[s] = w_guard > 0.0 ? w_guard : om_s;
-                    }
-                }
-                Vd<kSPL> rot;
-                if (light) {
-                    Vd<kSPL> unused;
-                    f1 = omega_rhs<false>(sh, w, d1, wg, rot, unused);
-                } else {
-                    f1 = omega_rhs<true>(sh, w, d1, wg, rot, lam);
-                }
-                bool flg = false;
-#pragma unroll
-                for (int s = 0; s < kSPL; ++s) {
-                    lds.f[e0 + s + 3] = f1[s];
-                    lds.w[e0 + s + 3] = wg[s];
-                    flg = flg || (i0 + s < nsteps && rot[s] > 0.27);
-                }
-                if (gl == 0) {
-                    double h1 = cf1, h2 = cf2, u1 = cw1, u2 = cw2;
-                    if (tile == 0) {   // start-up ghosts: linear continuation of points 0 and 1 in the index
-                        h1 = 2.0 * cf0 - f1[0]; u1 = 2.0 * om_s - wg[0];
-                        h2 = 3.0 * cf0 - 2.0 * f1[0]; u2 = 3.0 * om_s - 2.0 * wg[0];
-                    }
-                    lds.f[2] = cf0; lds.f[1] = h1; lds.f[0] = h2;
-                    lds.w[2] = om_s; lds.w[1] = u1; lds.w[0] = u2;
-                }
-                {
-                    const int word = (__any(not_ok) ? 1 : 0) | (__any(settled && flg) ? 2 : 0);
-                    if (lane == 0) lds.flags[fp][wave] = word;
-                }
-                __syncthreads();
-                {
-                    int all = 0;
-#pragma unroll
-                    for (int v = 0; v < W; ++v) all |= lds.flags[fp][v];
-                    fp ^= 1;
-                    pending = sweep == 0 || (all & 1);
-                    flagged = flagged || (all & 2);
-                }
-                if (!pending || flagged || sweep >= kMaxSweeps) break;
-                ++sweep;
-                double Ef[kSPL + 3], Ew[kSPL + 3];
-#pragma unroll
-                for (int s = 0; s < kSPL; ++s) { Ef[3 + s] = f1[s]; Ew[3 + s] = wg[s]; }
-                Ef[2] = lds.f[e0 + 2]; Ef[1] = lds.f[e0 + 1]; Ef[0] = lds.f[e0];
-                Ew[2] = lds.w[e0 + 2]; Ew[1] = lds.w[e0 + 1]; Ew[0] = lds.w[e0];
-                w_guard = Ew[2];
-                Vd<kSPL> n0, n1, n2, n3;
-#pragma unroll
-                for (int s = 0; s < kSPL; ++s) {
-                    n0[s] = fma(-lam[s], Ew[3 + s], Ef[3 + s]);
-                    n1[s] = fma(-lam[s], Ew[2 + s], Ef[2 + s]);
-                    n2[s] = fma(-lam[s], Ew[1 + s], Ef[1 + s]);
-                    n3[s] = fma(-lam[s], Ew[s], Ef[s]);
-                }
-                if (!light) {
-                    Vd<kSPL> zw;
-#pragma unroll
-                    for (int s = 0; s < kSPL; ++s) zw[s] = h[s] * lam[s];
-                    const Phi<kSPL> pw_ = phi1234(zw);
-                    ez = pw_.e;
-                    cw = eam4_node_weights(sh, pw_);
-                }
-                const Vd<kSPL> inc = eam4_increment_nodes(cw, h, n0, n1, n2, n3);
-                double A = 1.0, B = 0.0;
-#pragma unroll
-                for (int s = 0; s < kSPL; ++s) { B = fma(ez[s], B, inc[s]); A = A * ez[s]; }
-                double om_wave;
-                scan_affine_block<W>(A, B, lds.tot[tp], wave, lane, om_s, om_wave);   // barrier: also orders the LDS image reads
-                tp ^= 1;                                                              // before the next pass overwrites it
-                const double Ax = lane_prev(A, 1.0), Bx = lane_prev(B, 0.0);
-                double wc = fma(Ax, om_wave, Bx);
-                bool all_ok = true, all_settled = true, all_small = true;
-#pragma unroll
-                for (int s = 0; s < kSPL; ++s) {
-                    wc = fma(ez[s], wc, inc[s]);
-                    const double dw = fabs(wc - wg[s]), mag = fabs(wc);
-                    all_settled = all_settled && (dw <= 1.0e-3 * mag);
-                    all_small = all_small && (dw <= 1.0e-4 * mag);
-                    all_ok = all_ok && dw <= sh.sweep_tol * mag;
-                    wg[s] = wc;
-                }
-                settled = all_settled;
-                not_ok = !all_ok;
-                light = __all(all_small);
-            }
-            sweeps_total += sweep;
-
-            // ---------------- ONE barrier publishes the tile's (Mdisc, omega) image, the carries for the next tile
-            // and every wavefront's failure verdict
-            {
-                bool bad = false, over = false;
-#pragma unroll
-                for (int s = 0; s < kSPL; ++s) {
-                    const bool act = i0 + s < nsteps;
-                    bad = bad || (act && (!(isfinite(M1[s]) && isfinite(wg[s])) || M1[s] <= 0.0 || wg[s] <= 0.0));
-                    over = over || (act && sh.crot * wg[s] * wg[s] > 0.27);
-                }
-                const unsigned long long mb = __ballot(bad), mo = __ballot(over);
-                if (lane == 0) {
-                    lds.fail[tq][2 * wave] = mb ? wave * 64 + __ffsll(mb) - 1 : 0x7fffffff;
-                    lds.fail[tq][2 * wave + 1] = mo ? wave * 64 + __ffsll(mo) - 1 : 0x7fffffff;
-                }
-#pragma unroll
-                for (int s = 0; s < kSPL; ++s) {
-                    if (deferred) { lds.L[0][e0 + s + 1] = M1[s]; lds.L[1][e0 + s + 1] = wg[s]; }   // (Mdisc, omega) image
-                    const int back = kTile - 1 - (e0 + s);          // 0 = last step end of the tile
-                    if (back < 3) { lds.carry[tq][back] = ES[3 + s]; lds.carry[tq][3 + back] = f1[s]; }
-                    if (back < 5) lds.carry[tq][6 + back] = wg[s];
-                    if (back == 0) lds.carry[tq][11] = M1[s];
-                }
-                if (gl == 0 && deferred) { lds.L[0][0] = M_s; lds.L[1][0] = om_s; }
-                __syncthreads();
-                int first_bad = 0x7fffffff, first_flag = 0x7fffffff;
-#pragma unroll
-                for (int v = 0; v < W; ++v) { first_bad = min(first_bad, lds.fail[tq][2 * v]); first_flag = min(first_flag, lds.fail[tq][2 * v + 1]); }
-                // a tile whose sweeps flagged an iterate or never settled: the reference's 'flag' (walker_eval)
-                if (flagged || pending) first_flag = 0;
-                if (first_bad != 0x7fffffff || first_flag != 0x7fffffff) {
-                    status = first_flag <= first_bad ? MP_STATUS_FLAG : MP_STATUS_NONFINITE;
-                    break;
-                }
-                const bool mine = ob_tile == tile;
-                int j0 = 0, j1 = 0;
-                if (long_lc) { j0 = max(tptr[tile * kSPL * W], kRes); j1 = tptr[min((tile + 1) * kSPL * W, sh.n_tiles)]; }
-                if (mine) {
-                    const int g = ob_g - tile * kTile;
-                    obM[0] = lds.L[0][g]; obM[1] = lds.L[0][g + 1];
-                    obW[0] = lds.L[1][g]; obW[1] = lds.L[1][g + 1];
-                }
-                for (int j = j0 + gl; j < j1; j += kRes) {
-                    const int g = sh.obs_g[dsd.obs_off + j] - tile * kTile;
-                    double *p = sc + (j - 64);
-                    p[0] = lds.L[0][g]; p[sc_stride] = lds.L[0][g + 1];
-                    p[2 * sc_stride] = lds.L[1][g]; p[3 * sc_stride] = lds.L[1][g + 1];
-                }
-                cS0 = lds.carry[tq][0]; cS1 = lds.carry[tq][1]; cS2 = lds.carry[tq][2];
-                cf0 = lds.carry[tq][3]; cf1 = lds.carry[tq][4]; cf2 = lds.carry[tq][5];
-                om_s = lds.carry[tq][6]; cw1 = lds.carry[tq][7]; cw2 = lds.carry[tq][8]; cw3 = lds.carry[tq][9]; cw4 = lds.carry[tq][10];
-                M_s = lds.carry[tq][11];
-            }
-        }
-    }
-
-    if (deferred && status == MP_STATUS_OK) {   // the luminosity evaluations of this walker: one per 64*W observations
-        const Vd<2> Mv{{obM[0], obM[1]}}, Wv{{obW[0], obW[1]}};
-        const DiscPt<2> dp = disc_point(sh, w, Mv);
-        Vd<2> Lt, Lp, Ld;
-        luminosity(sh, w, dp, Wv, Lt, Lp, Ld);
-        if (ob_g >= 0) {
-            const double mod = fma((Lt[1] - Lt[0]) * ob_idt, ob_dx, Lt[0]) / 1.0e50;
-            const double res = (ob_y - mod) / ob_ye;
-            chi = res * res;
-        }
-        if (long_lc) {
-            __syncthreads();   // scratch rows written by other lanes
-            for (int jb = kRes; jb < dsd.n_obs; jb += kRes) {
-                const bool valid = jb + gl < dsd.n_obs;
-                const int j = valid ? jb + gl : dsd.n_obs - 1;
-                const double *p = sc + (j - 64);
-                const Vd<2> Mx{{p[0], p[sc_stride]}}, Wx{{p[2 * sc_stride], p[3 * sc_stride]}};
-                const DiscPt<2> dx = disc_point(sh, w, Mx);
-                Vd<2> Lx, Lpx, Ldx;
-                luminosity(sh, w, dx, Wx, Lx, Lpx, Ldx);
-                const int jj = dsd.obs_off + j;
-                const double mod = fma((Lx[1] - Lx[0]) * sh.obs_idt[jj], sh.obs_dx[jj], Lx[0]) / 1.0e50;
-                const double res = (sh.obs_y[jj] - mod) / sh.obs_yerr[jj];
-                if (valid) chi = fma(res, res, chi);
-            }
-        }
-    }
-    double lnp = -INFINITY;
-    if (status == MP_STATUS_OK) {
-        const double part = wave_sum(chi);
-        __syncthreads();
-        if (lane == 0) lds.tot[0][wave] = part;
-        __syncthreads();
-        double tot = 0.0;
-#pragma unroll
-        for (int v = 0; v < W; ++v) tot += lds.tot[0][v];
-        lnp = -0.5 * tot;
         if (!isfinite(lnp)) { lnp = -INFINITY; status = MP_STATUS_NONFINITE; }
     }
     lnp_out = lnp;

@@ -24,9 +24,10 @@
 //      tile's light curve is staged in LDS for the interpolation and written to HBM with coalesced stores.
 //   4. A wavefront reduction of the per-lane chi^2 terms gives -0.5*chi^2 (code/synthetic_datasets/mcmc_eqns.py:25).
 //
-// Kernels: lnprob_kernel<CURVES, SPL, LONG> (one wavefront per walker), lnprob_mw_kernel<SPL, W, LONG> (W wavefronts per
-// walker for batches that cannot fill the 1 024 SIMDs), stretch_kernel<SPL, W, LONG> (emcee's stretch move fused around
-// either); LONG = built with the scratch-row path for light curves of more than 64 points.
+// Kernels: lnprob_kernel<CURVES, SPL, LONG> (one wavefront per walker), lnprob_pc_kernel<SPL, LONG> (a producer and a
+// consumer wavefront per walker for batches that cannot fill the SIMDs), stretch_kernel<SPL, LONG, PC> (emcee's stretch
+// move fused around either) and stretch_apply_kernel (the state update of a half-step whose proposals were evaluated
+// on several GPUs); LONG = built with the scratch-row path for light curves of more than 64 points.
 // No MFMA (no dense contraction anywhere on this path), fp64 throughout; bound by the VALU issue rate of one wave per
 // SIMD (profiles/, tools/ubench).  The arithmetic is algebraically simplified with respect to the reference formulas
 // (e.g. fastness w = (Rm/Rc)^1.5 = omega*Rm^1.5/sqrt(GM), eta1-eta2 = -tanh); oracle/mp_oracle.c keeps the literal
@@ -86,25 +87,6 @@ __global__ __launch_bounds__(128) void lnprob_pc_kernel(const DevShared sh, cons
     }
 }
 
-template <int SPL, int W, bool LONG>
-__global__ __launch_bounds__(64 * W) void lnprob_mw_kernel(const DevShared sh, const LaunchArgs a) {
-    __shared__ MwLds<SPL, W> lds;
-    ktab_init();
-    const int walker = blockIdx.x;
-    double par[MP_MAX_NDIM];
-    const double *pw = a.pars + (size_t)walker * a.ndim;
-#pragma unroll
-    for (int i = 0; i < MP_MAX_NDIM; ++i) par[i] = i < a.ndim ? pw[i] : 0.0;
-    double lnp;
-    int status, sweeps;
-    walker_eval_mw<SPL, W, LONG>(sh, a, walker, par, lds, lnp, status, sweeps);
-    if (threadIdx.x == 0) {
-        a.lnprob[walker] = lnp;
-        if (a.status) a.status[walker] = status;
-        if (a.sweeps) a.sweeps[walker] = sweeps;
-    }
-}
-
 // ---------------------------------------------------------------- fused stretch-move half-step kernel
 // Counter-based RNG (Philox4x32-10, Salmon et al. 2011): one independent stream per (seed, step, walker).
 MP_DEV void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t (&out)[4]) {
@@ -143,15 +125,21 @@ MP_DEV double u01(uint32_t hi, uint32_t lo) {   // 53-bit uniform in [0, 1)
 // proposal (emcee's StretchMove.get_proposal), evaluate its log-posterior with walker_eval, accept or
 // reject against the walker's current value, update position / lnprob / counters in place and write the
 // step's row of the chain.  Walkers of the complementary half are only read, so the update is race-free.
-// PC: producer/consumer pair of wavefronts (W = 1, 128 threads), see lnprob_pc_kernel.
+// PC: producer/consumer pair of wavefronts (128 threads), see lnprob_pc_kernel.
+// A launch covers the slots [slot_lo, slot_lo + gridDim.x) of the active half (all ensembles flattened).  With g.upd set
+// (walker-sharded ensembles, one process per GPU) nothing is updated in place: the outcome of slot s goes to row
+// s - slot_lo of g.upd as (proposal[ndim], its lnprob, accepted 0/1) and stretch_apply_kernel commits the rows of all
+// ranks after the all-gather.  The random numbers are keyed by (seed; step, half, walker), so every rank draws what the
+// single-GPU launch would have drawn for the same walker.
 struct NoRing {};
-template <int SPL, int W, bool LONG, bool PC = false>
-__global__ __launch_bounds__(PC ? 128 : 64 * W) void stretch_kernel(const DevShared sh, const StretchArgs g) {
-    __shared__ typename std::conditional<(W > 1), MwLds<SPL, W>, double[2 * (64 * SPL + 1)]>::type lds;
+template <int SPL, bool LONG, bool PC = false>
+__global__ __launch_bounds__(PC ? 128 : 64) void stretch_kernel(const DevShared sh, const StretchArgs g) {
+    __shared__ double lds[2 * (64 * SPL + 1)];
     __shared__ typename std::conditional<PC, PcRing<SPL>, NoRing>::type ring;
     ktab_init();
-    const int w_ens = blockIdx.x / g.n_half;                       // which ensemble
-    const int slot = blockIdx.x - w_ens * g.n_half;                // which walker of the active half
+    const int gs = g.slot_lo + (int)blockIdx.x;                    // slot of the active half, all ensembles flattened
+    const int w_ens = gs / g.n_half;                               // which ensemble
+    const int slot = gs - w_ens * g.n_half;                        // which walker of the active half
     const int32_t *perm = g.perm + (size_t)w_ens * g.n_walkers;    // this step's random split of the ensemble
     const int base = w_ens * g.n_walkers;
     const int k = base + perm[g.half * g.n_half + slot];           // active walker (global index)
@@ -190,31 +178,70 @@ __global__ __launch_bounds__(PC ? 128 : 64 * W) void stretch_kernel(const DevSha
         }
     }
     double lnp;
-    int status, sweeps;
+    int status = MP_STATUS_OK, sweeps;
     if (g.target == 1) {   // isotropic unit Gaussian: exercises the move itself (tests)
         lnp = 0.0;
 #pragma unroll
         for (int i = 0; i < MP_MAX_NDIM; ++i) lnp = i < g.ndim ? sub_rn(lnp, mul_rn(mul_rn(0.5, prop[i]), prop[i])) : lnp;
-        status = MP_STATUS_OK;
     } else {
-        if constexpr (W > 1) walker_eval_mw<SPL, W, LONG>(sh, a, k, par, lds, lnp, status, sweeps);
-        else if constexpr (PC) walker_eval<false, SPL, LONG, 1>(sh, a, k, par, lds, lnp, status, sweeps, &ring);
+        if constexpr (PC) walker_eval<false, SPL, LONG, 1>(sh, a, k, par, lds, lnp, status, sweeps, &ring);
         else walker_eval<false, SPL, LONG>(sh, a, k, par, lds, lnp, status, sweeps);
     }
     if (threadIdx.x == 0) {
         const double lnp_old = g.lnprob[k];
         const double lnpdiff = sub_rn(add_rn(mul_rn(g.ndim - 1.0, log(zz)), lnp), lnp_old);
         const bool accept = lnpdiff > log(u01(r2[0], r2[1]));      // false for NaN / -inf proposals
-        if (accept) {
-            for (int i = 0; i < g.ndim; ++i) g.pos[(size_t)k * g.ndim + i] = prop[i];
-            g.lnprob[k] = lnp;
-            g.n_accepted[k] += 1;
+        if (g.upd) {
+            double *u = g.upd + (size_t)blockIdx.x * (g.ndim + 3);
+            for (int i = 0; i < g.ndim; ++i) u[i] = prop[i];
+            u[g.ndim] = lnp;
+            u[g.ndim + 1] = accept ? 1.0 : 0.0;
+            u[g.ndim + 2] = (double)status;
+        } else {
+            if (accept) {
+                for (int i = 0; i < g.ndim; ++i) g.pos[(size_t)k * g.ndim + i] = prop[i];
+                g.lnprob[k] = lnp;
+                g.n_accepted[k] += 1;
+            }
+            if (g.chain) {
+                double *c = g.chain + ((size_t)g.chain_row * g.n_total + k) * g.ndim;
+                for (int i = 0; i < g.ndim; ++i) c[i] = accept ? prop[i] : g.pos[(size_t)k * g.ndim + i];
+                g.chain_lnp[(size_t)g.chain_row * g.n_total + k] = accept ? lnp : lnp_old;
+            }
+            if (g.bad_log && status != MP_STATUS_OK && status != MP_STATUS_PRIOR) {
+                // the reference appends such parameter sets to its `fbad` file (code/synthetic_datasets/mcmc_eqns.py:72-79)
+                const unsigned slot_b = atomicAdd(g.bad_count, 1u);
+                if (slot_b < g.bad_cap)
+                    for (int i = 0; i < g.ndim; ++i) g.bad_log[(size_t)slot_b * g.ndim + i] = prop[i];
+            }
         }
-        if (g.chain) {
-            double *c = g.chain + ((size_t)g.chain_row * g.n_total + k) * g.ndim;
-            for (int i = 0; i < g.ndim; ++i) c[i] = accept ? prop[i] : g.pos[(size_t)k * g.ndim + i];
-            g.chain_lnp[(size_t)g.chain_row * g.n_total + k] = accept ? lnp : lnp_old;
-        }
+    }
+}
+
+// Commit one half-step from the gathered outcome rows (see stretch_kernel): one thread per slot of the active half.
+__global__ __launch_bounds__(256) void stretch_apply_kernel(const StretchArgs g) {
+    const int gs = blockIdx.x * 256 + threadIdx.x;
+    if (gs >= g.n_half * g.n_ensembles) return;
+    const int w_ens = gs / g.n_half, slot = gs - w_ens * g.n_half;
+    const int k = w_ens * g.n_walkers + g.perm[(size_t)w_ens * g.n_walkers + g.half * g.n_half + slot];
+    const double *u = g.upd + (size_t)gs * (g.ndim + 3);
+    const bool accept = u[g.ndim + 1] != 0.0;
+    const double lnp_old = g.lnprob[k];
+    if (accept) {
+        for (int i = 0; i < g.ndim; ++i) g.pos[(size_t)k * g.ndim + i] = u[i];
+        g.lnprob[k] = u[g.ndim];
+        g.n_accepted[k] += 1;
+    }
+    if (g.chain) {
+        double *c = g.chain + ((size_t)g.chain_row * g.n_total + k) * g.ndim;
+        for (int i = 0; i < g.ndim; ++i) c[i] = accept ? u[i] : g.pos[(size_t)k * g.ndim + i];
+        g.chain_lnp[(size_t)g.chain_row * g.n_total + k] = accept ? u[g.ndim] : lnp_old;
+    }
+    const int status = (int)u[g.ndim + 2];
+    if (g.bad_log && status != MP_STATUS_OK && status != MP_STATUS_PRIOR) {
+        const unsigned slot_b = atomicAdd(g.bad_count, 1u);
+        if (slot_b < g.bad_cap)
+            for (int i = 0; i < g.ndim; ++i) g.bad_log[(size_t)slot_b * g.ndim + i] = u[i];
     }
 }
 
@@ -256,28 +283,20 @@ int launch_lnprob(const DevShared &sh, const LaunchArgs &a, void *stream) {
     if (a.n <= 0) return 0;
     const bool curves = a.ltot || a.lprop || a.ldip || a.mdisc || a.omega;
     dim3 grid((unsigned)a.n), block(64);
-    // Variants (results agree to rounding):
-    //  - up to 512 walkers (SIMDs to spare): a producer/consumer pair of wavefronts per walker (the omega-independent
+    // Variants (results agree to rounding); sh.n_simd = SIMDs of the device:
+    //  - up to n_simd/2 walkers (SIMDs to spare): a producer/consumer pair of wavefronts per walker (the omega-independent
     //    Mdisc phase runs ahead on the second wavefront; bit-identical to the one-wavefront kernel, 17-20 % sooner);
-    //    the older 4-barrier-coupled-wavefronts kernel is kept behind MAGPROP_AMD_WPW=4;
-    //  - up to 1024 walkers (one wave per SIMD): one wavefront per walker, four steps per lane (256-step tiles
+    //  - up to n_simd walkers (one wave per SIMD): one wavefront per walker, four steps per lane (256-step tiles
     //    amortise the wavefront scans best; needs the whole register file of a SIMD);
     //  - beyond: two steps per lane, which keeps two waves resident per SIMD (they fill each other's issue gaps).
     //  - a handle that holds a light curve of more than 64 points runs the LONG builds of the same kernels.
-    const bool wide = (sh.force_spl ? sh.force_spl : kernel_spl(a.n)) == 4;
+    const bool wide = (sh.force_spl ? sh.force_spl : kernel_spl(sh, a.n)) == 4;
     const bool lng = sh.scratch_stride > 0;
     hipStream_t st = (hipStream_t)stream;
-    const int wpw = curves ? 1 : (sh.force_wpw ? sh.force_wpw : waves_per_walker(a.n));
-    const bool pc = !curves && sh.force_pc >= 0 && !sh.force_wpw && !sh.force_spl &&
-                    (sh.force_pc == 1 || two_wave_pair(a.n));
+    const bool pc = !curves && sh.force_pc >= 0 && !sh.force_spl && (sh.force_pc == 1 || two_wave_pair(sh, a.n));
     if (pc) {
         if (lng) hipLaunchKernelGGL((lnprob_pc_kernel<4, true>), grid, dim3(128), 0, st, sh, a);
         else hipLaunchKernelGGL((lnprob_pc_kernel<4, false>), grid, dim3(128), 0, st, sh, a);
-    } else if (wpw == 4) {
-        if (lng) hipLaunchKernelGGL((lnprob_mw_kernel<1, 4, true>), grid, dim3(256), 0, st, sh, a);
-        else hipLaunchKernelGGL((lnprob_mw_kernel<1, 4, false>), grid, dim3(256), 0, st, sh, a);
-    } else if (wpw == 2) {
-        hipLaunchKernelGGL((lnprob_mw_kernel<2, 2, true>), grid, dim3(128), 0, st, sh, a);
     } else if (curves) {
         if (wide) hipLaunchKernelGGL((lnprob_kernel<true, 4, false>), grid, block, 0, st, sh, a);
         else hipLaunchKernelGGL((lnprob_kernel<true, 2, false>), grid, block, 0, st, sh, a);
@@ -291,30 +310,30 @@ int launch_lnprob(const DevShared &sh, const LaunchArgs &a, void *stream) {
     return (int)hipGetLastError();
 }
 
-int launch_stretch(const DevShared &sh, const StretchArgs &g, void *stream) {
-    const int n_blocks = g.n_half * g.n_ensembles;
+// n_blocks slots of the active half starting at g.slot_lo
+int launch_stretch(const DevShared &sh, const StretchArgs &g, int n_blocks, void *stream) {
     if (n_blocks <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)n_blocks);
-    const int wpw = g.target == 1 ? 1 : (sh.force_wpw ? sh.force_wpw : waves_per_walker(n_blocks));
     const bool lng = sh.scratch_stride > 0;
-    const bool pc = g.target != 1 && sh.force_pc >= 0 && !sh.force_wpw && !sh.force_spl &&
-                    (sh.force_pc == 1 || two_wave_pair(n_blocks));
+    const bool pc = g.target != 1 && sh.force_pc >= 0 && !sh.force_spl && (sh.force_pc == 1 || two_wave_pair(sh, n_blocks));
     if (pc) {
-        if (lng) hipLaunchKernelGGL((stretch_kernel<4, 1, true, true>), grid, dim3(128), 0, st, sh, g);
-        else hipLaunchKernelGGL((stretch_kernel<4, 1, false, true>), grid, dim3(128), 0, st, sh, g);
-    } else if (wpw == 4) {
-        if (lng) hipLaunchKernelGGL((stretch_kernel<1, 4, true>), grid, dim3(256), 0, st, sh, g);
-        else hipLaunchKernelGGL((stretch_kernel<1, 4, false>), grid, dim3(256), 0, st, sh, g);
-    } else if (wpw == 2) {
-        hipLaunchKernelGGL((stretch_kernel<2, 2, true>), grid, dim3(128), 0, st, sh, g);
-    } else if ((sh.force_spl ? sh.force_spl : kernel_spl(n_blocks)) == 4) {
-        if (lng) hipLaunchKernelGGL((stretch_kernel<4, 1, true>), grid, dim3(64), 0, st, sh, g);
-        else hipLaunchKernelGGL((stretch_kernel<4, 1, false>), grid, dim3(64), 0, st, sh, g);
+        if (lng) hipLaunchKernelGGL((stretch_kernel<4, true, true>), grid, dim3(128), 0, st, sh, g);
+        else hipLaunchKernelGGL((stretch_kernel<4, false, true>), grid, dim3(128), 0, st, sh, g);
+    } else if ((sh.force_spl ? sh.force_spl : kernel_spl(sh, n_blocks)) == 4) {
+        if (lng) hipLaunchKernelGGL((stretch_kernel<4, true>), grid, dim3(64), 0, st, sh, g);
+        else hipLaunchKernelGGL((stretch_kernel<4, false>), grid, dim3(64), 0, st, sh, g);
     } else {
-        if (lng) hipLaunchKernelGGL((stretch_kernel<2, 1, true>), grid, dim3(64), 0, st, sh, g);
-        else hipLaunchKernelGGL((stretch_kernel<2, 1, false>), grid, dim3(64), 0, st, sh, g);
+        if (lng) hipLaunchKernelGGL((stretch_kernel<2, true>), grid, dim3(64), 0, st, sh, g);
+        else hipLaunchKernelGGL((stretch_kernel<2, false>), grid, dim3(64), 0, st, sh, g);
     }
+    return (int)hipGetLastError();
+}
+
+int launch_stretch_apply(const StretchArgs &g, void *stream) {
+    const int n = g.n_half * g.n_ensembles;
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(stretch_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g);
     return (int)hipGetLastError();
 }
 

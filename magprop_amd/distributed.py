@@ -90,66 +90,94 @@ class ShardedLnprob:
         return self.finish(self.start(pars))
 
 
-class DistributedStretchSampler:
-    """emcee's stretch move with the walkers' log-posterior evaluations sharded over the process group.
+class HipShardEngine:
+    """Adapter: a `magprop_amd.EnsembleSampler` (the C ABI's mp_sampler_halfstep_* entry points) behind the tensor-level
+    engine protocol `DistributedEnsembleSampler` drives.  Everything is enqueued on torch's current stream of the
+    sampler's device, so torch.distributed orders its collectives with the kernels."""
 
-    Every rank holds the full ensemble state and draws the same random numbers (replicated generator, same seed), so
-    the proposals of a half-step are identical everywhere; rank r evaluates its contiguous block of them on its GPU and
-    ONE all-gather of the lnprob slices (RCCL over xGMI) lets every rank take the same accept/reject decisions — the
-    pattern BASELINE.json's north star describes for 8 GPUs.  The move itself is a handful of small tensor operations on
-    the state's device; the single-GPU, fully fused version is `magprop_amd.EnsembleSampler`.
+    def __init__(self, sampler, device):
+        self.s = sampler
+        self.device = torch.device(device)
+        self.ntotal, self.ndim = sampler.ntotal, sampler.ndim
+        self.n_slots, self.row_doubles = sampler.n_slots, sampler.row_doubles
 
-    eval_local(pars_local) -> lnprob of the local block (same device), e.g. `LogProb.lnprob_device`.
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def set_positions(self, pos):
+        self.s.set_positions(pos)          # every rank evaluates the whole initial ensemble (once per run)
+
+    def halfstep_shard(self, half, lo, hi, rows):
+        assert rows.is_contiguous() and rows.dtype == torch.float64 and rows.shape[0] >= hi - lo
+        self.s.halfstep_shard(half, lo, hi, rows.data_ptr() if hi > lo else 0, stream=self._stream())
+
+    def halfstep_apply(self, half, rows, chain_row=None, lnp_row=None):
+        assert rows.is_contiguous() and rows.shape[0] >= self.n_slots
+        self.s.halfstep_apply(half, rows.data_ptr(), chain_row.data_ptr() if chain_row is not None else 0,
+                              lnp_row.data_ptr() if lnp_row is not None else 0, stream=self._stream())
+
+    def state(self):
+        """(pos, lnprob, n_accepted) as numpy arrays (synchronises)."""
+        return self.s.get_last_sample()
+
+
+class DistributedEnsembleSampler:
+    """emcee's stretch move on an ensemble whose walkers are sharded over the process group, one fused kernel and ONE
+    all-gather per half-step (the pattern of code/synthetic_datasets/synth_mcmc.py:178-185 with the pool replaced by GPUs).
+
+    Every rank holds the full ensemble state in HBM and the same seed.  Per half-step, rank r runs the fused stretch
+    kernel over ITS contiguous block of the active half's slots — the random numbers are counter-based and keyed by the
+    global walker index, so each rank draws exactly what a single-GPU launch would have drawn for those walkers, with no
+    communication — which leaves one outcome row per slot (proposal, its lnprob, accepted, status).  The rows of all
+    ranks are all-gathered (RCCL over xGMI; 72 B per proposal) and every rank commits all of them with a small kernel.
+    Nothing synchronises with the host inside the loop and no random number crosses a wire.  The chain equals the
+    single-GPU `magprop_amd.EnsembleSampler` chain (bit for bit while the per-rank block selects the same kernel variant).
+
+    engine: HipShardEngine (product) or any object with the same methods (tests drive the protocol on CPU with the numpy
+    restatement of the move).
     """
 
-    def __init__(self, eval_local, nwalkers, ndim, seed=0, a=2.0, group=None, device="cpu", via_host=False):
-        if nwalkers % 2 or nwalkers < 2:
-            raise ValueError("nwalkers must be even")
-        self.nwalkers, self.ndim, self.a = int(nwalkers), int(ndim), float(a)
-        self.device = torch.device(device)
-        self.lnprob_fn = ShardedLnprob(eval_local, group=group, via_host=via_host)
-        self.gen = torch.Generator(device="cpu").manual_seed(int(seed))     # replicated on every rank
-        self.pos = None
-        self.lnp = None
-        self.naccepted = torch.zeros(self.nwalkers, dtype=torch.int64, device=self.device)
+    def __init__(self, engine, group=None, via_host=False):
+        self.engine = engine
+        self.group = group
+        self.via_host = via_host       # gather through host memory: gloo rehearsal with GPU engines
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.lo, self.hi, self.per = shard_range(engine.n_slots, self.rank, self.world)
+        R = engine.row_doubles
+        dev = engine.device
+        self.send = torch.zeros(self.per, R, dtype=torch.float64, device=dev)                 # this rank's outcome rows
+        self.rows = self.send if self.world == 1 else torch.zeros(self.per * self.world, R, dtype=torch.float64, device=dev)
         self.iteration = 0
 
-    def _rand(self, n):
-        return torch.rand(n, dtype=torch.float64, generator=self.gen).to(self.device)
+    def _gather(self):
+        if self.world == 1:
+            return
+        if self.via_host:
+            host = torch.empty(self.rows.shape, dtype=torch.float64)
+            dist.all_gather_into_tensor(host.view(-1), self.send.cpu().view(-1), group=self.group)
+            self.rows.copy_(host)
+        else:
+            dist.all_gather_into_tensor(self.rows.view(-1), self.send.view(-1), group=self.group)
 
     def run_mcmc(self, pos, nsteps, store=True):
-        """Returns (chain[nsteps, nwalkers, ndim], lnprob[nsteps, nwalkers]) on the state's device (or None, None)."""
+        """pos: (ntotal, ndim) array or None to continue.  Returns (chain[nsteps, ntotal, ndim], lnprob[nsteps, ntotal])
+        tensors on the engine's device (None, None with store=False)."""
+        e = self.engine
         if pos is not None:
-            self.pos = torch.as_tensor(pos, dtype=torch.float64).to(self.device).contiguous().clone()
-            if self.pos.shape != (self.nwalkers, self.ndim):
-                raise ValueError(f"pos must have shape {(self.nwalkers, self.ndim)}")
-            self.lnp = self.lnprob_fn(self.pos).clone()
-        if self.pos is None:
-            raise RuntimeError("no state: pass the initial positions first")
-        n, half = self.nwalkers, self.nwalkers // 2
-        chain = torch.empty(nsteps, n, self.ndim, dtype=torch.float64, device=self.device) if store else None
-        clnp = torch.empty(nsteps, n, dtype=torch.float64, device=self.device) if store else None
+            e.set_positions(pos)
+        chain = lnp = None
+        if store and nsteps > 0:
+            chain = torch.empty(nsteps, e.ntotal, e.ndim, dtype=torch.float64, device=e.device)
+            lnp = torch.empty(nsteps, e.ntotal, dtype=torch.float64, device=e.device)
         for step in range(nsteps):
-            perm = torch.randperm(n, generator=self.gen).to(self.device)           # random red/blue split
-            for h in range(2):
-                act = perm[h * half:(h + 1) * half]
-                comp = perm[(1 - h) * half:(2 - h) * half]
-                zz = ((self.a - 1.0) * self._rand(half) + 1.0) ** 2 / self.a          # g(z) ~ 1/sqrt(z) on [1/a, a]
-                partner = comp[torch.randint(half, (half,), generator=self.gen).to(self.device)]
-                xk, xj = self.pos[act], self.pos[partner]
-                prop = (xj - (xj - xk) * zz[:, None]).contiguous()
-                new = self.lnprob_fn(prop)                                         # sharded kernel + all-gather
-                lnpdiff = (self.ndim - 1.0) * torch.log(zz) + new - self.lnp[act]
-                accept = lnpdiff > torch.log(self._rand(half))                     # False for NaN / -inf proposals
-                self.pos[act] = torch.where(accept[:, None], prop, xk)
-                self.lnp[act] = torch.where(accept, new, self.lnp[act])
-                self.naccepted[act] += accept.to(torch.int64)
-            if store:
-                chain[step] = self.pos
-                clnp[step] = self.lnp
+            for half in (0, 1):
+                e.halfstep_shard(half, self.lo, self.hi, self.send)
+                self._gather()     # rank r's block lands at rows [r*per, (r+1)*per): row index == slot index (shard_range)
+                e.halfstep_apply(half, self.rows, chain[step] if store else None, lnp[step] if store else None)
             self.iteration += 1
-        return chain, clnp
+        return chain, lnp
 
     @property
     def acceptance_fraction(self):
-        return self.naccepted.to(torch.float64) / max(self.iteration, 1)
+        return self.engine.state()[2] / max(self.iteration, 1)

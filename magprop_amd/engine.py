@@ -7,7 +7,8 @@ import numpy as np
 from . import _capi
 
 _lock = threading.Lock()
-_handles = {}
+_handles = {}          # key -> Engine, in least-recently-used order (dicts keep insertion order)
+MAX_ENGINES = 8        # each holds a stream, the grid and its workspace on the GPU: a keyword sweep must not pile them up
 
 
 def grid(GRBtype=None):
@@ -64,10 +65,14 @@ def engine(cfg, GRBtype=None, device=-1):
     """Cached Engine for (model configuration, grid, device)."""
     key = (_cfg_key(cfg), "S" if GRBtype == "S" else "L", int(device))
     with _lock:
-        e = _handles.get(key)
+        e = _handles.pop(key, None)
         if e is None:
+            while len(_handles) >= MAX_ENGINES:
+                old = _handles.pop(next(iter(_handles)))
+                with old.lock:                       # a caller still inside the old engine finishes first
+                    old.handle.close()
             e = Engine(cfg, grid(GRBtype), device)
-            _handles[key] = e
+        _handles[key] = e                            # most recently used last
         return e
 
 

@@ -19,17 +19,20 @@ from . import _capi, engine, synth
 
 class EnsembleSampler:
     def __init__(self, nwalkers, ndim=6, x=None, y=None, yerr=None, variant="synth", GRBtype=None, seed=0, a=2.0,
-                 datasets=None, lower="default", upper="default", log_mask=None, device=-1, target="posterior"):
-        """One ensemble on dataset (x, y, yerr), or one ensemble per entry of `datasets` = [(x, y, yerr), ...]."""
+                 datasets=None, lower="default", upper="default", log_mask=None, device=-1, target="posterior",
+                 fbad=None, sweep_tol=0.0):
+        """One ensemble on dataset (x, y, yerr), or one ensemble per entry of `datasets` = [(x, y, yerr), ...].
+        fbad: file that receives the proposals whose model failed, like the reference's lnprob(…, fbad)
+        (code/synthetic_datasets/mcmc_eqns.py:72-79); written after every run_mcmc call."""
         if nwalkers % 2 or nwalkers < 2:
             raise ValueError("nwalkers must be even")            # emcee requires an even number too
         self.nwalkers, self.ndim = int(nwalkers), int(ndim)
         self._L = _capi.lib()
         if variant == "synth":
-            cfg, lo, hi, mask = _capi.cfg_synth(), synth.PRIOR_LOWER, synth.PRIOR_UPPER, synth.LOG_MASK
+            cfg, lo, hi, mask = _capi.cfg_synth(sweep_tol=sweep_tol), synth.PRIOR_LOWER, synth.PRIOR_UPPER, synth.LOG_MASK
         elif variant == "lib":
             from . import mcmc_eqns
-            cfg = _capi.cfg_lib()
+            cfg = _capi.cfg_lib(sweep_tol=sweep_tol)
             lo, hi = mcmc_eqns._bounds(ndim)
             mask = mcmc_eqns.LIB_LOG_MASK
         else:
@@ -58,6 +61,8 @@ class EnsembleSampler:
         self._chain = None
         self._lnp = None
         self.iteration = 0
+        self.fbad = fbad
+        self._bad_written = 0
 
     def close(self):
         if getattr(self, "_s", None):
@@ -79,11 +84,7 @@ class EnsembleSampler:
     def run_mcmc(self, pos, nsteps, store=True, progress=False):
         """pos: (nwalkers, ndim) [or (nensembles*nwalkers, ndim)], or None to continue.  Returns the final positions."""
         if pos is not None:
-            p = np.ascontiguousarray(pos, dtype=np.float64)
-            if p.shape != (self.ntotal, self.ndim):
-                raise ValueError(f"pos must have shape {(self.ntotal, self.ndim)}")
-            _capi.check(self._L.mp_sampler_set_positions(self._s, p.ctypes.data_as(C.POINTER(C.c_double))),
-                        "mp_sampler_set_positions")
+            self.set_positions(pos)
         chain = lnp = None
         cp = lp = None
         if store and nsteps > 0:
@@ -95,7 +96,57 @@ class EnsembleSampler:
             self._chain = chain if self._chain is None else np.concatenate([self._chain, chain])
             self._lnp = lnp if self._lnp is None else np.concatenate([self._lnp, lnp])
         self.iteration += int(nsteps)
+        self._flush_fbad()
         return self.get_last_sample()[0]
+
+    # ---- failed proposals (the reference's fbad file)
+    def get_bad(self, max_rows=4096):
+        """(n_bad, pars[rows, ndim]): how many proposals inside the prior failed in the model so far, and the first
+        up to 4096 of them in sampler coordinates."""
+        buf = np.empty((max_rows, self.ndim))
+        n_bad = C.c_int64(0)
+        rows = self._L.mp_sampler_get_bad(self._s, buf.ctypes.data_as(C.POINTER(C.c_double)), int(max_rows), C.byref(n_bad))
+        if rows < 0:
+            _capi.check(rows, "mp_sampler_get_bad")
+        return int(n_bad.value), buf[:rows].copy()
+
+    def _flush_fbad(self):
+        if self.fbad is None or self._target != 0:
+            return
+        _, rows = self.get_bad()
+        new = rows[self._bad_written:]
+        if len(new):
+            with open(self.fbad, "a") as f:
+                for r in new:
+                    f.write(", ".join(f"{v}" for v in r) + "\n")
+            self._bad_written = len(rows)
+
+    # ---- walker-sharded driving (magprop_amd.distributed.DistributedEnsembleSampler); device pointers as ints
+    @property
+    def n_slots(self):
+        return self._L.mp_sampler_n_slots(self._s)
+
+    @property
+    def row_doubles(self):
+        return self._L.mp_sampler_row_doubles(self._s)
+
+    def set_positions(self, pos):
+        p = np.ascontiguousarray(pos, dtype=np.float64)
+        if p.shape != (self.ntotal, self.ndim):
+            raise ValueError(f"pos must have shape {(self.ntotal, self.ndim)}")
+        _capi.check(self._L.mp_sampler_set_positions(self._s, p.ctypes.data_as(C.POINTER(C.c_double))),
+                    "mp_sampler_set_positions")
+
+    def halfstep_shard(self, half, lo, hi, d_rows, stream=0):
+        _capi.check(self._L.mp_sampler_halfstep_shard(self._s, int(half), int(lo), int(hi), C.c_void_p(d_rows or None),
+                                                      C.c_void_p(stream or None)), "mp_sampler_halfstep_shard")
+
+    def halfstep_apply(self, half, d_rows, d_chain_row=0, d_chain_lnp_row=0, stream=0):
+        _capi.check(self._L.mp_sampler_halfstep_apply(self._s, int(half), C.c_void_p(d_rows), C.c_void_p(d_chain_row or None),
+                                                      C.c_void_p(d_chain_lnp_row or None), C.c_void_p(stream or None)),
+                    "mp_sampler_halfstep_apply")
+        if half == 1:
+            self.iteration += 1
 
     def get_last_sample(self):
         pos = np.empty((self.ntotal, self.ndim))
@@ -128,6 +179,8 @@ class EnsembleSampler:
     def acceptance_fraction(self):
         return self.get_last_sample()[2] / max(self.iteration, 1)
 
-    def get_autocorr_time(self, c=5.0, tol=50, quiet=True):
+    def get_autocorr_time(self, c=5.0, tol=50, quiet=False):
+        """emcee's default (quiet=False) raises when the chain is shorter than tol autocorrelation times; the
+        reference calls it bare (code/synthetic_datasets/synth_mcmc.py:220)."""
         from .mcmc_io import integrated_time
         return integrated_time(self._chain, c=c, tol=tol, quiet=quiet)

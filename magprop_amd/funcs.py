@@ -16,10 +16,13 @@ def init_conds(MdiscI, P):
     return np.array([MdiscI * Msol, (2.0 * np.pi) / (1.0e-3 * P)])
 
 
-def _curve(cfg, pars, xdata, GRBtype, device):
+def _curve(cfg, pars, xdata, GRBtype, device, dipeff, propeff, f_beam):
     pars = np.asarray(pars, dtype=np.float64)
     if pars.shape != (6,):
         raise ValueError("pars must hold the six parameters B, P, MdiscI, RdiscI, epsilon, delta")
+    # the efficiencies and the beaming fraction travel as parameters 7-9 of the kernel (the 9-parameter form of
+    # magnetar/mcmc_eqns.py:31-34), not in the handle's configuration: a scan over them reuses one cached handle
+    pars = np.concatenate([pars, [float(dipeff), float(propeff), float(f_beam)]])
     eng = engine.engine(cfg, GRBtype, device)
     with eng.lock:
         status, out = eng.handle.model_lc(pars)
@@ -38,23 +41,23 @@ def _curve(cfg, pars, xdata, GRBtype, device):
 
 def model_lc(pars, xdata=None, GRBtype=None, dipeff=0.05, propeff=0.4, f_beam=1.0, n=1.0, alpha=0.1, cs7=1.0,
              k=0.9, device=-1):
-    """magnetar/funcs.py:105-220.  As in the reference, ``n``, ``alpha``, ``cs7`` and ``k`` reach only
-    the luminosity stage: its ``odeint`` call passes five arguments (:150-151), so the ODE always runs
-    with n=1, alpha=0.1, cs7=1, k=0.9.  alpha/cs7/k different from those defaults are rejected here
-    instead of silently integrating one model and lighting another."""
+    """magnetar/funcs.py:105-220.  As in the reference, ``n``, ``alpha``, ``cs7`` and ``k`` reach only the luminosity
+    stage: its ``odeint`` call passes five arguments (:150-151), so the ODE always runs with n=1, alpha=0.1, cs7=1,
+    k=0.9.  In that stage they enter the radii, the fastness and the mass-flow split (:157-185), all of which feed
+    only the accretion torque ``Nacc`` — and the reference's luminosity stage sets ``Nacc = 0`` at every grid point
+    (``rot_param > 0.0`` always holds, :191-193), so ``Lprop`` is identically zero and ``Ltot = f_beam*dipeff*(-Ndip*omega)``
+    does not depend on them.  They are therefore accepted and, exactly as in the reference, change nothing
+    (reference outputs for several non-default values: tests/golden/golden_lib.npz ``lc_L_kw*``)."""
     engine.grid(GRBtype)  # ValueError for a bad GRBtype before anything else, as :138-141
-    if (alpha, cs7, k) != (0.1, 1.0, 0.9):
-        raise NotImplementedError("model_lc: alpha, cs7, k other than the reference defaults are not forwarded "
-                                  "to the ODE by the reference (magnetar/funcs.py:150-151); unsupported")
-    cfg = _capi.cfg_lib(dipeff=dipeff, propeff=propeff, f_beam=f_beam, n_lum=n)
-    return _curve(cfg, pars, xdata, GRBtype, device)
+    for name, v in (("n", n), ("alpha", alpha), ("cs7", cs7), ("k", k)):
+        float(v)          # a non-numeric keyword fails here as it would in the reference's arithmetic
+    return _curve(_capi.cfg_lib(), pars, xdata, GRBtype, device, dipeff, propeff, f_beam)
 
 
 def model_lum(pars, xdata=None, n=10.0, alpha=0.1, cs7=1.0, k=0.9, dipeff=1.0, propeff=1.0, f_beam=1.0, device=-1):
     """code/synthetic_datasets/funcs.py:146-236 (fixed logspace(0,6,10001) grid, all keywords forwarded)."""
-    cfg = _capi.cfg_synth(n_ode=n, n_lum=n, alpha=alpha, cs7=cs7, k=k, dipeff=dipeff, propeff=propeff,
-                          f_beam=f_beam)
-    return _curve(cfg, pars, xdata, None, device)
+    cfg = _capi.cfg_synth(n_ode=n, n_lum=n, alpha=alpha, cs7=cs7, k=k)
+    return _curve(cfg, pars, xdata, None, device, dipeff, propeff, f_beam)
 
 
 def _rhs(cfg, y, t, B, MdiscI, RdiscI, epsilon, delta, device):

@@ -4,6 +4,8 @@
 is then called with ``(n_walkers, ndim)`` arrays (``emcee.EnsembleSampler(..., vectorize=True)``) or a
 single parameter vector.  ``lnprob_device`` works on torch tensors already resident in HBM.
 """
+import threading
+
 import numpy as np
 
 from . import _capi, engine, synth
@@ -11,13 +13,15 @@ from . import _capi, engine, synth
 
 class LogProb:
     def __init__(self, x, y, yerr, variant="synth", GRBtype=None, lower="default", upper="default", log_mask=None,
-                 device=-1, fbad=None):
+                 device=-1, fbad=None, sweep_tol=0.0):
+        """sweep_tol: Newton-sweep tolerance of the time-parallel solver (0 = the library default,
+        include/magprop_amd.h MP_SWEEP_TOL_DEFAULT)."""
         if variant == "synth":
-            cfg = _capi.cfg_synth()
+            cfg = _capi.cfg_synth(sweep_tol=sweep_tol)
             lo, hi, mask = synth.PRIOR_LOWER, synth.PRIOR_UPPER, synth.LOG_MASK
         elif variant == "lib":
             from . import mcmc_eqns
-            cfg = _capi.cfg_lib()
+            cfg = _capi.cfg_lib(sweep_tol=sweep_tol)
             lo, hi = mcmc_eqns._bounds(6)
             mask = mcmc_eqns.LIB_LOG_MASK
         else:
@@ -30,25 +34,43 @@ class LogProb:
         self.handle = _capi.Handle(cfg, engine.grid(GRBtype), device)
         self.handle.set_prior(lo, hi, mask)
         self.n_datasets = 0
+        self._lock = threading.Lock()     # host-buffer calls from several Python threads (ctypes drops the GIL)
         self.add_dataset(x, y, yerr)
         self.fbad = fbad
 
     def add_dataset(self, x, y, yerr):
         """Register a further light curve (mixed lengths allowed); returns its ds_id."""
-        slot = self.n_datasets
-        self.handle.set_dataset(slot, x, y, yerr)
-        self.n_datasets += 1
+        with self._lock:
+            slot = self.n_datasets
+            self.handle.set_dataset(slot, x, y, yerr)
+            self.n_datasets += 1
         return slot
 
     def __call__(self, pars, ds_id=None):
         p = np.asarray(pars, dtype=np.float64)
-        if p.ndim == 1:
-            return float(self.handle.lnprob_batch(p[None, :], ds_id=ds_id)[0])
-        return self.handle.lnprob_batch(p, ds_id=ds_id)
+        scalar = p.ndim == 1
+        with self._lock:
+            out, st = self.handle.lnprob_batch(p[None, :] if scalar else p, ds_id=ds_id, want_status=True)
+        if self.fbad is not None:         # code/synthetic_datasets/mcmc_eqns.py:72-79
+            rows = np.atleast_2d(p)[(st == _capi.STATUS_FLAG) | (st == _capi.STATUS_NONFINITE)]
+            if len(rows):
+                with open(self.fbad, "a") as f:
+                    for r in rows:
+                        f.write(", ".join(f"{v}" for v in r) + "\n")
+        return float(out[0]) if scalar else out
 
-    def lnprob_device(self, pars, out=None, ds_id=None, status=None):
+    def lnprob_and_curves(self, pars, ds_id=None):
+        """(lnprob[n], status[n], Ltot[n, n_grid]): the log-posterior together with every walker's model light curve
+        on the grid in 1e50 erg/s (what model_lum(pars)[1] returns, code/synthetic_datasets/funcs.py:229-231); rows of
+        walkers that did not finish (status != 0) are NaN."""
+        p = np.atleast_2d(np.asarray(pars, dtype=np.float64))
+        with self._lock:
+            return self.handle.lnprob_batch(p, ds_id=ds_id, want_status=True, want_ltot=True)
+
+    def lnprob_device(self, pars, out=None, ds_id=None, status=None, ltot=None):
         """pars: contiguous float64 CUDA tensor (n, ndim) on this handle's device.  Asynchronous on torch's
-        current stream; returns the lnprob tensor."""
+        current stream; returns the lnprob tensor.  ltot: optional (n, n_grid) float64 tensor that receives the model
+        light curves (NaN rows for walkers that did not finish)."""
         import torch
         assert pars.is_cuda and pars.dtype == torch.float64 and pars.is_contiguous()
         n, nd = pars.shape
@@ -57,5 +79,6 @@ class LogProb:
         stream = torch.cuda.current_stream(pars.device).cuda_stream
         self.handle.lnprob_batch_dev(pars.data_ptr(), n, nd, out.data_ptr(),
                                      d_ds_id=ds_id.data_ptr() if ds_id is not None else 0,
-                                     d_status=status.data_ptr() if status is not None else 0, stream=stream)
+                                     d_status=status.data_ptr() if status is not None else 0,
+                                     d_ltot=ltot.data_ptr() if ltot is not None else 0, stream=stream)
         return out

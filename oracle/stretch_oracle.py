@@ -90,3 +90,86 @@ def run(pos, n_steps, seed, a=2.0, lnprob_fn=gaussian_lnprob, n_ensembles=1):
                     chain[step, k] = pos[k]
                     chain_lnp[step, k] = lnp[k]
     return chain, chain_lnp, acc
+
+
+# ---------------------------------------------------------------- the walker-sharded protocol (include/magprop_amd.h:
+# mp_sampler_halfstep_shard / mp_sampler_halfstep_apply), restated on numpy arrays
+def halfstep_rows(pos, lnp, perms, seed, step, half, lo, hi, n, a=2.0, lnprob_fn=gaussian_lnprob):
+    """Outcome rows (proposal, lnprob, accepted, status) of slots [lo, hi) of the active half, all ensembles flattened;
+    `perms[e]` = this step's split of ensemble e (n walkers each).  Reads pos / lnp, changes nothing."""
+    ndim = pos.shape[1]
+    half_n = n // 2
+    rows = np.zeros((hi - lo, ndim + 3))
+    for gs in range(lo, hi):
+        e, slot = divmod(gs, half_n)
+        base, perm = e * n, perms[e]
+        k = base + perm[half * half_n + slot]
+        r = philox4x32_10(seed & M32, seed >> 32, step, half, k, 0)
+        r2 = philox4x32_10(seed & M32, seed >> 32, step, half, k, 1)
+        n_comp = n - half_n
+        jc = int(u01(r[0], r[1]) * n_comp)
+        j = base + perm[(1 - half) * half_n + min(jc, n_comp - 1)]
+        zr = (a - 1.0) * u01(r[2], r[3]) + 1.0
+        zz = zr * zr / a
+        prop = pos[j] - (pos[j] - pos[k]) * zz
+        new = lnprob_fn(prop)
+        lnpdiff = (ndim - 1.0) * np.log(zz) + new - lnp[k]
+        with np.errstate(divide="ignore"):
+            accept = lnpdiff > np.log(u01(r2[0], r2[1]))
+        rows[gs - lo, :ndim] = prop
+        rows[gs - lo, ndim] = new
+        rows[gs - lo, ndim + 1] = 1.0 if accept else 0.0
+    return rows
+
+
+def apply_rows(pos, lnp, acc, perms, half, rows, n, chain_row=None, lnp_row=None):
+    """Commit the gathered outcome rows of one half-step (rows[slot]) to the state, in place."""
+    ndim = pos.shape[1]
+    half_n = n // 2
+    for gs in range(half_n * len(perms)):
+        e, slot = divmod(gs, half_n)
+        k = e * n + perms[e][half * half_n + slot]
+        if rows[gs, ndim + 1] != 0.0:
+            pos[k] = rows[gs, :ndim]
+            lnp[k] = rows[gs, ndim]
+            acc[k] += 1
+        if chain_row is not None:
+            chain_row[k] = pos[k]
+            lnp_row[k] = lnp[k]
+
+
+class NumpyShardEngine:
+    """The engine protocol of magprop_amd.distributed.DistributedEnsembleSampler on CPU tensors (tests of the sharding,
+    the gather layout and the commit order without a GPU)."""
+
+    def __init__(self, n_walkers, ndim, seed, a=2.0, n_ensembles=1, lnprob_fn=gaussian_lnprob):
+        import torch
+        self.device = torch.device("cpu")
+        self.n, self.ndim, self.seed, self.a, self.n_ens, self.fn = n_walkers, ndim, seed, a, n_ensembles, lnprob_fn
+        self.ntotal = n_walkers * n_ensembles
+        self.n_slots = (n_walkers // 2) * n_ensembles
+        self.row_doubles = ndim + 3
+        self.step = 0
+        self.calls = 0
+
+    def set_positions(self, pos):
+        self.pos = np.array(pos, dtype=np.float64)
+        self.lnp = np.array([self.fn(p) for p in self.pos])
+        self.acc = np.zeros(self.ntotal, dtype=np.int64)
+
+    def _perms(self):
+        return [split(self.seed, self.step, e, self.n) for e in range(self.n_ens)]
+
+    def halfstep_shard(self, half, lo, hi, rows):
+        self.calls += hi - lo
+        rows.numpy()[: hi - lo] = halfstep_rows(self.pos, self.lnp, self._perms(), self.seed, self.step, half, lo, hi,
+                                               self.n, self.a, self.fn)
+
+    def halfstep_apply(self, half, rows, chain_row=None, lnp_row=None):
+        apply_rows(self.pos, self.lnp, self.acc, self._perms(), half, rows.numpy(), self.n,
+                   None if chain_row is None else chain_row.numpy(), None if lnp_row is None else lnp_row.numpy())
+        if half == 1:
+            self.step += 1
+
+    def state(self):
+        return self.pos.copy(), self.lnp.copy(), self.acc.copy()

@@ -20,7 +20,7 @@ What is called (paths relative to /root/reference):
 `*_tight` arrays: the same reference code with its odeint call given rtol=atol=1e-12 (integrator noise
 removed; see tight_lsoda).
 Outputs: golden_synth.npz, golden_lib.npz, golden_flagscan.npz, golden_corners.npz, golden_libscan.npz, golden_longlc.npz,
-golden_flagscan2.npz, golden_libscan2.npz, golden_rhs.npz, MANIFEST.json.
+golden_flagscan2.npz, golden_libscan2.npz, golden_rhs.npz, golden_libkw.npz, MANIFEST.json.
 """
 import argparse
 import contextlib
@@ -309,6 +309,33 @@ def make_rhs(n=1500):
     print("rhs:", g["synth_dydt"][:2], g["lib_dydt"][:2])
 
 
+def make_libkw():
+    """model_lc with alpha / cs7 / k / n away from their defaults (magnetar/funcs.py:105-106): the reference integrates
+    with the defaults (:150-151) and lights with the given values (:157-185)."""
+    os.chdir(REF)
+    g = {}
+    pars = np.array(GRB_PARS["Humped"])
+    wide = np.array([3.0, 1.2, 5.0e-2, 300.0, 2.0, 0.5])
+    cases = [dict(alpha=0.3), dict(cs7=2.5), dict(k=0.5), dict(alpha=0.02, cs7=0.4, k=0.99, n=25.0),
+             dict(alpha=0.5, k=0.3, dipeff=0.2, propeff=0.9, f_beam=7.0)]
+    g["n_cases"] = np.array(len(cases))
+    for i, kw in enumerate(cases):
+        g[f"kw{i}_names"] = np.array(sorted(kw))
+        g[f"kw{i}_values"] = np.array([kw[k] for k in sorted(kw)])
+        for kind in ("L", "S"):
+            for tag, p in (("humped", pars), ("wide", wide)):
+                with np.errstate(all="ignore"):
+                    g[f"kw{i}_{kind}_{tag}"] = quiet(lib.model_lc, p, GRBtype=kind, **kw)[:, ::DECIM]
+    g["pars_humped"], g["pars_wide"] = pars, wide
+    x = np.array([1.0, 3.7, 250.0, 9.0e4, 1.0e6])
+    g["xdata"] = x
+    g["kw3_L_humped_xdata"] = quiet(lib.model_lc, pars, xdata=x, GRBtype="L", **cases[3])
+    np.savez_compressed(os.path.join(HERE, "golden_libkw.npz"), **g)
+    same = all(np.array_equal(g[f"kw{i}_L_humped"], lib.model_lc(pars, GRBtype="L", **{k: v for k, v in cases[i].items()
+               if k in ("dipeff", "propeff", "f_beam")})[:, ::DECIM]) for i in range(len(cases)))
+    print("libkw: curves with alpha/cs7/k/n changed equal the default-keyword curves bit for bit:", same)
+
+
 def make_lib():
     os.chdir(REF)  # magnetar/mcmc_eqns.py:55 reads a cwd-relative CSV
     import pandas as pd
@@ -439,7 +466,7 @@ def make_longlc():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--flag-scan", type=int, default=1500)
-    ap.add_argument("--only", choices=["all", "lib", "corners", "libscan", "longlc", "flagscan2", "libscan2", "rhs"], default="all", help="regenerate only one file")
+    ap.add_argument("--only", choices=["all", "lib", "libkw", "corners", "libscan", "longlc", "flagscan2", "libscan2", "rhs"], default="all", help="regenerate only one file")
     a = ap.parse_args()
     import scipy, pandas
     if a.only == "all":
@@ -449,6 +476,8 @@ def main():
         make_corners()
     if a.only in ("all", "lib"):
         make_lib()
+    if a.only in ("all", "libkw"):
+        make_libkw()
     if a.only in ("all", "libscan"):
         make_libscan()
     if a.only in ("all", "longlc"):

@@ -23,11 +23,11 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/magprop_amd.h but not exported"
     assert set(names) == set(_capi.EXPORTS)
-    assert L.mp_abi_version() == 1
+    assert L.mp_abi_version() == _capi.ABI_VERSION == 2
 
 
 def test_cfg_struct_layout_and_presets():
-    assert ctypes.sizeof(_capi.ModelCfg) == 11 * 8 + 2 * 4
+    assert ctypes.sizeof(_capi.ModelCfg) == 11 * 8 + 2 * 4 + 8 and _capi.cfg_synth().sweep_tol == 0.0   # 0 = MP_SWEEP_TOL_DEFAULT
     s, l = _capi.cfg_synth(), _capi.cfg_lib()
     assert (s.inertia_factor, s.rm_massflow_factor, s.n_ode, s.n_lum, s.nacc_lum_threshold, s.lprop_gm_term) == \
         (0.35, 3.0, 10.0, 10.0, 0.27, 1)
@@ -125,3 +125,40 @@ def test_fit_stats_match_reference(glib):
     assert mpa.aicc(yd, ym, ye, 6) == float(glib["fit_aicc_6"])
     with pytest.raises(ValueError, match="same length"):
         mpa.aicc(yd, ym[:-1], ye, 2)
+
+
+def test_model_lc_keyword_goldens_are_keyword_independent():
+    """model_lc(alpha, cs7, k, n != defaults) in the REFERENCE (tests/golden/golden_libkw.npz, made by make_golden.py
+    --only libkw): those keywords reach only its luminosity stage, whose accretion torque is identically zero
+    (magnetar/funcs.py:150-151,191-193), so the reference's curves equal its default-keyword curves.  This is the fact
+    magprop_amd.model_lc relies on when it accepts them without effect (GPU comparison: tests/test_gpu_parity.py)."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "golden_libkw.npz"))
+    lib = np.load(os.path.join(ROOT, "tests", "golden", "golden_lib.npz"))
+    for i in range(int(g["n_cases"])):
+        names = [str(n) for n in g[f"kw{i}_names"]]
+        if not set(names) & {"dipeff", "propeff", "f_beam"}:
+            for kind in ("L", "S"):
+                assert np.array_equal(g[f"kw{i}_{kind}_humped"], lib[f"lc_{kind}"]), (i, kind)
+        assert np.all(g[f"kw{i}_L_humped"][2] == 0.0)           # Lprop == 0 whatever the keywords
+
+
+def test_engine_cache_is_bounded(monkeypatch):
+    """A keyword sweep (one model configuration per value) must not pile up GPU handles: least recently used out."""
+    made, closed = [], []
+
+    class FakeHandle:
+        def __init__(self, cfg, tgrid, device):
+            made.append(self)
+
+        def close(self):
+            closed.append(self)
+
+    monkeypatch.setattr(_capi, "Handle", FakeHandle)
+    engine.clear()
+    first = engine.engine(_capi.cfg_synth(k=0.5))
+    for i in range(engine.MAX_ENGINES + 3):
+        engine.engine(_capi.cfg_synth(alpha=0.01 * (i + 1)))
+        assert engine.engine(_capi.cfg_synth(k=0.5)) is first     # kept alive by use
+    assert len(made) == engine.MAX_ENGINES + 4 and len(closed) == 4 and first.handle not in closed
+    engine.clear()
+    assert len(closed) == len(made)

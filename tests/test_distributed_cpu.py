@@ -81,56 +81,63 @@ def test_sharded_lnprob_gloo_world2(n):
 
 
 # ---------------------------------------------------------------- sharded stretch-move sampler
-def _gauss(p):
-    return -0.5 * (p ** 2).sum(dim=1)
+# The product engine is the HIP sampler (tests/test_gpu_sampler.py runs it across two processes on the GPU box); here the
+# SAME driver class runs the numpy restatement of the shard / gather / commit protocol over gloo.
+N_W, N_DIM, N_ENS, N_STEPS, SEED = 18, 3, 2, 25, 77
+
+
+def _start_positions():
+    return np.random.default_rng(5).normal(size=(N_W * N_ENS, N_DIM)) * 2.0 + 1.0
 
 
 def _sampler_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     sys.path.insert(0, ROOT)
-    from magprop_amd.distributed import DistributedStretchSampler
+    from magprop_amd.distributed import DistributedEnsembleSampler
+    from oracle.stretch_oracle import NumpyShardEngine
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    g = torch.Generator().manual_seed(5)
-    pos = torch.randn(48, 4, dtype=torch.float64, generator=g) * 2.0 + 1.0
-    s = DistributedStretchSampler(_gauss, 48, 4, seed=77)
-    chain, lnp = s.run_mcmc(pos, 60)
-    q.put((rank, chain.numpy().copy(), lnp.numpy().copy(), s.acceptance_fraction.numpy().copy()))
+    eng = NumpyShardEngine(N_W, N_DIM, SEED, n_ensembles=N_ENS)
+    s = DistributedEnsembleSampler(eng)
+    chain, lnp = s.run_mcmc(_start_positions(), N_STEPS)
+    q.put((rank, chain.numpy().copy(), lnp.numpy().copy(), s.acceptance_fraction.copy(), eng.calls, (s.lo, s.hi, s.per)))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_distributed_stretch_sampler_world2_equals_world1():
-    """Sharding the evaluations over two ranks changes nothing: both ranks hold the same chain, equal to the
-    single-process chain with the same seed."""
-    from magprop_amd.distributed import DistributedStretchSampler
+@pytest.mark.parametrize("world", [2, 3])
+def test_distributed_ensemble_sampler_equals_the_single_process_chain(world):
+    """Sharding the half-step's proposals over the ranks changes nothing: every rank ends with the chain of the
+    unsharded restatement of the move (oracle/stretch_oracle.run), bit for bit, having evaluated only its own block."""
+    from oracle import stretch_oracle as so
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29700 + os.getpid() % 200
-    procs = [ctx.Process(target=_sampler_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29700 + (os.getpid() + world) % 200
+    procs = [ctx.Process(target=_sampler_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=180) for _ in procs], key=lambda r: r[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    g = torch.Generator().manual_seed(5)
-    pos = torch.randn(48, 4, dtype=torch.float64, generator=g) * 2.0 + 1.0
-    s = DistributedStretchSampler(_gauss, 48, 4, seed=77)
-    chain, lnp = s.run_mcmc(pos, 60)
-    for rank, c, l, af in res:
-        assert np.array_equal(c, chain.numpy()) and np.array_equal(l, lnp.numpy())
-        assert np.array_equal(af, s.acceptance_fraction.numpy())
+    chain, lnp, acc = so.run(_start_positions(), N_STEPS, SEED, n_ensembles=N_ENS)
+    n_slots = (N_W // 2) * N_ENS
+    total_calls = 0
+    for rank, c, l, af, calls, (lo, hi, per) in res:
+        assert np.array_equal(c, chain) and np.array_equal(l, lnp)
+        assert np.array_equal(af, acc / N_STEPS)
+        assert calls == (hi - lo) * 2 * N_STEPS and lo == min(rank * per, n_slots)
+        total_calls += calls
+    assert total_calls == n_slots * 2 * N_STEPS                     # every proposal evaluated exactly once across the group
 
 
-def test_distributed_stretch_sampler_samples_the_target():
-    from magprop_amd.distributed import DistributedStretchSampler
-    g = torch.Generator().manual_seed(1)
-    s = DistributedStretchSampler(_gauss, 64, 3, seed=3)
-    chain, lnp = s.run_mcmc(torch.randn(64, 3, dtype=torch.float64, generator=g) * 0.1 + 3.0, 1200)
-    tail = chain[400:].reshape(-1, 3)
-    assert torch.all(tail.mean(dim=0).abs() < 0.1)
-    assert torch.all((tail.var(dim=0) - 1.0).abs() < 0.12)
-    assert 0.3 < float(s.acceptance_fraction.mean()) < 0.8
-    assert torch.allclose(lnp[-1], _gauss(chain[-1]))
-    with pytest.raises(ValueError):
-        DistributedStretchSampler(_gauss, 7, 3)
+def test_distributed_ensemble_sampler_single_process_and_continuation():
+    from magprop_amd.distributed import DistributedEnsembleSampler
+    from oracle import stretch_oracle as so
+    eng = so.NumpyShardEngine(N_W, N_DIM, SEED, n_ensembles=N_ENS)
+    s = DistributedEnsembleSampler(eng)
+    c1, l1 = s.run_mcmc(_start_positions(), 10)
+    c2, l2 = s.run_mcmc(None, N_STEPS - 10)                          # continue from the resident state
+    chain, lnp, acc = so.run(_start_positions(), N_STEPS, SEED, n_ensembles=N_ENS)
+    assert np.array_equal(np.concatenate([c1.numpy(), c2.numpy()]), chain)
+    assert np.array_equal(np.concatenate([l1.numpy(), l2.numpy()]), lnp)
+    assert s.run_mcmc(None, 3, store=False) == (None, None) and s.iteration == N_STEPS + 3

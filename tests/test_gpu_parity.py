@@ -199,6 +199,25 @@ def test_lib_light_curves_and_keywords(mpa, glib, kind):
         mpa.model_lc(p, GRBtype="X")
 
 
+def test_lib_model_lc_alpha_cs7_k_keywords(mpa):
+    """model_lc(alpha=, cs7=, k=, n=) against the reference's outputs for the same calls (golden_libkw.npz): the
+    reference integrates with the defaults and lights with the given values (magnetar/funcs.py:150-151,157-185)."""
+    import os
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "golden_libkw.npz"))
+    for i in range(int(g["n_cases"])):
+        kw = {str(k): float(v) for k, v in zip(g[f"kw{i}_names"], g[f"kw{i}_values"])}
+        for kind in ("L", "S"):
+            for tag in ("humped", "wide"):
+                ref = g[f"kw{i}_{kind}_{tag}"]
+                out = mpa.model_lc(g["pars_" + tag], GRBtype=kind, **kw)
+                assert np.array_equal(out[0, ::50], ref[0])
+                assert np.all(np.abs(out[1:, ::50] - ref[1:]) <= 1e-14 + 2e-6 * np.abs(ref[1:])), (i, kind, tag)
+    kw = {str(k): float(v) for k, v in zip(g["kw3_names"], g["kw3_values"])}
+    at = mpa.model_lc(g["pars_humped"], xdata=g["xdata"], GRBtype="L", **kw)
+    assert np.all(np.abs(at - g["kw3_L_humped_xdata"]) <= 2e-6 * np.abs(at))
+
+
 @pytest.mark.parametrize("kind", ["L", "S"])
 def test_lib_lnlike_6_to_9_parameters(mpa, glib, kind):
     import pandas as pd
@@ -328,16 +347,6 @@ def test_long_light_curves_every_kernel_variant(mpa, co, gsynth, tarr, nw):
     sub = np.r_[0:3, 4:9]
     small = lp_(P[sub], ds_id=ids[sub])
     assert np.allclose(small, out[sub], rtol=1e-10, atol=1e-9)
-    # ... and through the 4-barrier-coupled-wavefronts kernel (MAGPROP_AMD_WPW=4, read when a handle is created)
-    import os
-    os.environ["MAGPROP_AMD_WPW"] = "4"
-    try:
-        lp4 = LogProb(*sets[0])
-    finally:
-        del os.environ["MAGPROP_AMD_WPW"]
-    for s_ in sets[1:]:
-        lp4.add_dataset(*s_)
-    assert np.allclose(lp4(P[sub], ds_id=ids[sub]), out[sub], rtol=1e-10, atol=1e-9)
     # repeatable bit for bit (the scratch rows carry nothing over from one launch to the next)
     assert np.array_equal(lp_(P, ds_id=ids), out)
 

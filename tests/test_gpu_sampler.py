@@ -1,4 +1,6 @@
 """GPU tests of the fused stretch-move ensemble sampler through the C ABI."""
+import os
+
 import numpy as np
 import pytest
 
@@ -35,7 +37,6 @@ def test_two_ensembles_match_the_oracle():
     from oracle import stretch_oracle as so
     rng = np.random.default_rng(6)
     pos = rng.normal(size=(2 * 16, 2))
-    s = EnsembleSampler(16, 2, target="gaussian", seed=11, datasets=[(None, None, None)] * 2) if False else None
     # two Gaussian ensembles advanced together: built through the C ABI directly (no datasets needed for target 1)
     import ctypes as C
     from magprop_amd import _capi, engine
@@ -64,7 +65,7 @@ def test_gaussian_target_statistics():
     assert np.all(np.abs(tail.var(axis=0) - 1.0) < 0.06)
     af = s.acceptance_fraction
     assert 0.3 < af.mean() < 0.7
-    tau = s.get_autocorr_time()
+    tau = s.get_autocorr_time(quiet=True)
     assert tau.shape == (6,) and np.all(tau > 1.0) and np.all(tau < 200.0)
 
 
@@ -125,9 +126,8 @@ def test_sampler_on_a_long_light_curve(gsynth):
     yerr = 0.2 * y0
     y = y0 + rng.normal(0, yerr)
     import os
-    for nwalk, env in ((32, {}), (640, {}), (2600, {}), (32, {"MAGPROP_AMD_WPW": "4"})):
-        # producer/consumer pair (half-steps of 16 and 320 proposals), one wavefront per walker (1 300), and the
-        # 4-barrier-coupled-wavefronts kernel behind its environment switch (read when the sampler's handle is created)
+    for nwalk, env in ((32, {}), (640, {}), (2600, {})):
+        # producer/consumer pair (half-steps of 16 and 320 proposals) and one wavefront per walker (1 300)
         pos = truth + 1.0e-4 * rng.standard_normal((nwalk, 6))
         os.environ.update(env)
         try:
@@ -230,3 +230,92 @@ def test_sharded_lnprob_pipelined_over_rccl(gsynth):
         assert torch.equal(sh(batches[0]), want[0])              # blocking form
     finally:
         dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------- walker-sharded ensembles
+def _sharded_case(case, world=2):
+    import torch.multiprocessing as tmp
+    from _shard_worker import run
+    ctx = tmp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29300 + (os.getpid() + case["seed"]) % 300
+    procs = [ctx.Process(target=run, args=(r, world, port, case, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return res
+
+
+def test_sharded_sampler_gaussian_two_ranks_equal_the_fused_chain_and_the_oracle():
+    """Two processes, each evaluating its half of every half-step's proposals with the fused kernel, one gather of the
+    outcome rows, commit on both: the chain of mp_sampler_run (single GPU) bit for bit — and of the numpy restatement."""
+    from magprop_amd import EnsembleSampler
+    from oracle import stretch_oracle as so
+    rng = np.random.default_rng(21)
+    case = {"nwalkers": 66, "ndim": 3, "seed": 4242, "target": "gaussian", "nsteps": 40, "datasets": None,
+            "pos": rng.normal(size=(66, 3)) * 1.5}
+    res = _sharded_case(case)                                  # one ensemble of 66 walkers: slots 0..32 split 17 / 16
+    s = EnsembleSampler(66, 3, target="gaussian", seed=4242)
+    s.run_mcmc(case["pos"], 40)
+    ref_chain, ref_lnp, ref_acc = so.run(case["pos"], 40, 4242)
+    assert np.array_equal(s.get_chain(), ref_chain)
+    for rank, chain, lnp, af, (lo, hi), _ in res:
+        assert np.array_equal(chain, ref_chain) and np.array_equal(lnp, ref_lnp), rank
+        assert np.array_equal(af, ref_acc / 40)
+    assert [r[4] for r in res] == [(0, 17), (17, 33)]
+
+
+def test_sharded_sampler_posterior_two_ranks_equal_the_fused_chain(gsynth):
+    """The magnetar posterior, two ensembles (a 50-point and a 300-point light curve: scratch rows in play), 2 x 48
+    walkers over two ranks: bit-identical to the single-GPU fused sampler, failed proposals logged on both ranks."""
+    from magprop_amd import EnsembleSampler, engine, model_lum
+    rng = np.random.default_rng(31)
+    tarr = engine.grid(None)
+    phys = np.array(TRUTHS["Classic"])
+    phys[2:] = 10.0 ** phys[2:]
+    x = np.sort(10.0 ** rng.uniform(0.0, 6.0, 300))
+    y0 = model_lum(phys, xdata=x)
+    sets = [(gsynth["Humped_x"], gsynth["Humped_y"], gsynth["Humped_yerr"]), (x, y0 + rng.normal(0, 0.2 * y0), 0.2 * y0)]
+    pos = np.concatenate([np.array(TRUTHS["Humped"]) + 0.3 * rng.standard_normal((48, 6)),      # wide: some proposals fail
+                          np.array(TRUTHS["Classic"]) + 1.0e-3 * rng.standard_normal((48, 6))])
+    pos = np.clip(pos, gsynth["prior_lower"] + 1e-6, gsynth["prior_upper"] - 1e-6)
+    case = {"nwalkers": 48, "ndim": 6, "seed": 99, "target": "posterior", "nsteps": 30, "datasets": sets, "pos": pos}
+    res = _sharded_case(case)
+    s = EnsembleSampler(48, 6, datasets=sets, seed=99)
+    s.run_mcmc(pos, 30)
+    n_bad = s.get_bad()[0]
+    for rank, chain, lnp, af, (lo, hi), nb in res:
+        assert np.array_equal(chain, s.get_chain()) and np.array_equal(lnp, s.get_log_prob()), rank
+        assert np.array_equal(af, s.acceptance_fraction) and nb == n_bad
+    assert tarr[0] <= x[0]
+
+
+def test_sharded_entry_points_in_one_process_and_fbad(gsynth, tmp_path):
+    """World size one through the shard / apply entry points equals mp_sampler_run; the failed proposals reach the fbad
+    file like the reference's lnprob(…, fbad) (code/synthetic_datasets/mcmc_eqns.py:72-79)."""
+    import torch
+    from magprop_amd import EnsembleSampler, LogProb
+    from magprop_amd.distributed import DistributedEnsembleSampler, HipShardEngine
+    x, y, yerr = gsynth["Humped_x"], gsynth["Humped_y"], gsynth["Humped_yerr"]
+    rng = np.random.default_rng(3)
+    lo, hi = gsynth["prior_lower"], gsynth["prior_upper"]
+    pos = lo + (hi - lo) * rng.random((64, 6))                 # prior-wide start: plenty of break-up failures early on
+    fbad = tmp_path / "bad.csv"
+    a = EnsembleSampler(64, 6, x, y, yerr, seed=12, fbad=str(fbad))
+    a.run_mcmc(pos, 25)
+    b = EnsembleSampler(64, 6, x, y, yerr, seed=12)
+    d = DistributedEnsembleSampler(HipShardEngine(b, f"cuda:{b.handle.device}"))
+    chain, lnp = d.run_mcmc(pos, 25)
+    torch.cuda.synchronize()
+    assert np.array_equal(chain.cpu().numpy(), a.get_chain()) and np.array_equal(lnp.cpu().numpy(), a.get_log_prob())
+    n_bad, rows = a.get_bad()
+    assert n_bad == b.get_bad()[0] and n_bad > 0 and len(rows) == min(n_bad, 4096)
+    logged = np.loadtxt(fbad, delimiter=",", ndmin=2)
+    assert logged.shape == (len(rows), 6) and np.allclose(logged, rows, rtol=1e-15)
+    # every logged row is inside the prior and fails in the model (status flag / non-finite), as in the reference
+    lp_ = LogProb(x, y, yerr)
+    out, st = lp_.handle.lnprob_batch(rows, want_status=True)
+    assert np.all((st == 1) | (st == 2)) and np.all(out == -np.inf)

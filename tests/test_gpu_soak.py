@@ -64,8 +64,7 @@ def test_every_kernel_variant_against_the_c_oracle(gsynth, tarr):
     summary = {"n": N_SOAK, "oracle_status_counts": np.bincount(rst, minlength=4).tolist(), "variants": {}}
     for batch, label, env in ((256, "producer/consumer pair of wavefronts", {}),
                               (1024, "1 wavefront, 4 steps per lane", {}),
-                              (4096, "1 wavefront, 2 steps per lane", {}),
-                              (256, "4 barrier-coupled wavefronts (MAGPROP_AMD_WPW=4)", {"MAGPROP_AMD_WPW": "4"})):
+                              (4096, "1 wavefront, 2 steps per lane", {})):
         os.environ.update(env)                                    # read when the handle is created
         try:
             lp_ = LogProb(*sets[0])

@@ -30,7 +30,7 @@ def main():
         dt = time.perf_counter() - t0
         chain = s.get_chain()[burn:].reshape(-1, 6)
         lo, med, hi = np.percentile(chain, [16, 50, 84], axis=0)
-        tau = s.get_autocorr_time()
+        tau = s.get_autocorr_time(quiet=True)
         inside = np.sum((np.array(truth) >= np.percentile(chain, 2.5, axis=0)) & (np.array(truth) <= np.percentile(chain, 97.5, axis=0)))
         print(f"{grb}: {nwalk * nstep / dt / 1e6:.2f} M walker-steps/s, acceptance {s.acceptance_fraction.mean():.3f}, "
               f"mean tau {np.mean(tau):.0f}, truths inside the central 95 %: {inside}/6")

@@ -53,7 +53,7 @@ def main(argv=None):
     s.run_mcmc(pos, a.n_step)
     dt = time.perf_counter() - t0
     mcmc_io.write_chain_files(base, s.get_chain(), s.get_log_prob())
-    tau = s.get_autocorr_time()
+    tau = s.get_autocorr_time(quiet=True)
     info = mcmc_io.write_info(base + "_info.json", 6, a.n_walk, a.n_step, a.seed, s.acceptance_fraction, tau)
     print(f"{a.grb}\nMean acceptance fraction: {info['acceptance_fraction']}\nAverage auto-correlation time: {np.mean(tau):.3f}")
     print(f"{a.n_walk * (a.n_step + 1)} lnprob evaluations in {dt:.3f} s ({a.n_walk * a.n_step / dt:.0f} walker-steps/s); files under {a.out}/")
