@@ -96,9 +96,13 @@ typedef struct mp_model_cfg {
                                /* time-parallel solver; 0 = MP_SWEEP_TOL_DEFAULT.  What it buys and costs: DESIGN.md 3     */
 } mp_model_cfg;
 
-/* The reference integrates with LSODA at rtol = atol ~ 1.5e-8 and its lnprob carries up to 1.4e-5 relative integrator
- * noise.  Default here: sweeps contract by 1e-2..1e-3 per pass, so stopping at 1e-9 leaves <= 4e-11 relative in lnprob. */
-#define MP_SWEEP_TOL_DEFAULT 1.0e-9
+/* The sweeps contract by 1e-2..1e-3 per pass, so a tile whose last correction was <= 1e-7 relative is converged to
+ * <= 4.5e-9 relative in lnprob (measured over the golden clouds and the prior-wide scans, tools/tol_scan.py) — 10x below
+ * the 6e-8 by which the scheme itself differs from the reference integrated at rtol = atol = 1e-12, and 3000x below the
+ * reference's own LSODA noise (1.4e-5).  MP_SWEEP_TOL_STRICT (1e-9: <= 4e-11) is what the tests use when they compare
+ * kernel variants with each other and with the serial restatement of the scheme. */
+#define MP_SWEEP_TOL_DEFAULT 1.0e-7
+#define MP_SWEEP_TOL_STRICT 1.0e-9
 
 typedef struct mp_handle mp_handle;
 

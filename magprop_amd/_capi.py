@@ -161,9 +161,15 @@ def check(rc, what):
     raise MagpropAmdError(f"{what} failed (rc={rc}): {msg}")
 
 
+SWEEP_TOL_DEFAULT, SWEEP_TOL_STRICT = 1.0e-7, 1.0e-9   # include/magprop_amd.h MP_SWEEP_TOL_*
+DEFAULT_SWEEP_TOL = 0.0   # what cfg_synth()/cfg_lib() put into mp_model_cfg.sweep_tol (0 = the library default); the test
+                          # suite sets SWEEP_TOL_STRICT here for its kernel-vs-serial-restatement comparisons
+
+
 def cfg_synth(**kw):
     c = ModelCfg()
     lib().mp_cfg_synth(C.byref(c))
+    c.sweep_tol = DEFAULT_SWEEP_TOL
     for k, v in kw.items():
         setattr(c, k, v)
     return c
@@ -172,6 +178,7 @@ def cfg_synth(**kw):
 def cfg_lib(**kw):
     c = ModelCfg()
     lib().mp_cfg_lib(C.byref(c))
+    c.sweep_tol = DEFAULT_SWEEP_TOL
     for k, v in kw.items():
         setattr(c, k, v)
     return c

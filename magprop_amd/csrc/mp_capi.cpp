@@ -316,7 +316,7 @@ mp_handle *mp_create(const mp_model_cfg *cfg, const double *tgrid, int n_grid, i
     s.force_spl = 0;
     if (const char *e = std::getenv("MAGPROP_AMD_SPL")) {          // experiments only
         const int v = std::atoi(e);
-        if (v == 2 || v == 4) s.force_spl = v;
+        if (v == 1 || v == 2 || v == 4) s.force_spl = v;
     }
     s.force_pc = 0;
     if (const char *e = std::getenv("MAGPROP_AMD_PC")) {           // experiments only

@@ -38,11 +38,18 @@
 
 #include "mp_eval.hpp"
 
+#ifndef MP_WPE_SPL2
+#define MP_WPE_SPL2 2   // resident waves per SIMD the 2-steps-per-lane kernels are compiled for
+#endif
+#ifndef MP_WPE_SPL1
+#define MP_WPE_SPL1 4
+#endif
+
 namespace mp {
 
 // ---------------------------------------------------------------- batched log-posterior kernel
 template <bool CURVES, int SPL, bool LONG>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, SPL >= 4 ? 1 : 2))) void lnprob_kernel(const DevShared sh, const LaunchArgs a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPL >= 4 ? 1 : (SPL == 2 ? MP_WPE_SPL2 : MP_WPE_SPL1), SPL >= 4 ? 1 : (SPL == 2 ? MP_WPE_SPL2 : MP_WPE_SPL1)))) void lnprob_kernel(const DevShared sh, const LaunchArgs a) {
     __shared__ double Lbuf[2 * (64 * SPL + 1)];
     ktab_init();
     const int walker = blockIdx.x;
@@ -251,6 +258,7 @@ __global__ __launch_bounds__(256) void stretch_apply_kernel(const StretchArgs g)
 // (funcs.py:119,131-140).  Serves `odes`/`ODEs` of the Python front end and pins the simplified algebra of the kernels
 // against the reference's literal formulas point by point.
 __global__ __launch_bounds__(64) void rhs_kernel(const DevShared sh, const RhsArgs r) {
+    ktab_init();
     const int i = blockIdx.x * 64 + threadIdx.x;
     const int ii = min(i, r.n - 1);                       // idle lanes repeat the last point (wave-wide votes inside)
     double par[MP_MAX_NDIM];
@@ -303,6 +311,9 @@ int launch_lnprob(const DevShared &sh, const LaunchArgs &a, void *stream) {
     } else if (wide) {
         if (lng) hipLaunchKernelGGL((lnprob_kernel<false, 4, true>), grid, block, 0, st, sh, a);
         else hipLaunchKernelGGL((lnprob_kernel<false, 4, false>), grid, block, 0, st, sh, a);
+    } else if (sh.force_spl == 1) {   // experiments (MAGPROP_AMD_SPL=1): one step per lane, 64-step tiles
+        if (lng) hipLaunchKernelGGL((lnprob_kernel<false, 1, true>), grid, block, 0, st, sh, a);
+        else hipLaunchKernelGGL((lnprob_kernel<false, 1, false>), grid, block, 0, st, sh, a);
     } else {
         if (lng) hipLaunchKernelGGL((lnprob_kernel<false, 2, true>), grid, block, 0, st, sh, a);
         else hipLaunchKernelGGL((lnprob_kernel<false, 2, false>), grid, block, 0, st, sh, a);

@@ -102,7 +102,7 @@ MP_DEV void horner(Vd<N> &p, const Vd<N> &x, double c) {
 // log2(e), -ln2_hi, -ln2_lo, pad.  Filled by ktab_init() at kernel entry.
 typedef double d2v __attribute__((ext_vector_type(2)));
 template <int N>
-constexpr bool kUseKtab = N == 2;
+constexpr bool kUseKtab = N <= 2;
 constexpr int kKtabN = 18;
 __shared__ __attribute__((aligned(16))) double g_ktab[kKtabN];
 

@@ -20,7 +20,7 @@ from . import _capi, engine, synth
 class EnsembleSampler:
     def __init__(self, nwalkers, ndim=6, x=None, y=None, yerr=None, variant="synth", GRBtype=None, seed=0, a=2.0,
                  datasets=None, lower="default", upper="default", log_mask=None, device=-1, target="posterior",
-                 fbad=None, sweep_tol=0.0):
+                 fbad=None, sweep_tol=None):
         """One ensemble on dataset (x, y, yerr), or one ensemble per entry of `datasets` = [(x, y, yerr), ...].
         fbad: file that receives the proposals whose model failed, like the reference's lnprob(…, fbad)
         (code/synthetic_datasets/mcmc_eqns.py:72-79); written after every run_mcmc call."""
@@ -28,11 +28,12 @@ class EnsembleSampler:
             raise ValueError("nwalkers must be even")            # emcee requires an even number too
         self.nwalkers, self.ndim = int(nwalkers), int(ndim)
         self._L = _capi.lib()
+        tol_kw = {} if sweep_tol is None else {"sweep_tol": float(sweep_tol)}   # None: _capi.DEFAULT_SWEEP_TOL
         if variant == "synth":
-            cfg, lo, hi, mask = _capi.cfg_synth(sweep_tol=sweep_tol), synth.PRIOR_LOWER, synth.PRIOR_UPPER, synth.LOG_MASK
+            cfg, lo, hi, mask = _capi.cfg_synth(**tol_kw), synth.PRIOR_LOWER, synth.PRIOR_UPPER, synth.LOG_MASK
         elif variant == "lib":
             from . import mcmc_eqns
-            cfg = _capi.cfg_lib(sweep_tol=sweep_tol)
+            cfg = _capi.cfg_lib(**tol_kw)
             lo, hi = mcmc_eqns._bounds(ndim)
             mask = mcmc_eqns.LIB_LOG_MASK
         else:

@@ -13,15 +13,16 @@ from . import _capi, engine, synth
 
 class LogProb:
     def __init__(self, x, y, yerr, variant="synth", GRBtype=None, lower="default", upper="default", log_mask=None,
-                 device=-1, fbad=None, sweep_tol=0.0):
+                 device=-1, fbad=None, sweep_tol=None):
         """sweep_tol: Newton-sweep tolerance of the time-parallel solver (0 = the library default,
         include/magprop_amd.h MP_SWEEP_TOL_DEFAULT)."""
+        tol_kw = {} if sweep_tol is None else {"sweep_tol": float(sweep_tol)}   # None: _capi.DEFAULT_SWEEP_TOL
         if variant == "synth":
-            cfg = _capi.cfg_synth(sweep_tol=sweep_tol)
+            cfg = _capi.cfg_synth(**tol_kw)
             lo, hi, mask = synth.PRIOR_LOWER, synth.PRIOR_UPPER, synth.LOG_MASK
         elif variant == "lib":
             from . import mcmc_eqns
-            cfg = _capi.cfg_lib(sweep_tol=sweep_tol)
+            cfg = _capi.cfg_lib(**tol_kw)
             lo, hi = mcmc_eqns._bounds(6)
             mask = mcmc_eqns.LIB_LOG_MASK
         else:

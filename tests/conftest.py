@@ -62,6 +62,20 @@ def pytest_collection_modifyitems(config, items):
             it.add_marker(skip)
 
 
+@pytest.fixture
+def strict():
+    """Newton-sweep tolerance 1e-9 (MP_SWEEP_TOL_STRICT) for every handle created inside the test: used where the HIP
+    kernels are compared with the serial C restatement of the scheme or with each other (1e-10).  Everything that is
+    compared with the reference's golden values runs at the product's default tolerance."""
+    from magprop_amd import _capi, engine
+    engine.clear()
+    old = _capi.DEFAULT_SWEEP_TOL
+    _capi.DEFAULT_SWEEP_TOL = _capi.SWEEP_TOL_STRICT
+    yield
+    _capi.DEFAULT_SWEEP_TOL = old
+    engine.clear()
+
+
 @pytest.fixture(scope="session")
 def gsynth():
     return np.load(os.path.join(GOLDEN, "golden_synth.npz"))

@@ -87,8 +87,11 @@ def test_mode_b_batched_light_curves(gsynth, gflag, tarr, n):
             if same_variant:
                 assert np.array_equal(lt[i], out_i[1]), i
             else:
-                worst = max(worst, float(np.max(np.abs(lt[i] - out_i[1]) / (np.abs(out_i[1]) + 1e-12 * out_i[1].max()))))
-    assert worst <= 1e-9, worst
+                # the other kernel variant (tiles of 128 instead of 256 steps) at the product's default sweep tolerance:
+                # the light curve of a prior-wide walker agrees to ~3e-7 where the propeller switches on or off (3e-8 at
+                # the strict tolerance; the reference's own LSODA noise on these curves is 1e-6 ... 5e-6)
+                worst = max(worst, float(np.max(np.abs(lt[i] - out_i[1]) / (np.abs(out_i[1]) + 1e-3 * out_i[1].max()))))
+    assert worst <= 1e-6, worst
     # the canonical rows against the reference's model_lum (golden_synth.npz, decimated; LSODA noise ~1e-6)
     d = int(gsynth["decim"])
     for k, t in enumerate(TYPES):
@@ -103,8 +106,10 @@ def test_mode_b_batched_light_curves(gsynth, gflag, tarr, n):
     inside[[5, 6]] = False
     assert np.array_equal(st_s[inside], st_b[inside])
     both = ok & inside
-    assert np.allclose(lt_s[both], lt[both], rtol=1e-10, atol=0.0)
-    assert np.allclose(lnp_s[both], lnp_b[both], rtol=1e-10, atol=1e-9)
+    # (a last-bit change of a parameter moves a prior-wide curve by up to ~1e-9 where the propeller switches)
+    scale = lt[both].max(axis=1, keepdims=True)
+    assert np.all(np.abs(lt_s[both] - lt[both]) <= 1e-8 * np.abs(lt[both]) + 1e-10 * scale)
+    assert np.allclose(lnp_s[both], lnp_b[both], rtol=1e-8, atol=1e-9)
     assert np.all(np.isnan(lt_s[~ok]))
     hp.close()
     hs.close()
@@ -163,9 +168,11 @@ def test_config5_four_types_mixed_lengths_one_launch(gsynth, glonglc, tarr, co):
     from magprop_amd import LogProb
     sets = _config5_sets(gsynth, glonglc, tarr)
     assert sorted(len(s[0]) for s in sets) == [8, 50, 50, 50, 50, 63, 64, 65, 112, 410, 1944]
-    lp_ = LogProb(*sets[0])
+    lp_ = LogProb(*sets[0])                                    # product default: against the reference's values
+    lps = LogProb(*sets[0], sweep_tol=1.0e-9)                  # strict: against the serial restatement of the scheme
     for s in sets[1:]:
         lp_.add_dataset(*s)
+        lps.add_dataset(*s)
     rng = np.random.default_rng(2026)
     nw = 1024
     P = np.empty((4 * nw, 6))
@@ -197,12 +204,16 @@ def test_config5_four_types_mixed_lengths_one_launch(gsynth, glonglc, tarr, co):
         assert np.all(o[~ok] == -np.inf)
     sample = np.concatenate([rng.choice(4096, 300, replace=False), [0, 1023, 1024, 2047, 2048, 3071, 3072, 4095],
                              np.nonzero(ids == 6)[0][:6], np.nonzero(ids == 7)[0][:6]])
+    out_s, st_s = lps.handle.lnprob_batch(P, ds_id=ids, want_status=True)
+    assert np.array_equal(st_s, st)
+    fin = st == 0
+    assert np.all(np.abs(out[fin] - out_s[fin]) <= 2e-8 * np.abs(out_s[fin]) + 1e-9)       # default vs strict sweep tolerance
     for i in sample:
         x, y, yerr = sets[ids[i]]
         ref, rs = co.lnprob_batch(co.cfg_synth(), P[i], tarr, x, y, yerr, gsynth["prior_lower"], gsynth["prior_upper"], LOG_MASK)
         assert st[i] == rs[0], (i, st[i], rs[0])
         if rs[0] == 0:
-            assert abs(out[i] - ref[0]) <= 1e-9 * abs(ref[0]) + 1e-9, (i, ids[i], out[i], ref[0])
+            assert abs(out_s[i] - ref[0]) <= 1e-9 * abs(ref[0]) + 1e-9, (i, ids[i], out_s[i], ref[0])
     # size-independent properties at full size: a permutation of the batch permutes the result bit for bit, and the
     # four types evaluated separately (1 024 each: another kernel variant) agree to rounding
     perm = rng.permutation(4096)
@@ -213,7 +224,7 @@ def test_config5_four_types_mixed_lengths_one_launch(gsynth, glonglc, tarr, co):
         o_k = lp_.handle.lnprob_batch(P[blk], ds_id=ids[blk])
         fin = np.isfinite(out[blk])
         assert np.array_equal(np.isfinite(o_k), fin)
-        assert np.allclose(o_k[fin], out[blk][fin], rtol=1e-9, atol=1e-9)
+        assert np.allclose(o_k[fin], out[blk][fin], rtol=1e-8, atol=1e-9)
 
 
 def test_config5_through_the_ensemble_sampler(gsynth, glonglc, tarr):
@@ -238,7 +249,7 @@ def test_config5_through_the_ensemble_sampler(gsynth, glonglc, tarr):
     ids = np.repeat(np.arange(4, dtype=np.int32), nw)
     for row in (0, nsteps - 1):
         ref = lp_(chain[row], ds_id=ids)
-        assert np.allclose(ref, lnp[row], rtol=1e-9, atol=1e-9)
+        assert np.allclose(ref, lnp[row], rtol=1e-8, atol=1e-9)
     af = s.acceptance_fraction.reshape(4, nw).mean(axis=1)
     assert np.all(af > 0.2) and np.all(af < 0.95), af
     moved = np.any(chain[-1] != pos, axis=1).reshape(4, nw).mean(axis=1)

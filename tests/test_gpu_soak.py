@@ -12,6 +12,7 @@ from conftest import TRUTHS, TYPES
 pytestmark = pytest.mark.gpu
 LOG_MASK = 0b111100
 N_SOAK = int(os.environ.get("MAGPROP_SOAK_N", "32768"))
+STRICT = 1.0e-9   # MP_SWEEP_TOL_STRICT: the kernels against the serial restatement of the scheme
 
 
 def _walkers(rng, n, lo, hi):
@@ -64,13 +65,10 @@ def test_every_kernel_variant_against_the_c_oracle(gsynth, tarr):
     summary = {"n": N_SOAK, "oracle_status_counts": np.bincount(rst, minlength=4).tolist(), "variants": {}}
     for batch, label, env in ((256, "producer/consumer pair of wavefronts", {}),
                               (1024, "1 wavefront, 4 steps per lane", {}),
-                              (4096, "1 wavefront, 2 steps per lane", {})):
-        os.environ.update(env)                                    # read when the handle is created
-        try:
-            lp_ = LogProb(*sets[0])
-        finally:
-            for k_ in env:
-                del os.environ[k_]
+                              (4096, "1 wavefront, 2 steps per lane", {}),
+                              (4096, "1 wavefront, 2 steps per lane, default sweep tolerance", {"default_tol": True})):
+        loose = bool(env.get("default_tol"))                      # the product's default: 1e-7 (include/magprop_amd.h)
+        lp_ = LogProb(*sets[0], sweep_tol=None if loose else STRICT)
         for s in sets[1:]:
             lp_.add_dataset(*s)
         out = np.empty(N_SOAK)
@@ -89,8 +87,9 @@ def test_every_kernel_variant_against_the_c_oracle(gsynth, tarr):
         assert not np.any(np.isnan(out))
         assert np.all(out[st != 0] == -np.inf)
         assert np.sum(rst != st) <= max(2, N_SOAK // 4000), summary["variants"][label]
-        assert rel.max() <= 1e-9, summary["variants"][label]
-        assert np.quantile(rel, 0.999) <= 1e-10, summary["variants"][label]
+        # default tolerance (1e-7): observed max 2.1e-8 over the 32 768 walkers, 99.9 % below 1e-8
+        assert rel.max() <= (5e-8 if loose else 1e-9), summary["variants"][label]
+        assert np.quantile(rel, 0.999) <= (1e-8 if loose else 1e-10), summary["variants"][label]
     out_dir = os.path.join(os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(__file__))), "gpurun_out")
     if os.path.isdir(out_dir):
         with open(os.path.join(out_dir, "soak_parity.json"), "w") as f:
@@ -115,7 +114,7 @@ def test_library_variant_against_the_c_oracle(glib, tarr):
         res = pool.map(oracle_slice, [("lib", P[p], ds, tarr, lo, hi, mcmc_eqns.LIB_LOG_MASK) for p in parts], chunksize=1)
     ref = np.concatenate([r[0] for r in res])
     rst = np.concatenate([r[1] for r in res])
-    lp_ = LogProb(*ds, variant="lib", lower=lo, upper=hi)
+    lp_ = LogProb(*ds, variant="lib", lower=lo, upper=hi, sweep_tol=STRICT)
     for batch in (256, 1024, 4096):
         out = np.empty(n)
         st = np.empty(n, dtype=np.int32)
