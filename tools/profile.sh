@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/profile.sh <tag> [bench args...] — run ON THE GPU BOX (through gpurun).  Produces under gpurun_out/prof_<tag>/:
+# [KERN=<kernel name fragment>] tools/profile.sh <tag> [bench args...] — run ON THE GPU BOX (through gpurun).  Produces under gpurun_out/prof_<tag>/:
 #   trace/  rocprofv3 --kernel-trace --stats of `bench.py`      (per-kernel time)
 #   pmc_sq/ pmc_fetch/ pmc_write/  separate --pmc passes        (VALU issue mix; HBM bytes: MI355X_MICROARCH.md HBM section)
 # Copy the summary written by tools/summarize_prof.py into profiles/ to have it judged.
@@ -16,5 +16,5 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d
 rocprofv3 --kernel-trace --pmc WRITE_SIZE SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $OUT/pmc_write -- python3 $REPO/bench.py $ARGS > $OUT/bench_pmc_write.json 2> $OUT/pmc_write.log || exit 4
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_FLOPS_FP64 --output-format csv -d $OUT/pmc_mix -- python3 $REPO/bench.py $ARGS > $OUT/bench_pmc_mix.json 2> $OUT/pmc_mix.log || exit 5
 rocprofv3 --kernel-trace --pmc SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_IFETCH SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_INSTS_VALU_FLOPS_FP64_TRANS SQ_INSTS_VALU_INT64 --output-format csv -d $OUT/pmc_misc -- python3 $REPO/bench.py $ARGS > $OUT/bench_pmc_misc.json 2> $OUT/pmc_misc.log || exit 6
-python3 $REPO/tools/summarize_prof.py $OUT $TAG > $OUT/summary.md
+python3 $REPO/tools/summarize_prof.py $OUT $TAG ${KERN:-lnprob_kernel} > $OUT/summary.md
 cat $OUT/summary.md

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Condense a tools/profile.sh output directory into a short markdown + JSON summary (per-launch numbers
-for the dominant kernel mp::lnprob_kernel)."""
+"""Condense a tools/profile.sh output directory into a short markdown + JSON summary: per-launch numbers of ONE kernel
+(name fragment = third argument or $KERN, default "lnprob_kernel"; e.g. stretch_kernel, lnprob_pc_kernel)."""
 import csv
 import glob
 import json
@@ -9,7 +9,7 @@ import sys
 from collections import defaultdict
 
 out, tag = sys.argv[1], sys.argv[2]
-KERN = "lnprob_kernel"
+KERN = sys.argv[3] if len(sys.argv) > 3 else os.environ.get("KERN", "lnprob_kernel")
 
 
 def find(sub, pat):
@@ -51,7 +51,7 @@ avg = {k: sum(v) / len(v) for k, v in counters.items()}
 summary["counters_per_launch"] = avg
 summary["dispatch"] = meta
 if avg:
-    lines += ["## PMC counters, average per launch of `mp::lnprob_kernel`", "", "| counter | value |", "|---|---|"]
+    lines += ["## PMC counters, average per launch of `mp::%s`" % KERN, "", "| counter | value |", "|---|---|"]
     for k in sorted(avg):
         lines.append(f"| {k} | {avg[k]:.6g} |")
     lines.append("")
@@ -85,6 +85,9 @@ if avg:
         d["hbm_write_bytes"] = avg["WRITE_SIZE"] * 1024.0
     if "hbm_read_bytes_raw" in d and "hbm_write_bytes" in d:
         d["traffic_bytes_per_launch"] = d["hbm_read_bytes_x2_gfx950"] + d["hbm_write_bytes"]
+        if "kernel_avg_us" in summary:
+            d["hbm_write_GBps"] = d["hbm_write_bytes"] / (summary["kernel_avg_us"] * 1e-6) / 1e9
+            d["hbm_traffic_GBps"] = d["traffic_bytes_per_launch"] / (summary["kernel_avg_us"] * 1e-6) / 1e9
     summary["derived"] = d
     lines += ["## derived", "", "| quantity | value |", "|---|---|"]
     for k, v in d.items():
@@ -97,7 +100,9 @@ for b in ("bench_trace.json",):
         try:
             j = json.loads(open(p).read().strip().splitlines()[-1])
             summary["bench_under_profiler"] = {"value": j["value"], "kernel_ms_avg": j["roofline"]["kernel_ms_avg"],
-                                               "workload": j["config"]["workload"]}
+                                               "workload": j["config"]["workload"],
+                                               "evals_per_launch": j["roofline"]["evals_per_launch"],
+                                               "ensemble_sampler": j.get("ensemble_sampler")}
             lines += ["", f"bench.py under the profiler: {j['value']:.0f} evals/s, HIP-event kernel time "
                           f"{j['roofline']['kernel_ms_avg']*1e3:.1f} us ({j['config']['workload']})"]
         except Exception as e:  # noqa: BLE001
