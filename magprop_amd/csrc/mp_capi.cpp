@@ -310,13 +310,15 @@ mp_handle *mp_create(const mp_model_cfg *cfg, const double *tgrid, int n_grid, i
     s.sqrtGM = std::sqrt(s.GM);
     s.inv_sqrtGM = 1.0 / s.sqrtGM;
     s.sqrtR = std::sqrt(mp::kR);
+    s.crm_unit = std::pow(1.0e15 * mp::kR * mp::kR * mp::kR, 4.0 / 7.0) * std::pow(s.GM, -1.0 / 7.0) *
+                 std::pow(cfg->rm_massflow_factor, -2.0 / 7.0);
     s.q = q;
     s.sweep_tol = cfg->sweep_tol > 0.0 ? cfg->sweep_tol : MP_SWEEP_TOL_DEFAULT;
     s.n_simd = std::max(1, prop.multiProcessorCount) * 4;         // 4 SIMDs per CU (1 024 on MI355X)
     s.force_spl = 0;
     if (const char *e = std::getenv("MAGPROP_AMD_SPL")) {          // experiments only
         const int v = std::atoi(e);
-        if (v == 1 || v == 2 || v == 4) s.force_spl = v;
+        if (v == 2 || v == 4) s.force_spl = v;
     }
     s.force_pc = 0;
     if (const char *e = std::getenv("MAGPROP_AMD_PC")) {           // experiments only

@@ -49,6 +49,7 @@ struct DevShared {
     uint32_t log_mask;
     // derived star constants (host-computed once from cfg)
     double GM, inertia, inv_inertia, crot /* 0.5*I/|W| */, sqrtGM, inv_sqrtGM, sqrtR;
+    double crm_unit;      // (1e15 R^3)^(4/7) GM^(-1/7) f_Rm^(-2/7): Alfven-radius constant of a 1e15 G field
     // geometric grid: ratio q = t_{j+1}/t_j and the exponential Adams-Moulton quadrature matrix for it
     double q, inv_q;
     double sweep_tol;     // relative change of the step-end values that ends the Newton sweeps of a tile

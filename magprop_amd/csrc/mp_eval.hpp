@@ -177,7 +177,7 @@ MP_DEV int walker_setup(const DevShared &sh, const LaunchArgs &a, double (&par)[
         if (outside) status = MP_STATUS_PRIOR;
 #pragma unroll
         for (int i = 0; i < MP_MAX_NDIM; ++i)
-            if (i < a.ndim && ((sh.log_mask >> i) & 1u)) par[i] = pow(10.0, par[i]);
+            if (i < a.ndim && ((sh.log_mask >> i) & 1u)) par[i] = exp10_fast(par[i]);
     }
 
     // ---- walker constants (code/synthetic_datasets/funcs.py:98-102)
@@ -185,12 +185,14 @@ MP_DEV int walker_setup(const DevShared &sh, const LaunchArgs &a, double (&par)[
         const double B = par[0], MdiscI = par[2], RdiscI = par[3], epsilon = par[4], delta = par[5];
         const double tau = (RdiscI * 1.0e5) / (sh.cfg.alpha * sh.cfg.cs7 * 1.0e7);
         const double mu = 1.0e15 * B * (kR * kR * kR);
+        const Vd<1> Bv{{B}};
+        const double b17 = pow_m1_7_fast(Bv)[0];                       // B^(-1/7); B^(4/7) = B * (B^(-1/7))^3
         const double M0 = delta * MdiscI * kMsol;
         const double tfb = epsilon * tau;
         w.inv_tau = 1.0 / tau;
         w.S_amp = M0 / tfb;
         w.inv_tfb = 1.0 / tfb;
-        w.Crm = pow(mu, 4.0 / 7.0) * pow(sh.GM, -1.0 / 7.0) * pow(sh.cfg.rm_massflow_factor, -2.0 / 7.0);
+        w.Crm = sh.crm_unit * (B * (b17 * b17 * b17));                 // mu^(4/7) GM^(-1/7) f^(-2/7), mu = 1e15 B R^3
         w.sqrtCrm = sqrt(w.Crm);
         w.Crm15 = w.Crm * w.sqrtCrm * sh.inv_sqrtGM;
         w.D = (mu * mu) / (6.0 * kC * kC * kC);
@@ -378,8 +380,12 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
             if (!(isfinite(M_s) && isfinite(om_s)) || M_s <= 0.0 || om_s <= 0.0) status = MP_STATUS_NONFINITE;
             else if (rot0[0] > 0.27) status = MP_STATUS_FLAG;
         }
-        luminosity(sh, w, d_s, ov, Lt0, Lp0, Ld0);
-        L_s = Lt0[0]; Lp_s = Lp0[0]; Ld_s = Ld0[0];
+        if constexpr (CURVES) {
+            luminosity(sh, w, d_s, ov, Lt0, Lp0, Ld0);
+            L_s = Lt0[0]; Lp_s = Lp0[0]; Ld_s = Ld0[0];
+        } else {
+            L_s = Lp_s = Ld_s = 0.0;
+        }
     }
 
     const int dsid = a.ds_id ? a.ds_id[walker] : 0;

@@ -38,18 +38,11 @@
 
 #include "mp_eval.hpp"
 
-#ifndef MP_WPE_SPL2
-#define MP_WPE_SPL2 2   // resident waves per SIMD the 2-steps-per-lane kernels are compiled for
-#endif
-#ifndef MP_WPE_SPL1
-#define MP_WPE_SPL1 4
-#endif
-
 namespace mp {
 
 // ---------------------------------------------------------------- batched log-posterior kernel
 template <bool CURVES, int SPL, bool LONG>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPL >= 4 ? 1 : (SPL == 2 ? MP_WPE_SPL2 : MP_WPE_SPL1), SPL >= 4 ? 1 : (SPL == 2 ? MP_WPE_SPL2 : MP_WPE_SPL1)))) void lnprob_kernel(const DevShared sh, const LaunchArgs a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, SPL >= 4 ? 1 : 2))) void lnprob_kernel(const DevShared sh, const LaunchArgs a) {
     __shared__ double Lbuf[2 * (64 * SPL + 1)];
     ktab_init();
     const int walker = blockIdx.x;
@@ -68,6 +61,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPL >= 4 ? 1
 }
 
 // Two wavefronts per walker, producer (Mdisc phase) and consumer (omega, observations): mp_eval.hpp, PcRing.
+// The consumer is the critical path: it runs at raised issue priority, so that where both wavefronts of a pair (or of two
+// pairs) share a SIMD the producer only takes the issue slots the consumer leaves free.
+constexpr int kPcPrio = 3;
+MP_DEV bool pc_is_producer() { return threadIdx.x >= 64; }
+
 template <int SPL, bool LONG>
 __global__ __launch_bounds__(128) void lnprob_pc_kernel(const DevShared sh, const LaunchArgs a) {
     __shared__ double Lbuf[2 * (64 * SPL + 1)];
@@ -80,14 +78,15 @@ __global__ __launch_bounds__(128) void lnprob_pc_kernel(const DevShared sh, cons
     for (int i = 0; i < MP_MAX_NDIM; ++i) par[i] = i < a.ndim ? pw[i] : 0.0;
     if (threadIdx.x == 0) { ring.produced = 0; ring.consumed = 0; ring.abort = 0; }
     __syncthreads();
-    if (threadIdx.x >= 64) {
+    if (pc_is_producer()) {
         walker_produce<SPL>(sh, a, par, ring);
         return;
     }
+    __builtin_amdgcn_s_setprio(kPcPrio);
     double lnp;
     int status, sweeps;
     walker_eval<false, SPL, LONG, 1>(sh, a, walker, par, Lbuf, lnp, status, sweeps, &ring);
-    if (threadIdx.x == 0) {
+    if ((threadIdx.x & 63) == 0) {
         a.lnprob[walker] = lnp;
         if (a.status) a.status[walker] = status;
         if (a.sweeps) a.sweeps[walker] = sweeps;
@@ -179,10 +178,11 @@ __global__ __launch_bounds__(PC ? 128 : 64) void stretch_kernel(const DevShared 
         // consumer's update of it at the very end
         if (threadIdx.x == 0) { ring.produced = 0; ring.consumed = 0; ring.abort = 0; }
         __syncthreads();
-        if (threadIdx.x >= 64) {
+        if (pc_is_producer()) {
             if (g.target != 1) walker_produce<SPL>(sh, a, par, ring);
             return;
         }
+        __builtin_amdgcn_s_setprio(kPcPrio);
     }
     double lnp;
     int status = MP_STATUS_OK, sweeps;
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(PC ? 128 : 64) void stretch_kernel(const DevShared 
         if constexpr (PC) walker_eval<false, SPL, LONG, 1>(sh, a, k, par, lds, lnp, status, sweeps, &ring);
         else walker_eval<false, SPL, LONG>(sh, a, k, par, lds, lnp, status, sweeps);
     }
-    if (threadIdx.x == 0) {
+    if ((threadIdx.x & 63) == 0) {   // lane 0 of the evaluating wavefront
         const double lnp_old = g.lnprob[k];
         const double lnpdiff = sub_rn(add_rn(mul_rn(g.ndim - 1.0, log(zz)), lnp), lnp_old);
         const bool accept = lnpdiff > log(u01(r2[0], r2[1]));      // false for NaN / -inf proposals
@@ -311,9 +311,6 @@ int launch_lnprob(const DevShared &sh, const LaunchArgs &a, void *stream) {
     } else if (wide) {
         if (lng) hipLaunchKernelGGL((lnprob_kernel<false, 4, true>), grid, block, 0, st, sh, a);
         else hipLaunchKernelGGL((lnprob_kernel<false, 4, false>), grid, block, 0, st, sh, a);
-    } else if (sh.force_spl == 1) {   // experiments (MAGPROP_AMD_SPL=1): one step per lane, 64-step tiles
-        if (lng) hipLaunchKernelGGL((lnprob_kernel<false, 1, true>), grid, block, 0, st, sh, a);
-        else hipLaunchKernelGGL((lnprob_kernel<false, 1, false>), grid, block, 0, st, sh, a);
     } else {
         if (lng) hipLaunchKernelGGL((lnprob_kernel<false, 2, true>), grid, block, 0, st, sh, a);
         else hipLaunchKernelGGL((lnprob_kernel<false, 2, false>), grid, block, 0, st, sh, a);

@@ -137,21 +137,23 @@ class DistributedEnsembleSampler:
     restatement of the move).
     """
 
-    def __init__(self, engine, group=None, via_host=False):
+    def __init__(self, engine, group=None, via_host=False, always_gather=False):
         self.engine = engine
         self.group = group
         self.via_host = via_host       # gather through host memory: gloo rehearsal with GPU engines
+        self.always_gather = always_gather   # run the collective even in a group of one (exercises RCCL on a 1-GPU box)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.lo, self.hi, self.per = shard_range(engine.n_slots, self.rank, self.world)
         R = engine.row_doubles
         dev = engine.device
         self.send = torch.zeros(self.per, R, dtype=torch.float64, device=dev)                 # this rank's outcome rows
-        self.rows = self.send if self.world == 1 else torch.zeros(self.per * self.world, R, dtype=torch.float64, device=dev)
+        alone = self.world == 1 and not always_gather
+        self.rows = self.send if alone else torch.zeros(self.per * self.world, R, dtype=torch.float64, device=dev)
         self.iteration = 0
 
     def _gather(self):
-        if self.world == 1:
+        if self.rows is self.send:
             return
         if self.via_host:
             host = torch.empty(self.rows.shape, dtype=torch.float64)

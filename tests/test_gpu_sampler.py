@@ -209,6 +209,19 @@ def test_sharded_lnprob_pipelined_over_rccl(gsynth):
         for w, g_ in zip(want, got):
             assert torch.equal(w, g_)
         assert torch.equal(sh(batches[0]), want[0])              # blocking form
+        # the walker-sharded sampler with its real collective (all_gather_into_tensor of the outcome rows over RCCL)
+        from magprop_amd import EnsembleSampler
+        from magprop_amd.distributed import DistributedEnsembleSampler, HipShardEngine
+        rng = np.random.default_rng(17)
+        pos = np.array(TRUTHS["Humped"]) + 1.0e-4 * rng.standard_normal((128, 6))
+        a = EnsembleSampler(128, 6, x, y, yerr, seed=8)
+        a.run_mcmc(pos, 15)
+        b = EnsembleSampler(128, 6, x, y, yerr, seed=8)
+        d = DistributedEnsembleSampler(HipShardEngine(b, dev), always_gather=True)
+        chain, lnp = d.run_mcmc(pos, 15)
+        torch.cuda.synchronize()
+        assert d.rows is not d.send
+        assert np.array_equal(chain.cpu().numpy(), a.get_chain()) and np.array_equal(lnp.cpu().numpy(), a.get_log_prob())
     finally:
         dist.destroy_process_group()
 
