@@ -309,7 +309,8 @@ MP_DEV void walker_produce(const DevShared &sh, const LaunchArgs &a, double (&pa
                 A = A * am[s];
             }
             scan_affine(A, B);
-            const double Ax = lane_prev(A, 1.0), Bx = lane_prev(B, 0.0);
+            double Ax, Bx;
+            lane_prev_map(A, B, Ax, Bx);
             double Mc = fma(Ax, M_s, Bx);
 #pragma unroll
             for (int s = 0; s < kSPL; ++s) { Mc = fma(am[s], Mc, bm[s]); M1[s] = Mc; }
@@ -486,7 +487,8 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                     A = A * am[s];
                 }
                 scan_affine(A, B);
-                const double Ax = lane_prev(A, 1.0), Bx = lane_prev(B, 0.0);   // exclusive prefix
+                double Ax, Bx;
+            lane_prev_map(A, B, Ax, Bx);   // exclusive prefix
                 double Mc = fma(Ax, M_s, Bx);            // Mdisc at this lane's first step start
 #pragma unroll
                 for (int s = 0; s < kSPL; ++s) { Mc = fma(am[s], Mc, bm[s]); M1[s] = Mc; }
@@ -586,7 +588,8 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                     A = A * aw[s];
                 }
                 scan_affine(A, B);
-                const double Ax = lane_prev(A, 1.0), Bx = lane_prev(B, 0.0);
+                double Ax, Bx;
+            lane_prev_map(A, B, Ax, Bx);
                 double wc = fma(Ax, om_s, Bx);           // omega at this lane's first step start
                 bool all_ok = true, all_settled = true, all_small = true;
 #pragma unroll

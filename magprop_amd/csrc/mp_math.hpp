@@ -27,6 +27,16 @@ MP_DEV double dpp_move(double keep, double src) {
 // value of lane-1 (lane 0 receives `first`)
 MP_DEV double lane_prev(double v, double first) { return dpp_move<0x138, 0xF>(first, v); }
 
+// exclusive prefix of a scanned affine map: (a, b) of lane-1, the identity (1, 0) in lane 0 (zero dwords by bound_ctrl)
+MP_DEV void lane_prev_map(double a, double b, double &pa, double &pb) {
+    const int alo = __builtin_amdgcn_update_dpp(0, __double2loint(a), 0x138, 0xF, 0xF, true);
+    const int ahi = __builtin_amdgcn_update_dpp(0x3FF00000, __double2hiint(a), 0x138, 0xF, 0xF, false);
+    const int blo = __builtin_amdgcn_update_dpp(0, __double2loint(b), 0x138, 0xF, 0xF, true);
+    const int bhi = __builtin_amdgcn_update_dpp(0, __double2hiint(b), 0x138, 0xF, 0xF, true);
+    pa = __hiloint2double(ahi, alo);
+    pb = __hiloint2double(bhi, blo);
+}
+
 // broadcast lane `src` (wave-uniform index) to all lanes
 MP_DEV double lane_bcast(double v, int src) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
@@ -36,10 +46,22 @@ MP_DEV double lane_bcast(double v, int src) {
 
 // Inclusive scan of affine maps x -> a*x + b over the 64 lanes: afterwards lane l holds
 // m_l o m_{l-1} o ... o m_0.  Lanes without a DPP source combine with the identity (1, 0).
+// Within-row shifts (all rows enabled) let the hardware supply the zero dwords of the identity (bound_ctrl: a lane
+// whose source is outside the row reads 0): only the high dword of 1.0 has to be preset, one v_mov instead of four.
 template <int CTRL, int ROW_MASK>
 MP_DEV void scan_step(double &a, double &b) {
-    const double pa = dpp_move<CTRL, ROW_MASK>(1.0, a);
-    const double pb = dpp_move<CTRL, ROW_MASK>(0.0, b);
+    double pa, pb;
+    if constexpr (ROW_MASK == 0xF) {
+        const int alo = __builtin_amdgcn_update_dpp(0, __double2loint(a), CTRL, 0xF, 0xF, true);
+        const int ahi = __builtin_amdgcn_update_dpp(0x3FF00000, __double2hiint(a), CTRL, 0xF, 0xF, false);
+        const int blo = __builtin_amdgcn_update_dpp(0, __double2loint(b), CTRL, 0xF, 0xF, true);
+        const int bhi = __builtin_amdgcn_update_dpp(0, __double2hiint(b), CTRL, 0xF, 0xF, true);
+        pa = __hiloint2double(ahi, alo);
+        pb = __hiloint2double(bhi, blo);
+    } else {
+        pa = dpp_move<CTRL, ROW_MASK>(1.0, a);
+        pb = dpp_move<CTRL, ROW_MASK>(0.0, b);
+    }
     b = fma(a, pb, b);
     a = a * pa;
 }

@@ -54,7 +54,7 @@ def _columns(data):
             np.asarray(data["Lum50err"], dtype=np.float64))
 
 
-def _evaluate(pars, data, GRBtype, lower, upper, log_mask, device=-1):
+def _evaluate(pars, data, GRBtype, lower, upper, log_mask, device=-1, want_status=False):
     p = np.asarray(pars, dtype=np.float64)
     scalar = p.ndim == 1
     p2 = np.atleast_2d(p)
@@ -65,14 +65,21 @@ def _evaluate(pars, data, GRBtype, lower, upper, log_mask, device=-1):
     with eng.lock:
         slot = eng.dataset_slot(x, y, yerr)
         eng.set_prior(lower, upper, log_mask)
-        out = eng.handle.lnprob_batch(p2, ds_id=slot)
+        out, st = eng.handle.lnprob_batch(p2, ds_id=slot, want_status=True)
+    if want_status:
+        return (float(out[0]) if scalar else out), st
     return float(out[0]) if scalar else out
 
 
-def lnlike(pars, data, GRBtype, device=-1):
+def lnlike(pars, data, GRBtype, device=-1, reference_quirk=False):
     """-0.5*chi^2 of model_lc against data (physical parameters; 6/7/8/9-parameter dispatch of :22-34).
-    A failed integration gives -inf (the reference raises on ``y - 'flag'``)."""
-    return _evaluate(pars, data, GRBtype, None, None, 0, device)
+    A failed integration gives -inf.  The reference has no branch for it: its ``model_lc`` returns the string 'flag'
+    and ``ydata - 'flag'`` raises (:37); ``reference_quirk=True`` raises the same TypeError."""
+    out, st = _evaluate(pars, data, GRBtype, None, None, 0, device, want_status=True)
+    if reference_quirk and np.any(st == _capi.STATUS_FLAG):
+        raise TypeError("unsupported operand type(s) for -: 'float' and 'str'  (model_lc returned 'flag', "
+                        "magnetar/mcmc_eqns.py:37)")
+    return out
 
 
 def lnprior(pars, custom_lims=None):
@@ -84,7 +91,12 @@ def lnprior(pars, custom_lims=None):
     return np.where(inside, 0.0, -np.inf)
 
 
-def lnprob(pars, data, GRBtype, custom_lims=None, device=-1):
+def lnprob(pars, data, GRBtype, custom_lims=None, device=-1, reference_quirk=False):
+    """Default: the documented intent (module docstring) — box prior in sampler coordinates, parameters
+    3-6 un-logged before the model.  ``reference_quirk=True`` evaluates what the reference's code literally does: the
+    same box test, then the SAME numbers handed to ``model_lc`` un-exponentiated (:108-113), so a point inside the
+    log-space box reaches the model with e.g. MdiscI = -2.5; the model state goes non-finite and the result is -inf
+    (:115-116) wherever the reference would return -inf or NaN."""
     p = np.asarray(pars, dtype=np.float64)
     lo, hi = _bounds(p.shape[-1], custom_lims)
-    return _evaluate(p, data, GRBtype, lo, hi, LIB_LOG_MASK, device)
+    return _evaluate(p, data, GRBtype, lo, hi, 0 if reference_quirk else LIB_LOG_MASK, device)

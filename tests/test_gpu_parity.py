@@ -290,6 +290,12 @@ def test_lib_prior_wide_scan_short_grb_grid(mpa, glib, glibscan2):
     ok = rst == 0
     assert np.array_equal(np.isfinite(out), ok)
     assert np.all(np.abs(out[ok] - ref[ok]) <= REF_ATOL + REF_RTOL * np.abs(ref[ok]))
+    if np.any(rst == 1):   # a failed integration: -inf here, a TypeError in the reference (magnetar/mcmc_eqns.py:37)
+        p = glibscan2["pars_sampler"][np.nonzero(rst == 1)[0][0]].copy()
+        p[2:6] = 10.0 ** p[2:6]
+        assert mpa.lnlike(p, data, "S") == -np.inf
+        with pytest.raises(TypeError, match="flag"):
+            mpa.lnlike(p, data, "S", reference_quirk=True)
 
 
 def test_lib_lnprob_intent(mpa, glib):
@@ -302,6 +308,8 @@ def test_lib_lnprob_intent(mpa, glib):
     p_phys[2:] = 10.0 ** p_phys[2:]
     assert mpa.lnprob(p_log, data, "L") == pytest.approx(mpa.lnlike(p_phys, data, "L"), rel=1e-12)
     assert mpa.lnprob([1.0, 5.0, -3.5, 2.0, 0.0, 0.0], data, "L") == -np.inf
+    # the reference's literal behaviour (the log-space numbers reach model_lc as they are: MdiscI = -2.5): never finite
+    assert mpa.lnprob(p_log, data, "L", reference_quirk=True) == -np.inf
     assert mpa.lnprob([1.0, 5.0, -2.5, 2.0, 0.0, 0.0, 700.0], data, "L") == -np.inf     # f_beam above 600
 
 
