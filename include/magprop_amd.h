@@ -240,6 +240,8 @@ void *mp_stream(const mp_handle *h); /* the handle's own hipStream_t */
 int mp_n_grid(const mp_handle *h);
 /* mean Newton sweeps per tile of the most recent host-buffer batch (diagnostic) */
 double mp_last_mean_sweeps(const mp_handle *h);
+/* total Newton sweeps of every walker of that batch (all tiles; 0 for walkers that never started); returns the count copied */
+int mp_last_sweeps(const mp_handle *h, int32_t *out, int n);
 double mp_sweep_tol(const mp_handle *h); /* the tolerance in force (cfg.sweep_tol or the default) */
 int mp_n_simd(const mp_handle *h);       /* SIMDs of the handle's device: batch-size thresholds of the kernel variants */
 

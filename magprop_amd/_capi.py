@@ -24,7 +24,7 @@ EXPORTS = (
     "mp_synchronize", "mp_device", "mp_stream", "mp_n_grid", "mp_last_mean_sweeps",
     "mp_sampler_create", "mp_sampler_destroy", "mp_sampler_set_positions", "mp_sampler_run", "mp_sampler_get_state",
     "mp_sampler_get_bad", "mp_sampler_n_slots", "mp_sampler_row_doubles", "mp_sampler_halfstep_shard",
-    "mp_sampler_halfstep_apply", "mp_sampler_state_ptrs", "mp_sweep_tol", "mp_n_simd",
+    "mp_sampler_halfstep_apply", "mp_sampler_state_ptrs", "mp_sweep_tol", "mp_n_simd", "mp_last_sweeps",
 )
 ABI_VERSION = 2
 
@@ -127,6 +127,8 @@ def lib():
     L.mp_sweep_tol.argtypes = [vp]
     L.mp_sweep_tol.restype = C.c_double
     L.mp_n_simd.argtypes = [vp]
+    L.mp_last_sweeps.argtypes = [vp, ip, C.c_int]
+    L.mp_last_sweeps.restype = C.c_int
     L.mp_sampler_get_bad.argtypes = [vp, dp, C.c_int, i64p]
     L.mp_sampler_n_slots.argtypes = [vp]
     L.mp_sampler_row_doubles.argtypes = [vp]
@@ -296,6 +298,12 @@ class Handle:
     @property
     def last_mean_sweeps(self):
         return self._L.mp_last_mean_sweeps(self._h)
+
+    def last_sweeps(self, n):
+        """Total Newton sweeps (over all tiles) of each of the first n walkers of the most recent host-buffer batch."""
+        out = np.zeros(n, dtype=np.int32)
+        m = self._L.mp_last_sweeps(self._h, _iptr(out), int(n))
+        return out[:max(m, 0)]
 
     @property
     def sweep_tol(self):

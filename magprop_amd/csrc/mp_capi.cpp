@@ -120,6 +120,7 @@ struct mp_handle {
     PinnedBuf h_io;
     DevBuf<double> w_scratch;   // DevShared::obs_scratch (only allocated once a light curve longer than 64 points is set)
     double last_mean_sweeps = 0.0;
+    std::vector<int32_t> last_sweeps;   // per walker, most recent host-buffer batch (diagnostic)
     // Threading / stream contract (include/magprop_amd.h): every entry point that takes a handle or a sampler holds
     // `mu` for its duration.  The scratch rows are indexed by walker, so two launches that use them must not overlap:
     // each records `scratch_done` on its stream and the next one, if it runs on another stream, waits for it there.
@@ -496,6 +497,7 @@ int mp_lnprob_batch(mp_handle *h, const double *pars, const int32_t *ds_id, int 
     if (status_out) std::memcpy(status_out, status, sizeof(int32_t) * (size_t)n);
     double tot = 0.0;
     int cnt = 0;
+    h->last_sweeps.assign(sweeps, sweeps + n);
     for (int i = 0; i < n; ++i)
         if (status[i] == MP_STATUS_OK) { tot += sweeps[i]; ++cnt; }
     const int ktile = mp::kTile * (h->sh.force_spl ? h->sh.force_spl : mp::kernel_spl(h->sh, n));
@@ -903,6 +905,12 @@ int mp_device(const mp_handle *h) { return h ? h->device : -1; }
 void *mp_stream(const mp_handle *h) { return h ? (void *)h->stream : nullptr; }
 int mp_n_grid(const mp_handle *h) { return h ? (int)h->tgrid.size() : 0; }
 double mp_last_mean_sweeps(const mp_handle *h) { return h ? h->last_mean_sweeps : 0.0; }
+int mp_last_sweeps(const mp_handle *h, int32_t *out, int n) {
+    if (!h || !out || n < 0) return fail(MP_EINVAL, "mp_last_sweeps: bad argument");
+    const int m = std::min<int>(n, (int)h->last_sweeps.size());
+    std::copy(h->last_sweeps.begin(), h->last_sweeps.begin() + m, out);
+    return m;
+}
 double mp_sweep_tol(const mp_handle *h) { return h ? h->sh.sweep_tol : 0.0; }
 int mp_n_simd(const mp_handle *h) { return h ? h->sh.n_simd : 0; }
 

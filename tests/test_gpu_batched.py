@@ -263,3 +263,48 @@ def test_config5_through_the_ensemble_sampler(gsynth, glonglc, tarr):
     assert np.array_equal(s2.get_chain(), chain)
     s.close()
     s2.close()
+
+
+# ---------------------------------------------------------------- threads and streams (include/magprop_amd.h contract)
+def test_one_handle_from_several_threads_and_streams(gsynth, tarr):
+    """A handle that holds a long light curve owns per-walker scratch rows: host calls from several Python threads
+    (ctypes drops the GIL) and device calls on two torch streams must give the results of the same calls made one
+    after the other."""
+    import threading
+    import torch
+    import magprop_amd as mpa
+    from magprop_amd import LogProb
+    rng = np.random.default_rng(77)
+    base = mpa.model_lum(CANON["Humped"])
+    lp_ = LogProb(gsynth["Humped_x"], gsynth["Humped_y"], gsynth["Humped_yerr"])
+    lp_.add_dataset(*_long_set(rng, tarr, base[1], 900))
+    batches = [np.array(TRUTHS["Humped"]) + 0.01 * rng.standard_normal((n, 6)) for n in (700, 1500, 300, 1100)]
+    ids = [np.ones(len(b), np.int32) for b in batches]                    # everyone on the 900-point light curve
+    want = [lp_(b, ds_id=i) for b, i in zip(batches, ids)]
+    got = [None] * len(batches)
+
+    def work(k):
+        for _ in range(5):
+            got[k] = lp_(batches[k], ds_id=ids[k])
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(len(batches))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for w, g_ in zip(want, got):
+        assert np.array_equal(w, g_)
+    # device entry on two streams, interleaved: the library orders the launches that share the scratch rows
+    dev = torch.device("cuda", lp_.handle.device)
+    s1, s2 = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    tb = [torch.from_numpy(b).to(dev) for b in batches]
+    ti = [torch.from_numpy(i).to(dev) for i in ids]
+    outs = [torch.empty(len(b), dtype=torch.float64, device=dev) for b in batches]
+    torch.cuda.synchronize(dev)
+    for rep in range(4):
+        for k in range(len(batches)):
+            with torch.cuda.stream(s1 if k % 2 == 0 else s2):
+                lp_.lnprob_device(tb[k], out=outs[k], ds_id=ti[k])
+    torch.cuda.synchronize(dev)
+    for w, o in zip(want, outs):
+        assert np.array_equal(w, o.cpu().numpy())
