@@ -105,21 +105,56 @@ def rhs(y, t, v, n, tvisc, mu, M0, tfb):
     return Mdotfb - Mdotacc - Mdotprop, (Nacc + Ndip) / inertia
 
 
-def integrate(pars, tarr, v=SYNTH, rtol=None, atol=None, mxstep=0):
+def rhs_per_call_constants(y, t, v, n, B, MdiscI, RdiscI, epsilon, delta):
+    """The same right-hand side with the reference's COST structure: the reference derives the walker constants and the
+    star's binding energy afresh inside every call (code/synthetic_datasets/funcs.py:98-118), ~9 800 times per light
+    curve.  Same numbers as `rhs`; used by the cpu_baseline timing (reference_cost=True)."""
+    tvisc, mu, M0, tfb = _walker_constants(v, B, MdiscI, RdiscI, epsilon, delta)
+    beta = GM / (R * c ** 2.0)
+    binding = 0.6 * M * c ** 2.0 * (beta / (1.0 - 0.5 * beta))
+    Mdisc, omega = y
+    inertia = v.inertia
+    Rm = (mu ** (4.0 / 7.0)) * (GM ** (-1.0 / 7.0)) * ((v.rm_massflow_factor * Mdisc) / tvisc) ** (-2.0 / 7.0)
+    Rc = (GM / omega ** 2.0) ** (1.0 / 3.0)
+    Rlc = c / omega
+    if Rm >= v.k * Rlc:
+        Rm = v.k * Rlc
+    w = (Rm / Rc) ** 1.5
+    rot_param = (0.5 * inertia * omega ** 2.0) / binding
+    Ndip = (-1.0 * mu ** 2.0 * omega ** 3.0) / (6.0 * c ** 3.0)
+    eta2 = 0.5 * (1.0 + np.tanh(n * (w - 1.0)))
+    eta1 = 1.0 - eta2
+    Mdotprop = eta2 * (Mdisc / tvisc)
+    Mdotacc = eta1 * (Mdisc / tvisc)
+    Mdotfb = (M0 / tfb) * ((t + tfb) / tfb) ** (-5.0 / 3.0)
+    if rot_param > 0.27:
+        Nacc = 0.0
+    elif Rm >= R:
+        Nacc = (GM * Rm) ** 0.5 * (Mdotacc - Mdotprop)
+    else:
+        Nacc = (GM * R) ** 0.5 * (Mdotacc - Mdotprop)
+    return Mdotfb - Mdotacc - Mdotprop, (Nacc + Ndip) / inertia
+
+
+def integrate(pars, tarr, v=SYNTH, rtol=None, atol=None, mxstep=0, reference_cost=False):
     """(soln[n,2] or None if LSODA reports anything but success, info)."""
     B, P, MdiscI, RdiscI, epsilon, delta = pars[:6]
     y0 = (MdiscI * Msol, (2.0 * np.pi) / (1.0e-3 * P))
     wc = _walker_constants(v, B, MdiscI, RdiscI, epsilon, delta)
+    fn, args = (rhs_per_call_constants, (v, v.n_ode, B, MdiscI, RdiscI, epsilon, delta)) if reference_cost else \
+        (rhs, (v, v.n_ode) + wc)
     with np.errstate(all="ignore"):
-        soln, info = odeint(rhs, y0, tarr, args=(v, v.n_ode) + wc, full_output=True,
+        soln, info = odeint(fn, y0, tarr, args=args, full_output=True,
                             rtol=rtol, atol=atol, mxstep=mxstep, printmessg=False)
     if info["message"] != "Integration successful.":
         return None, info
     return soln, info
 
 
-def luminosity(soln, pars, v=SYNTH):
-    """Vectorised luminosity stage: (Ltot, Lprop, Ldip) in erg/s on the grid."""
+def luminosity(soln, pars, v=SYNTH, reference_cost=False):
+    """Luminosity stage: (Ltot, Lprop, Ldip) in erg/s on the grid.  Vectorised; with reference_cost=True the accretion
+    torque is filled element by element in the interpreter, as the reference does over its 10 001 grid points
+    (code/synthetic_datasets/funcs.py:204-212, ~8 ms per light curve)."""
     B, P, MdiscI, RdiscI, epsilon, delta = pars[:6]
     tvisc, mu, M0, tfb = _walker_constants(v, B, MdiscI, RdiscI, epsilon, delta)
     Mdisc = soln[:, 0]
@@ -135,8 +170,18 @@ def luminosity(soln, pars, v=SYNTH):
         eta1 = 1.0 - eta2
         Mdotprop = eta2 * (Mdisc / tvisc)
         Mdotacc = eta1 * (Mdisc / tvisc)
-        arm = np.where(Rm >= R, (GM * Rm) ** 0.5, (GM * R) ** 0.5)
-        Nacc = np.where(rot_param > v.nacc_lum_threshold, 0.0, arm * (Mdotacc - Mdotprop))
+        if reference_cost:
+            Nacc = np.zeros_like(Mdisc)
+            for j in range(Nacc.size):
+                if rot_param[j] > v.nacc_lum_threshold:
+                    Nacc[j] = 0.0
+                elif Rm[j] >= R:
+                    Nacc[j] = (GM * Rm[j]) ** 0.5 * (Mdotacc[j] - Mdotprop[j])
+                else:
+                    Nacc[j] = (GM * R) ** 0.5 * (Mdotacc[j] - Mdotprop[j])
+        else:
+            arm = np.where(Rm >= R, (GM * Rm) ** 0.5, (GM * R) ** 0.5)
+            Nacc = np.where(rot_param > v.nacc_lum_threshold, 0.0, arm * (Mdotacc - Mdotprop))
         Ldip = v.dipeff * ((mu ** 2.0 * omega ** 4.0) / (6.0 * c ** 3.0))
         Ldip = np.where(Ldip <= 0.0, 0.0, Ldip)
         Ldip = np.where(np.isfinite(Ldip), Ldip, 0.0)
@@ -149,12 +194,12 @@ def luminosity(soln, pars, v=SYNTH):
     return v.f_beam * (Ldip + Lprop), Lprop, Ldip
 
 
-def model(pars, tarr, xdata=None, v=SYNTH):
+def model(pars, tarr, xdata=None, v=SYNTH, reference_cost=False):
     """model_lc / model_lum: 'flag' | L(xdata)/1e50 | array([tarr, Ltot, Lprop, Ldip]/1e50)."""
-    soln, _ = integrate(pars, tarr, v)
+    soln, _ = integrate(pars, tarr, v, reference_cost=reference_cost)
     if soln is None:
         return "flag"
-    Ltot, Lprop, Ldip = luminosity(soln, pars, v)
+    Ltot, Lprop, Ldip = luminosity(soln, pars, v, reference_cost=reference_cost)
     if xdata is None:
         return np.array([tarr, Ltot / 1.0e50, Lprop / 1.0e50, Ldip / 1.0e50])
     xdata = np.asarray(xdata, dtype=float)
@@ -175,9 +220,9 @@ def with_extra_pars(v, pars):
     return v
 
 
-def lnlike_physical(pars, tarr, x, y, yerr, v=SYNTH):
+def lnlike_physical(pars, tarr, x, y, yerr, v=SYNTH, reference_cost=False):
     """(-0.5*chi2 or -inf, status) for PHYSICAL parameters; status 1 = LSODA flag."""
-    mod = model(pars[:6], tarr, xdata=x, v=with_extra_pars(v, pars))
+    mod = model(pars[:6], tarr, xdata=x, v=with_extra_pars(v, pars), reference_cost=reference_cost)
     if isinstance(mod, str):
         return -np.inf, 1
     ll = -0.5 * np.sum(((y - mod) / yerr) ** 2.0)
@@ -194,7 +239,7 @@ def lnprior(pars, lower, upper):
 
 
 def lnprob(pars, tarr, x, y, yerr, lower=SYNTH_PRIOR_LOWER, upper=SYNTH_PRIOR_UPPER, log_mask=0b111100,
-           v=SYNTH):
+           v=SYNTH, reference_cost=False):
     """(lnprob, status) in sampler coordinates; code/synthetic_datasets/mcmc_eqns.py:52-81."""
     if not np.isfinite(lnprior(pars, lower, upper)):
         return -np.inf, 3
@@ -202,7 +247,7 @@ def lnprob(pars, tarr, x, y, yerr, lower=SYNTH_PRIOR_LOWER, upper=SYNTH_PRIOR_UP
     for i in range(arr.size):
         if (log_mask >> i) & 1:
             arr[i] = 10.0 ** arr[i]
-    return lnlike_physical(arr, tarr, x, y, yerr, v)
+    return lnlike_physical(arr, tarr, x, y, yerr, v, reference_cost=reference_cost)
 
 
 # ---- multiprocessing helper for the cpu_baseline leg (mirrors synth_mcmc.py:178-185's Pool) ----
@@ -214,5 +259,6 @@ def _pool_init(tarr, x, y, yerr):
 
 
 def _pool_eval(p):
+    """One evaluation with the reference's cost structure (what bench.py's cpu_baseline times)."""
     s = _POOL_STATE
-    return lnprob(p, s["tarr"], s["x"], s["y"], s["yerr"])[0]
+    return lnprob(p, s["tarr"], s["x"], s["y"], s["yerr"], reference_cost=True)[0]

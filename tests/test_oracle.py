@@ -308,3 +308,15 @@ def test_out_of_grid_times_raise(tarr):
         lp.model(CANON["Humped"], tarr, xdata=np.array([0.5, 10.0]))
     with pytest.raises(ValueError):
         lp.grid("X")
+
+
+def test_lsoda_port_reference_cost_mode_gives_the_same_numbers(gsynth, tarr):
+    """bench.py's cpu_baseline times the port with the reference's cost structure (constants re-derived in every RHS call,
+    element-wise accretion-torque loop: calibrated to +5 % of the real reference per evaluation); the values do not change."""
+    from oracle import lsoda_port as lp
+    x, y, yerr = gsynth["Humped_x"], gsynth["Humped_y"], gsynth["Humped_yerr"]
+    for p in gsynth["Humped_pars"][:3]:
+        a = lp.lnprob(p, tarr, x, y, yerr)
+        b = lp.lnprob(p, tarr, x, y, yerr, reference_cost=True)
+        assert a == b
+    assert lp._pool_eval.__doc__ and "cost structure" in lp._pool_eval.__doc__
