@@ -14,6 +14,7 @@
 #include <mutex>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "mp_device.h"
@@ -631,6 +632,22 @@ static void draw_split(const mp_sampler *s, uint64_t step64, int32_t *perm) {
     }
 }
 
+// splits of `count` consecutive steps into perm[count][n_total]; the steps are independent (counter-based generator), so
+// large ensembles are drawn by a few host threads (8 192 walkers: 0.4 ms per step on one core, more than a half-step of a
+// walker-sharded ensemble takes on the GPU)
+static void draw_splits(const mp_sampler *s, uint64_t step0, int count, int32_t *perm) {
+    const size_t nt = (size_t)s->n_total;
+    const int n_thr = (int)std::min<size_t>({(size_t)count, (size_t)4, (nt * (size_t)count) / 8192});
+    auto work = [&](int first, int stride) {
+        for (int i = first; i < count; i += stride) draw_split(s, step0 + (uint64_t)i, perm + (size_t)i * nt);
+    };
+    if (n_thr <= 1) { work(0, 1); return; }
+    std::vector<std::thread> pool;
+    for (int k = 1; k < n_thr; ++k) pool.emplace_back(work, k, n_thr);
+    work(0, n_thr);
+    for (auto &th : pool) th.join();
+}
+
 static mp::StretchArgs stretch_args(const mp_sampler *s, const int32_t *d_perm, uint64_t step, int half) {
     mp::StretchArgs g{};
     g.pos = s->d_pos.p; g.lnprob = s->d_lnprob.p; g.n_accepted = s->d_acc.p;
@@ -757,7 +774,7 @@ int mp_sampler_run(mp_sampler *s, int n_steps, double *chain, double *chain_lnpr
         }
         for (int sub = 0; sub < chunk; sub += kSub) {
             const int sub_end = std::min(chunk, sub + kSub);
-            for (int st = sub; st < sub_end; ++st) draw_split(s, s->steps_done + (uint64_t)st, perm + (size_t)st * nt);
+            draw_splits(s, s->steps_done + (uint64_t)sub, sub_end - sub, perm + (size_t)sub * nt);
             HIP_TRY(hipMemcpyAsync(s->d_perm.p + (size_t)sub * nt, perm + (size_t)sub * nt,
                                    (size_t)(sub_end - sub) * nt * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
             for (int st = sub; st < sub_end; ++st) {
@@ -800,8 +817,7 @@ static int current_split(mp_sampler *s, hipStream_t st, const int32_t **d_perm) 
         if ((rc = s->h_win[b].ensure(bytes)) || (rc = s->d_win[b].ensure((size_t)mp_sampler::kWin * nt))) return rc;
         if (s->win_id[b] >= 0) HIP_TRY(hipEventSynchronize(s->win_copied[b]));   // staged two windows ago: long done
         int32_t *perm = (int32_t *)s->h_win[b].p;
-        for (int i = 0; i < mp_sampler::kWin; ++i)
-            draw_split(s, (uint64_t)win * mp_sampler::kWin + (uint64_t)i, perm + (size_t)i * nt);
+        draw_splits(s, (uint64_t)win * mp_sampler::kWin, mp_sampler::kWin, perm);
         // stream order puts the copy behind every kernel that still reads this buffer's previous contents
         HIP_TRY(hipMemcpyAsync(s->d_win[b].p, perm, bytes, hipMemcpyHostToDevice, st));
         HIP_TRY(hipEventRecord(s->win_copied[b], st));
