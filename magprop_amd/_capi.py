@@ -211,6 +211,9 @@ class Handle:
             self._h = None
 
     def __del__(self):
+        import sys
+        if sys.is_finalizing():      # interpreter shutdown: the HIP runtime may already be gone; the OS reclaims the rest
+            return
         try:
             self.close()
         except Exception:  # noqa: BLE001

@@ -73,6 +73,9 @@ class EnsembleSampler:
             self.handle.close()
 
     def __del__(self):
+        import sys
+        if sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:  # noqa: BLE001
