@@ -615,6 +615,7 @@ struct mp_sampler {
     PinnedBuf h_win[2];
     hipEvent_t win_copied[2] = {nullptr, nullptr};
     int64_t win_id[2] = {-1, -1};
+    bool ext_stream_work = false;   // half-steps were enqueued on a caller's stream since the last device-wide wait
 };
 
 // random split of every ensemble for step `step` (emcee's randomize_split): Fisher-Yates, counter (step, ensemble, i, 'split')
@@ -727,6 +728,7 @@ int mp_sampler_set_positions(mp_sampler *s, const double *pos) {
     for (size_t i = 0; i < nt * s->ndim; ++i)
         if (!std::isfinite(pos[i])) return fail(MP_EINVAL, "mp_sampler_set_positions: non-finite coordinate");
     HIP_TRY(hipDeviceSynchronize());   // the sharded entry points may have work in flight on a caller's stream
+    s->ext_stream_work = false;
     HIP_TRY(hipMemcpyAsync(s->d_pos.p, pos, nt * s->ndim * sizeof(double), hipMemcpyHostToDevice, h->stream));
     if (s->target == 1) {
         std::vector<double> lp(nt, 0.0);
@@ -763,6 +765,10 @@ int mp_sampler_run(mp_sampler *s, int n_steps, double *chain, double *chain_lnpr
     constexpr int kSub = 8;   // steps per batch of splits: the host draws the next batch while the GPU runs this one
     int rc;
     if ((rc = ensure_scratch(h, s->n_total))) return rc;
+    if (s->ext_stream_work) {   // sharded half-steps on a caller's stream may still be updating the state
+        HIP_TRY(hipDeviceSynchronize());
+        s->ext_stream_work = false;
+    }
     if (h->sh.scratch_stride > 0 && h->scratch_busy && h->scratch_stream != h->stream)
         HIP_TRY(hipStreamWaitEvent(h->stream, h->scratch_done, 0));
     for (int done = 0; done < n_steps;) {
@@ -843,6 +849,7 @@ int mp_sampler_halfstep_shard(mp_sampler *s, int half, int slot_lo, int slot_hi,
     const int32_t *d_perm = nullptr;
     int rc;
     if ((rc = current_split(s, st, &d_perm)) || (rc = ensure_scratch(h, s->n_total))) return rc;
+    s->ext_stream_work = true;
     if (slot_hi == slot_lo) return MP_OK;
     const bool uses_scratch = h->sh.scratch_stride > 0;
     if (uses_scratch && h->scratch_busy && h->scratch_stream != st) HIP_TRY(hipStreamWaitEvent(st, h->scratch_done, 0));
@@ -870,6 +877,7 @@ int mp_sampler_halfstep_apply(mp_sampler *s, int half, const double *d_rows, dou
     const int32_t *d_perm = nullptr;
     int rc;
     if ((rc = current_split(s, (hipStream_t)stream, &d_perm))) return rc;
+    s->ext_stream_work = true;
     mp::StretchArgs g = stretch_args(s, d_perm, s->steps_done, half);
     g.upd = const_cast<double *>(d_rows);
     g.chain = d_chain_row;

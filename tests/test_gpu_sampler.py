@@ -309,6 +309,10 @@ def test_sharded_entry_points_in_one_process_and_fbad(gsynth, tmp_path):
     chain, lnp = d.run_mcmc(pos, 25)
     torch.cuda.synchronize()
     assert np.array_equal(chain.cpu().numpy(), a.get_chain()) and np.array_equal(lnp.cpu().numpy(), a.get_log_prob())
+    # the two drivers can take turns on one sampler: ten more steps, fused on both, continue the same chain
+    a.run_mcmc(None, 10)
+    b.run_mcmc(None, 10)
+    assert np.array_equal(b.get_chain(), a.get_chain()[25:])
     n_bad, rows = a.get_bad()
     assert n_bad == b.get_bad()[0] and n_bad > 0 and len(rows) == min(n_bad, 4096)
     logged = np.loadtxt(fbad, delimiter=",", ndmin=2)
