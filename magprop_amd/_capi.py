@@ -5,6 +5,7 @@ This is the stub a magprop maintainer would add next to ``magnetar/funcs.py`` to
 device is visible, importing/creating raises ``MagpropAmdError`` loudly.
 """
 import ctypes as C
+import sys
 import os
 import subprocess
 
@@ -211,8 +212,7 @@ class Handle:
             self._h = None
 
     def __del__(self):
-        import sys
-        if sys.is_finalizing():      # interpreter shutdown: the HIP runtime may already be gone; the OS reclaims the rest
+        if sys is None or sys.is_finalizing():      # interpreter shutdown: the HIP runtime may already be gone; the OS reclaims the rest
             return
         try:
             self.close()

@@ -11,6 +11,7 @@ stretch-move half-step as one fused kernel (propose -> lnprob -> accept -> store
 trip per half-step.  Several independent ensembles (e.g. one per GRB dataset) can be advanced together.
 """
 import ctypes as C
+import sys
 
 import numpy as np
 
@@ -73,8 +74,7 @@ class EnsembleSampler:
             self.handle.close()
 
     def __del__(self):
-        import sys
-        if sys.is_finalizing():
+        if sys is None or sys.is_finalizing():
             return
         try:
             self.close()
