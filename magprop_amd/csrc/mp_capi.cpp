@@ -331,6 +331,8 @@ mp_handle *mp_create(const mp_model_cfg *cfg, const double *tgrid, int n_grid, i
         const double v = std::atof(e);
         if (v > 0.0 && v < 1.0) s.sweep_tol = v;
     }
+    s.ultra_tol = std::min(1.0e-5, 100.0 * s.sweep_tol);
+    if (const char *e = std::getenv("MAGPROP_AMD_ULTRA_TOL")) s.ultra_tol = std::atof(e);   // experiments only (0 disables)
     s.inv_q = 1.0 / q;
     {   // exponential Adams-Moulton quadrature matrix for nodes t_{j+1}, t_j, t_{j-1}, t_{j-2}:
         // W[k][m] = m! * [theta^m] l_k(theta), l_k the Lagrange basis on theta = 1, 0, -1/q, -(1/q + 1/q^2)

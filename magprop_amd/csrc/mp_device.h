@@ -53,6 +53,7 @@ struct DevShared {
     // geometric grid: ratio q = t_{j+1}/t_j and the exponential Adams-Moulton quadrature matrix for it
     double q, inv_q;
     double sweep_tol;     // relative change of the step-end values that ends the Newton sweeps of a tile
+    double ultra_tol;     // corrections below this let the next sweep linearise omega_dot instead of evaluating it
     int32_t n_simd;       // SIMDs of the device (multiProcessorCount x 4): batch sizes up to this get one wave per SIMD
     int32_t force_spl;    // experiments: 0 = automatic, else steps per lane of the one-wavefront kernels (2, 4)
     double eamW[4][4];

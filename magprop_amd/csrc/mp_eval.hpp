@@ -339,7 +339,9 @@ constexpr int kMaxSweepsMargin = 16;  // sweeps allowed beyond the tile length (
 // code/synthetic_datasets/funcs.py:131-132) is chattering on that discontinuity and ends as a 'flag' anyway; after this
 // many sweeps with an iterate beyond the limit the verdict is taken at once instead of after tile-length sweeps
 // (a prior-wide launch used to last as long as its one chattering walker: 0.45 instead of 0.30 ms at 1 024 walkers).
-constexpr int kChatterSweeps = 8;
+// Not fewer: a 256-step tile that starts from a poor guess may overshoot the limit for a dozen sweeps and still converge
+// below it (5 of the 32 768 soak walkers did with a threshold of 8).
+constexpr int kChatterSweeps = 24;
 
 // ---------------------------------------------------------------- the kernel
 // Evaluate ONE walker on the calling wavefront (all 64 lanes enter with identical arguments).
@@ -526,9 +528,13 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
             // A sweep that follows a small correction (every lane moved by < 1e-4) keeps the Jacobian lambda, e^{h lambda}
             // and the quadrature weights of the previous one and only re-evaluates omega_dot ("light" sweep): the scheme
             // may linearise about any nearby point, the result moves by ~1e-14, and the verification sweep costs a third less.
+            // A sweep that follows a FULL sweep whose correction was below ultra_tol (1e-5 at the default sweep tolerance, 1e-7 at the strict one) does
+            // not evaluate omega_dot at all: omega_dot at the new point is its linearisation about the previous one,
+            // f + lambda*(omega_new - omega_old), exact to the second order in that correction (< 5e-9 relative in omega_dot even across
+            // the propeller switch).  Such a sweep is the cheap verification pass of a tile whose first guess was good.
             Vd<kSPL> lam, ez;
             EamW<kSPL> cw;
-            bool light = false;
+            bool light = false, ultra = false;
             while (true) {
                 ++sweep;
                 {
@@ -542,18 +548,26 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                     }
                 }
                 Vd<kSPL> rot, f1;
-                if (light) {
+                const bool full = !light;                 // lambda, e^{h lambda} and the weights are renewed in this sweep
+                if (ultra) {
+#pragma unroll
+                    for (int s = 0; s < kSPL; ++s) {
+                        f1[s] = fma(lam[s], wg[s] - Ew[3 + s], Ef[3 + s]);
+                        rot[s] = sh.crot * (wg[s] * wg[s]);
+                    }
+                } else if (light) {
                     Vd<kSPL> unused;
                     f1 = omega_rhs<false>(sh, w, d1, wg, rot, unused);
                 } else {
                     f1 = omega_rhs<true>(sh, w, d1, wg, rot, lam);
                 }
-                bool flg = false;
+                bool flg = false, near_limit = false;
 #pragma unroll
                 for (int s = 0; s < kSPL; ++s) {
                     Ef[3 + s] = f1[s];
                     Ew[3 + s] = wg[s];
                     flg = flg || (active[s] && rot[s] > 0.27);
+                    near_limit = near_limit || rot[s] > 0.26;   // close to the break-up switch of the torque: no linearisation
                 }
                 // break-up reached by an iterate that is no longer a wild guess: the reference's 'flag'
                 flagged |= __ballot(settled && flg);
@@ -598,18 +612,22 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 double Ax, Bx;
             lane_prev_map(A, B, Ax, Bx);
                 double wc = fma(Ax, om_s, Bx);           // omega at this lane's first step start
-                bool all_ok = true, all_settled = true, all_small = true;
+                bool all_ok = true, all_settled = true, all_small = true, all_tiny = true;
 #pragma unroll
                 for (int s = 0; s < kSPL; ++s) {
                     wc = fma(aw[s], wc, bw[s]);
                     const double dw = fabs(wc - wg[s]), mag = fabs(wc);
                     all_settled = all_settled && (dw <= 1.0e-3 * mag);               // false for NaN
                     all_small = all_small && (dw <= 1.0e-4 * mag);
+                    all_tiny = all_tiny && (dw <= sh.ultra_tol * mag);
                     all_ok = all_ok && dw <= sh.sweep_tol * mag;
                     wg[s] = wc;
                 }
                 settled = all_settled;
                 light = __all(all_small);
+                // (lambda is the derivative at the point this sweep evaluated; the linearisation cannot see the break-up
+                // discontinuity of the accretion torque, so tiles that come near it keep evaluating omega_dot)
+                ultra = full && __all(all_tiny && !near_limit);
                 pending = __ballot(!all_ok);
                 if (pending == 0ull || flagged != 0ull || sweep >= kMaxSweeps) break;
                 if (over_sweeps >= kChatterSweeps) { flagged |= over_now ? over_now : pending; break; }

@@ -66,7 +66,8 @@ def test_every_kernel_variant_against_the_c_oracle(gsynth, tarr):
     for batch, label, env in ((256, "producer/consumer pair of wavefronts", {}),
                               (1024, "1 wavefront, 4 steps per lane", {}),
                               (4096, "1 wavefront, 2 steps per lane", {}),
-                              (4096, "1 wavefront, 2 steps per lane, default sweep tolerance", {"default_tol": True})):
+                              (4096, "1 wavefront, 2 steps per lane, default sweep tolerance", {"default_tol": True}),
+                              (1024, "1 wavefront, 4 steps per lane, default sweep tolerance", {"default_tol": True})):
         loose = bool(env.get("default_tol"))                      # the product's default: 1e-7 (include/magprop_amd.h)
         lp_ = LogProb(*sets[0], sweep_tol=None if loose else STRICT)
         for s in sets[1:]:
@@ -86,7 +87,7 @@ def test_every_kernel_variant_against_the_c_oracle(gsynth, tarr):
                                       "p999_rel_diff": float(np.quantile(rel, 0.999))}
         assert not np.any(np.isnan(out))
         assert np.all(out[st != 0] == -np.inf)
-        assert np.sum(rst != st) <= max(2, N_SOAK // 4000), summary["variants"][label]
+        assert np.sum(rst != st) == 0, summary["variants"][label]      # ok / flag / prior verdicts identical to the oracle's
         # default tolerance (1e-7): observed max 2.1e-8 over the 32 768 walkers, 99.9 % below 1e-8
         assert rel.max() <= (5e-8 if loose else 1e-9), summary["variants"][label]
         assert np.quantile(rel, 0.999) <= (1e-8 if loose else 1e-10), summary["variants"][label]
