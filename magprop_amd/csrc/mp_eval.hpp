@@ -561,14 +561,17 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 } else {
                     f1 = omega_rhs<true>(sh, w, d1, wg, rot, lam);
                 }
-                bool flg = false, near_limit = false;
+                // largest rotation parameter among this lane's step ends (the padding steps of the last tile repeat the
+                // last grid point once the first sweep has run; before that nothing is decided on them: `settled` is false)
+                double rot_max = rot[0];
 #pragma unroll
                 for (int s = 0; s < kSPL; ++s) {
                     Ef[3 + s] = f1[s];
                     Ew[3 + s] = wg[s];
-                    flg = flg || (active[s] && rot[s] > 0.27);
-                    near_limit = near_limit || rot[s] > 0.26;   // close to the break-up switch of the torque: no linearisation
+                    if (s > 0) rot_max = fmax(rot_max, rot[s]);
                 }
+                const bool flg = rot_max > 0.27;
+                const bool near_limit = rot_max > 0.26;   // close to the break-up switch of the torque: no linearisation
                 // break-up reached by an iterate that is no longer a wild guess: the reference's 'flag'
                 flagged |= __ballot(settled && flg);
                 const unsigned long long over_now = __ballot(flg);
@@ -612,17 +615,20 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 double Ax, Bx;
             lane_prev_map(A, B, Ax, Bx);
                 double wc = fma(Ax, om_s, Bx);           // omega at this lane's first step start
-                bool all_ok = true, all_settled = true, all_small = true, all_tiny = true;
+                // The convergence tests look at the lane's MEAN correction (its steps are consecutive and move together):
+                // one set of comparisons per lane instead of one per step.  NaN propagates through the sum: "not converged".
+                double dsum = 0.0;
 #pragma unroll
                 for (int s = 0; s < kSPL; ++s) {
                     wc = fma(aw[s], wc, bw[s]);
-                    const double dw = fabs(wc - wg[s]), mag = fabs(wc);
-                    all_settled = all_settled && (dw <= 1.0e-3 * mag);               // false for NaN
-                    all_small = all_small && (dw <= 1.0e-4 * mag);
-                    all_tiny = all_tiny && (dw <= sh.ultra_tol * mag);
-                    all_ok = all_ok && dw <= sh.sweep_tol * mag;
+                    dsum += fabs(wc - wg[s]);
                     wg[s] = wc;
                 }
+                const double mag = (double)kSPL * fabs(wc);
+                const bool all_settled = dsum <= 1.0e-3 * mag;                       // false for NaN
+                const bool all_small = dsum <= 1.0e-4 * mag;
+                const bool all_tiny = dsum <= sh.ultra_tol * mag;
+                const bool all_ok = dsum <= sh.sweep_tol * mag;
                 settled = all_settled;
                 light = __all(all_small);
                 // (lambda is the derivative at the point this sweep evaluated; the linearisation cannot see the break-up
