@@ -537,7 +537,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
             bool light = false, ultra = false;
             while (true) {
                 ++sweep;
-                {
+                if (!light) {   // (after a sweep that moved every lane by < 1e-4 the guesses are positive and finite)
                     bool wild = false;
 #pragma unroll
                     for (int s = 0; s < kSPL; ++s) wild = wild || !(wg[s] > 0.0);
@@ -640,14 +640,19 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
             }
             sweeps_total += sweep;
 
-            // ---------------- failure detection in time order (oracle/mp_oracle.c)
+            // ---------------- failure detection in time order (oracle/mp_oracle.c).  Per lane: a NaN or an
+            // infinity anywhere shows in the sum, a non-positive value in the minimum, the break-up limit in the largest
+            // omega (the padding steps of the last tile repeat the last grid point).
             {
-                bool bad = false, over = false;
+                double vsum = M1[0] + wg[0], vmin = fmin(M1[0], wg[0]), wmax = wg[0];
 #pragma unroll
-                for (int s = 0; s < kSPL; ++s) {
-                    bad = bad || (active[s] && (!(isfinite(M1[s]) && isfinite(wg[s])) || M1[s] <= 0.0 || wg[s] <= 0.0));
-                    over = over || (active[s] && sh.crot * wg[s] * wg[s] > 0.27);
+                for (int s = 1; s < kSPL; ++s) {
+                    vsum += M1[s] + wg[s];
+                    vmin = fmin(vmin, fmin(M1[s], wg[s]));
+                    wmax = fmax(wmax, wg[s]);
                 }
+                const bool bad = !isfinite(vsum) || !(vmin > 0.0);
+                const bool over = sh.crot * wmax * wmax > 0.27;
                 const unsigned long long mb = __ballot(bad);
                 // a step whose sweeps never settle is chattering on the Nacc discontinuity: same verdict as a flag
                 const unsigned long long mf = flagged | __ballot(over) | (flagged ? 0ull : pending);
