@@ -94,8 +94,10 @@ MP_DEV Flow<N> flow_state(const Walker &w, double n, const DiscPt<N> &p, const V
     FORN f.sq[i] = f.capped[i] ? w.sqrt_kc * y[i] : p.squ[i];       // sqrt(Rm)
     FORN f.fast[i] = f.capped[i] ? w.Kc * y[i] : om[i] * p.qu[i];
     FORN x[i] = fma(n, f.fast[i], -n);
-    bool saturated = true;                                          // |x| > 19.5: tanh(x) = +-1 to the last bit
-    FORN saturated = saturated && fabs(x[i]) > 19.5;
+    double xmin = fabs(x[0]);                                       // |x| > 19.5: tanh(x) = +-1 to the last bit
+#pragma unroll
+    for (int i = 1; i < N; ++i) xmin = fmin(xmin, fabs(x[i]));
+    const bool saturated = xmin > 19.5;                             // (false for a NaN lane minimum)
     if (__all(saturated)) {                                         // wave-uniform: deep propeller / deep accretion tiles
         FORN { f.e[i] = 0.0; f.r[i] = 1.0; f.th[i] = copysign(1.0, x[i]); }
     } else {
@@ -439,12 +441,10 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
         for (int tile = 0; tile < n_tiles; ++tile) {
             const int i0 = tile * kTile + lane * kSPL;   // this lane's first step: tgrid[i0] -> tgrid[i0+1]
             Vd<kSPL> tb, h;
-            Vb<kSPL> active;
 #pragma unroll
             for (int s = 0; s < kSPL; ++s) {
                 tb[s] = tb_next[s];
                 tb_next[s] = sh.tgrid[min(i0 + kTile + s + 1, nsteps)];
-                active[s] = i0 + s < nsteps;
             }
             {
                 const double ta0 = lane_prev(tb[kSPL - 1], t_s);

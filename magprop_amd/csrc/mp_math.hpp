@@ -275,8 +275,10 @@ MP_DEV Phi<N> phi1234(const Vd<N> &z) {
     // Taylor series of phi_4: 7 terms when every |z| of the wavefront is below 1/32 (< 2e-17 relative), 13 terms
     // for |z| < 1/2, closed forms elsewhere
     Vd<N> s;
-    bool all_tiny = true;
-    FORN all_tiny = all_tiny && fabs(z[i]) < 0.03125;
+    double zmax = fabs(z[0]);                      // the lane's largest |z|: one comparison per range instead of one per step
+#pragma unroll
+    for (int i = 1; i < N; ++i) zmax = fmax(zmax, fabs(z[i]));
+    const bool all_tiny = zmax < 0.03125;
     double inv6 = 1.0 / 6.0;
     if constexpr (kUseKtab<N>) {
         if (__all(all_tiny)) {
@@ -332,10 +334,10 @@ MP_DEV Phi<N> phi1234(const Vd<N> &z) {
     FORN r.p2[i] = fma(z[i], r.p3[i], 0.5);
     FORN r.p1[i] = fma(z[i], r.p2[i], 1.0);
     FORN r.e[i] = fma(z[i], r.p1[i], 1.0);
-    Vb<N> big;
-    bool any_big = false;
-    FORN { big[i] = !(fabs(z[i]) < 0.5); any_big = any_big || big[i]; }
+    const bool any_big = !(zmax < 0.5);           // (a NaN among the z is not seen by fmax: it stays a NaN in the series below)
     if (__any(any_big)) {                          // wave-uniform: only stiff / late-time tiles pay for this
+        Vb<N> big;
+        FORN big[i] = !(fabs(z[i]) < 0.5);
         Vd<N> zc, zs;
         FORN zc[i] = fmax(z[i], -750.0);
         FORN zs[i] = big[i] ? z[i] : 1.0;
