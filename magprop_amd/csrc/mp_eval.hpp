@@ -495,7 +495,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 }
                 scan_affine(A, B);
                 double Ax, Bx;
-            lane_prev_map(A, B, Ax, Bx);   // exclusive prefix
+                lane_prev_map(A, B, Ax, Bx);   // exclusive prefix
                 double Mc = fma(Ax, M_s, Bx);            // Mdisc at this lane's first step start
 #pragma unroll
                 for (int s = 0; s < kSPL; ++s) { Mc = fma(am[s], Mc, bm[s]); M1[s] = Mc; }
@@ -613,7 +613,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 }
                 scan_affine(A, B);
                 double Ax, Bx;
-            lane_prev_map(A, B, Ax, Bx);
+                lane_prev_map(A, B, Ax, Bx);
                 double wc = fma(Ax, om_s, Bx);           // omega at this lane's first step start
                 // The convergence tests look at the lane's MEAN correction (its steps are consecutive and move together):
                 // one set of comparisons per lane instead of one per step.  NaN propagates through the sum: "not converged".
