@@ -144,6 +144,30 @@ def test_sampler_on_a_long_light_curve(gsynth):
     assert tarr[0] <= x[0] and x[-1] <= tarr[-1]
 
 
+def test_sampler_library_variant_seven_parameters_short_grb_grid(glib):
+    """The `magnetar` package variant through the fused sampler: 7 parameters (f_beam sampled, magnetar/mcmc_eqns.py:22-25,
+    64-75), the "S" grid (magnetar/funcs.py:132-133): the stored log-posteriors are those of magprop_amd.lnprob — the
+    front end checked against the reference's values in tests/test_gpu_parity.py — at the stored positions."""
+    import pandas as pd
+    import magprop_amd as mpa
+    from magprop_amd import EnsembleSampler
+    x, y, yerr = glib["ds_S"]
+    data = pd.DataFrame({"t": x, "Lum50": y, "Lum50err": yerr})
+    rng = np.random.default_rng(12)
+    start = np.array([1.0, 5.0, -3.0, 2.0, -1.0, 0.0, 5.0])                 # B, P, lg MdiscI, lg RdiscI, lg eps, lg delta, f_beam
+    pos = start + 1.0e-3 * rng.standard_normal((56, 7))
+    s = EnsembleSampler(56, 7, x, y, yerr, variant="lib", GRBtype="S", seed=21)
+    s.run_mcmc(pos, 25)
+    chain, lnp = s.get_chain(), s.get_log_prob()
+    assert chain.shape == (25, 56, 7) and np.all(np.isfinite(lnp))
+    ref = mpa.lnprob(chain[-1], data, "S")
+    assert np.allclose(ref, lnp[-1], rtol=1e-8, atol=1e-9)
+    assert 0.1 < s.acceptance_fraction.mean() < 0.95 and np.any(chain[-1] != pos)
+    lo, hi = mpa.mcmc_eqns._bounds(7)
+    assert np.all(chain >= lo) and np.all(chain <= hi)                      # accepted positions never leave the prior box
+    s.close()
+
+
 def test_synth_mcmc_tool_rerun_reproduces_the_chain(tmp_path, capsys):
     """synth_mcmc.py:139-149 (--re-run): the run recorded in <grb>_info.json is repeated bit for bit."""
     import filecmp
