@@ -154,7 +154,7 @@ def test_sampler_library_variant_seven_parameters_short_grb_grid(glib):
     x, y, yerr = glib["ds_S"]
     data = pd.DataFrame({"t": x, "Lum50": y, "Lum50err": yerr})
     rng = np.random.default_rng(12)
-    start = np.array([1.0, 5.0, -3.0, 2.0, -1.0, 0.0, 5.0])                 # B, P, lg MdiscI, lg RdiscI, lg eps, lg delta, f_beam
+    start = np.array([1.0, 5.0, -2.0, 2.0, 0.5, 0.0, 5.0])                  # B, P, lg MdiscI, lg RdiscI, lg eps, lg delta, f_beam (inside magnetar/mcmc_limits.csv)
     pos = start + 1.0e-3 * rng.standard_normal((56, 7))
     s = EnsembleSampler(56, 7, x, y, yerr, variant="lib", GRBtype="S", seed=21)
     s.run_mcmc(pos, 25)
