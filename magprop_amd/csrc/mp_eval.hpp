@@ -94,9 +94,7 @@ MP_DEV Flow<N> flow_state(const Walker &w, double n, const DiscPt<N> &p, const V
     FORN f.sq[i] = f.capped[i] ? w.sqrt_kc * y[i] : p.squ[i];       // sqrt(Rm)
     FORN f.fast[i] = f.capped[i] ? w.Kc * y[i] : om[i] * p.qu[i];
     FORN x[i] = fma(n, f.fast[i], -n);
-    double xmin = fabs(x[0]);                                       // |x| > 19.5: tanh(x) = +-1 to the last bit
-#pragma unroll
-    for (int i = 1; i < N; ++i) xmin = fmin(xmin, fabs(x[i]));
+    const double xmin = lane_minabs(x.v);                           // |x| > 19.5: tanh(x) = +-1 to the last bit
     const bool saturated = xmin > 19.5;                             // (false for a NaN lane minimum)
     if (__all(saturated)) {                                         // wave-uniform: deep propeller / deep accretion tiles
         FORN { f.e[i] = 0.0; f.r[i] = 1.0; f.th[i] = copysign(1.0, x[i]); }
@@ -563,13 +561,12 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 }
                 // largest rotation parameter among this lane's step ends (the padding steps of the last tile repeat the
                 // last grid point once the first sweep has run; before that nothing is decided on them: `settled` is false)
-                double rot_max = rot[0];
 #pragma unroll
                 for (int s = 0; s < kSPL; ++s) {
                     Ef[3 + s] = f1[s];
                     Ew[3 + s] = wg[s];
-                    if (s > 0) rot_max = fmax(rot_max, rot[s]);
                 }
+                const double rot_max = lane_max(rot.v);
                 const bool flg = rot_max > 0.27;
                 const bool near_limit = rot_max > 0.26;   // close to the break-up switch of the torque: no linearisation
                 // break-up reached by an iterate that is no longer a wild guess: the reference's 'flag'
@@ -644,13 +641,10 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
             // infinity anywhere shows in the sum, a non-positive value in the minimum, the break-up limit in the largest
             // omega (the padding steps of the last tile repeat the last grid point).
             {
-                double vsum = M1[0] + wg[0], vmin = fmin(M1[0], wg[0]), wmax = wg[0];
+                double vsum = M1[0] + wg[0];
 #pragma unroll
-                for (int s = 1; s < kSPL; ++s) {
-                    vsum += M1[s] + wg[s];
-                    vmin = fmin(vmin, fmin(M1[s], wg[s]));
-                    wmax = fmax(wmax, wg[s]);
-                }
+                for (int s = 1; s < kSPL; ++s) vsum += M1[s] + wg[s];
+                const double vmin = min_raw(lane_min(M1.v), lane_min(wg.v)), wmax = lane_max(wg.v);
                 const bool bad = !isfinite(vsum) || !(vmin > 0.0);
                 const bool over = sh.crot * wmax * wmax > 0.27;
                 const unsigned long long mb = __ballot(bad);

@@ -110,6 +110,61 @@ MP_DEV double fma3(double a, double b, double c) {
     return d;
 }
 
+// Raw hardware max / min (IEEE maxNum / minNum: a NaN operand is dropped).  hipcc's fmax/fmin first canonicalise every
+// operand it cannot prove canonical (one v_max_f64 x, x, x each): in the per-lane extrema below that doubles the count.
+// Operands are plain VALU results everywhere these are used.
+MP_DEV double max_raw(double a, double b) {
+    double d;
+    asm("v_max_f64 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+MP_DEV double min_raw(double a, double b) {
+    double d;
+    asm("v_min_f64 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+MP_DEV double maxabs_raw(double a, double b) {   // max(|a|, |b|)
+    double d;
+    asm("v_max_f64 %0, |%1|, |%2|" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+MP_DEV double minabs_raw(double a, double b) {   // min(|a|, |b|)
+    double d;
+    asm("v_min_f64 %0, |%1|, |%2|" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+// extrema over the N values of a lane
+template <int N>
+MP_DEV double lane_maxabs(const double (&v)[N]) {
+    double m = N > 1 ? maxabs_raw(v[0], v[1]) : fabs(v[0]);
+#pragma unroll
+    for (int i = 2; i + 1 < N; i += 2) m = max_raw(m, maxabs_raw(v[i], v[i + 1]));
+    if (N > 2 && (N & 1)) m = maxabs_raw(m, v[N - 1]);
+    return m;
+}
+template <int N>
+MP_DEV double lane_minabs(const double (&v)[N]) {
+    double m = N > 1 ? minabs_raw(v[0], v[1]) : fabs(v[0]);
+#pragma unroll
+    for (int i = 2; i + 1 < N; i += 2) m = min_raw(m, minabs_raw(v[i], v[i + 1]));
+    if (N > 2 && (N & 1)) m = minabs_raw(m, v[N - 1]);
+    return m;
+}
+template <int N>
+MP_DEV double lane_max(const double (&v)[N]) {
+    double m = v[0];
+#pragma unroll
+    for (int i = 1; i < N; ++i) m = max_raw(m, v[i]);
+    return m;
+}
+template <int N>
+MP_DEV double lane_min(const double (&v)[N]) {
+    double m = v[0];
+#pragma unroll
+    for (int i = 1; i < N; ++i) m = min_raw(m, v[i]);
+    return m;
+}
+
 // p <- p*x + c on all N chains
 template <int N>
 MP_DEV void horner(Vd<N> &p, const Vd<N> &x, double c) {
@@ -275,9 +330,7 @@ MP_DEV Phi<N> phi1234(const Vd<N> &z) {
     // Taylor series of phi_4: 7 terms when every |z| of the wavefront is below 1/32 (< 2e-17 relative), 13 terms
     // for |z| < 1/2, closed forms elsewhere
     Vd<N> s;
-    double zmax = fabs(z[0]);                      // the lane's largest |z|: one comparison per range instead of one per step
-#pragma unroll
-    for (int i = 1; i < N; ++i) zmax = fmax(zmax, fabs(z[i]));
+    const double zmax = lane_maxabs(z.v);          // the lane's largest |z|: one comparison per range instead of one per step
     const bool all_tiny = zmax < 0.03125;
     double inv6 = 1.0 / 6.0;
     if constexpr (kUseKtab<N>) {
