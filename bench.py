@@ -146,6 +146,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=20261003)
+    ap.add_argument("--spin-up", type=int, default=300,
+                    help="untimed launches before the W warmup steps: the CPU-baseline leg leaves the GPU idle for ~15 s and "
+                         "the first few dozen launches after that run at idle clocks (a 20-step timed region read 8 %% low)")
     ap.add_argument("--no-mcmc", action="store_true", help="skip the ensemble-sampler leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the prior-wide / burnt-in kernel timings and the golden check")
     ap.add_argument("--mcmc-steps", type=int, default=100)
@@ -285,6 +288,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    if n_local > 0 and a.spin_up > 0:                           # bring the clocks up (untimed, before the warmup steps)
+        spin_out = torch.empty(n_local, dtype=torch.float64, device=dev)
+        for _ in range(a.spin_up):
+            launch(props[0][lo:hi], spin_out, ds_local, status)
+        torch.cuda.synchronize(dev)
     loop(0, a.warmup)                                          # same ops as the timed loop (lazy kernel loads happen here)
     fence()
     t0 = time.perf_counter()
@@ -414,7 +422,7 @@ def main():
                      "frac": None if flops_launch is None else flops_launch / kavg / 1e12 / FP64_VALU_PEAK_TFLOPS,
                      "note": "flops executed = 64 x (2 FMA + MUL + ADD) fp64 instructions counted by rocprofv3 PMC for this "
                              "launch size (profiles/pmc_figures.json) / kernel time measured here"},
-            "kernel_evals_per_sec_per_gpu": n_local / kavg,
+            "kernel_evals_per_sec_per_gpu": n_local / kavg, "spin_up_launches": a.spin_up,
             "host_enqueue_ms_per_step": 1e3 * t_host / a.steps,
             "check": {"lnprob0": first, "n_not_ok": n_flag, "checksum": float(checksum.item())},
         }
