@@ -239,17 +239,19 @@ MP_DEV Vd<N> exp_fast(const Vd<N> &x) {
     Vd<N> k, r, p;
     if constexpr (kUseKtab<N>) {
         const d2v la = ktab2(14), lb = ktab2(16);    // log2(e), -ln2_hi | -ln2_lo, pad
+        const d2v c4 = ktab2(4), c6 = ktab2(6), c8 = ktab2(8), c10 = ktab2(10), c12 = ktab2(12);   // all reads first
         FORN k[i] = __builtin_rint(x[i] * la.x);
         FORN r[i] = fma(k[i], la.y, x[i]);
         FORN r[i] = fma(k[i], lb.x, r[i]);
-        {
-            const d2v c = ktab2(4);                  // Taylor degree 12 on |r| <= ln2/2: 1.7e-16
-            FORN p[i] = fma3(r[i], c.x, c.y);        // r/12! + 1/11!
-        }
-        horner2(p, r, 6);                            // 1/10!, 1/9!
-        horner2(p, r, 8);                            // 1/8!, 1/7!
-        horner2(p, r, 10);                           // 1/6!, 1/5!
-        horner2(p, r, 12);                           // 1/4!, 1/3!
+        FORN p[i] = fma3(r[i], c4.x, c4.y);          // Taylor degree 12 on |r| <= ln2/2 (1.7e-16): r/12! + 1/11!
+        FORN p[i] = fma3(p[i], r[i], c6.x);          // 1/10!
+        FORN p[i] = fma3(p[i], r[i], c6.y);          // 1/9!
+        FORN p[i] = fma3(p[i], r[i], c8.x);          // 1/8!
+        FORN p[i] = fma3(p[i], r[i], c8.y);          // 1/7!
+        FORN p[i] = fma3(p[i], r[i], c10.x);         // 1/6!
+        FORN p[i] = fma3(p[i], r[i], c10.y);         // 1/5!
+        FORN p[i] = fma3(p[i], r[i], c12.x);         // 1/4!
+        FORN p[i] = fma3(p[i], r[i], c12.y);         // 1/3!
     } else {
         FORN k[i] = __builtin_rint(x[i] * 1.4426950408889634074);
         FORN r[i] = fma(k[i], -6.93147180369123816490e-01, x[i]);
@@ -335,15 +337,15 @@ MP_DEV Phi<N> phi1234(const Vd<N> &z) {
     double inv6 = 1.0 / 6.0;
     if constexpr (kUseKtab<N>) {
         if (__all(all_tiny)) {
-            {
-                const d2v c = ktab2(6);
-                FORN s[i] = fma3(z[i], c.x, c.y);     // z/10! + 1/9!
-            }
-            horner2(s, z, 8);                         // 1/8!, 1/7!
-            horner2(s, z, 10);                        // 1/6!, 1/5!
-            const d2v c = ktab2(12);
-            FORN s[i] = fma3(s[i], z[i], c.x);        // 1/4!
-            inv6 = c.y;
+            // all four table reads first (they return in order, so each use waits only for its own pair)
+            const d2v c6 = ktab2(6), c8 = ktab2(8), c10 = ktab2(10), c12 = ktab2(12);
+            FORN s[i] = fma3(z[i], c6.x, c6.y);       // z/10! + 1/9!
+            FORN s[i] = fma3(s[i], z[i], c8.x);       // 1/8!
+            FORN s[i] = fma3(s[i], z[i], c8.y);       // 1/7!
+            FORN s[i] = fma3(s[i], z[i], c10.x);      // 1/6!
+            FORN s[i] = fma3(s[i], z[i], c10.y);      // 1/5!
+            FORN s[i] = fma3(s[i], z[i], c12.x);      // 1/4!
+            inv6 = c12.y;
         } else {
             {
                 const d2v c = ktab2(0);
