@@ -162,3 +162,25 @@ def test_engine_cache_is_bounded(monkeypatch):
     assert len(made) == engine.MAX_ENGINES + 4 and len(closed) == 4 and first.handle not in closed
     engine.clear()
     assert len(closed) == len(made)
+
+
+def test_only_the_checkers_touch_the_oracle():
+    """oracle/ is test infrastructure: besides tests/, only bench.py's cpu_baseline leg and __graft_entry__.smoke() (and
+    build(), which compiles it) may refer to it — no tool, no product module."""
+    import re
+    allowed = {"bench.py": "def cpu_baseline", "__graft_entry__.py": None}
+    for dirpath, dirs, files in os.walk(ROOT):
+        dirs[:] = [d for d in dirs if d not in (".git", "gpurun_out", "tests", "oracle", "__pycache__", ".pytest_cache")]
+        for f in files:
+            if not f.endswith((".py", ".sh", ".cpp", ".hip", ".hpp", ".h")):
+                continue
+            rel = os.path.relpath(os.path.join(dirpath, f), ROOT)
+            src = open(os.path.join(dirpath, f)).read()
+            # imports, links or executions (comments that cite oracle/mp_oracle.c as the serial restatement are fine)
+            uses = re.search(r"^\s*(from|import)\s+oracle|libmp_oracle|#include\s+\"[^\"]*oracle|python[^\n]*oracle/", src, re.M) is not None
+            if rel in allowed:
+                if rel == "bench.py":      # every import of the oracle sits inside cpu_baseline()
+                    body = src[src.index("def cpu_baseline"):src.index("def config5_datasets")]
+                    assert src.count("from oracle") == body.count("from oracle") == 1
+                continue
+            assert not uses, rel
