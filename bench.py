@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
 """bench.py — walker-lnprob evaluations/sec of the HIP hot path (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps K --warmup W [--config 2|3|4|5]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-           --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config 2|3|4|5]
+
+With N > 1 and no WORLD_SIZE in the environment bench.py launches its own N rank processes (one per GPU, before the
+parent makes any GPU call), waits for them and exits with the first non-zero child code; rank 0 prints the line.  Under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...` it is one rank of that job.
 
 A "step" is one pass of the hot path over one ensemble of proposals: every walker's lnprior + ODE integration over
 the 10 001-point grid + luminosity + interpolation + chi^2.  Workloads (BASELINE.json configs; --config):
@@ -15,18 +17,24 @@ the 10 001-point grid + luminosity + interpolation + chi^2.  Workloads (BASELINE
   5            all four GRB types, 1 024 walkers each, light curves of mixed lengths (8 ... 1 944 points) selected per
                walker, 4 096 walkers in total sharded over the N GPUs (configs[4]; strong scaling)
 
-Every rank evaluates its contiguous block of the replicated proposal batch; ONE RCCL all-gather of the lnprob slices
-follows so every rank sees the full ensemble (what the stretch move needs).  Proposals are resident in HBM before the
-timed region (generated on device, replicated on every rank from a common seed).
+Every rank evaluates its contiguous block of the replicated proposal batch; with N > 1 ONE RCCL all-gather of the lnprob
+slices follows so every rank sees the full ensemble (what the stretch move needs).  Proposals are resident in HBM before
+the timed region (generated on device, replicated on every rank from a common seed).
 
 Prints one JSON line on rank 0 (contract in the task description) with extra objects:
   roofline         the lnprob kernel's algorithmic HBM bytes / measured kernel time vs the 8 TB/s peak.  This path is
                    NOT HBM-bound (and has no MFMA work): it is a latency-bound fp64 VALU recurrence; "valu" prices the
                    same kernel against the fp64 vector peak with the flops the PMC counters saw (profiles/).
-  kernel_ms        the same kernel on harder inputs (N = 1): walkers uniform over the prior box, and a burnt-in ensemble
+  configs          the other BASELINE workloads through the same timed loop, shorter: N = 1: configs 3, 4 (8 192 walkers
+                   on one GPU), 5 and mode B ("curve": config 2 with the model light curve written to HBM); N > 1: configs
+                   4 and 5 with their fixed totals sharded over the N GPUs (strong scaling).
+  sustained        N = 1: >= 2 s of back-to-back config-2 passes (the headline's timed region is a few ms), with the
+                   shader clock read before / during / after.
+  config1          N = 1: BASELINE configs[0] (24 walkers x 50 steps of the stretch move): through the CPU port on this
+                   box's host cores, and through the HIP sampler.
+  kernel_ms        N = 1: the same kernel on harder inputs: walkers uniform over the prior box, and a burnt-in ensemble
                    (positions after 500 sampler steps), each with its Newton sweeps per tile.
-  check            the reference's own golden walkers (tests/golden/golden_synth.npz) evaluated in this run: max
-                   deviation from the reference run with a tight integrator.
+  check            the reference's own golden walkers (tests/golden/golden_synth.npz) evaluated in this run.
   ensemble_sampler the same metric through the device-resident stretch move (N = 1: fused single-GPU sampler;
                    N > 1: walker-sharded half-steps with one all-gather each — dependent launches, nothing overlapped).
   cpu_baseline     oracle/lsoda_port.py in its reference_cost mode (scipy odeint + Python RHS that re-derives the constants
@@ -34,8 +42,11 @@ Prints one JSON line on rank 0 (contract in the task description) with extra obj
                    values) timed on this box's host cores over a bounded sample of the same walkers (rank 0, N = 1 only).
 """
 import argparse
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -58,7 +69,11 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X fp64 vector peak (spec)
 BYTES_PER_EVAL_A = 48 + 8 + 4  # mode A: 6 fp64 parameters in, lnprob + status out
 BYTES_LTOT = 10001 * 8         # mode B adds the model light curve
-EVENT_EVERY = 4                # kernel duration is sampled with HIP events on every 4th launch of the timed region
+EVENT_EVERY = 4                # kernel duration is sampled with HIP events on every 4th launch of a timed region
+# |lnprob - reference| contract of SURVEY.md 8(c); points where the reference's default-tolerance LSODA run itself is off
+# by more than this are enumerated in the golden files (*_lsoda_noise_idx) and checked against the tight run instead
+REF_ATOL, REF_RTOL = 1.0e-5, 2.0e-6
+TIGHT_ATOL, TIGHT_RTOL = 1.0e-7, 1.0e-7
 
 
 def usable_cores():
@@ -76,9 +91,9 @@ def usable_cores():
     return max(1, min(n, 64))
 
 
+# ---------------------------------------------------------------- CPU legs (before this process touches the GPU: they fork)
 def cpu_baseline(grb, budget_s, seed):
-    """Time the scipy/LSODA port over a bounded sample; must run BEFORE this process touches the GPU
-    (it forks worker processes)."""
+    """Time the scipy/LSODA port over a bounded sample."""
     import multiprocessing as mp
 
     from oracle import lsoda_port as lp
@@ -107,10 +122,85 @@ def cpu_baseline(grb, budget_s, seed):
             "ms_per_eval_per_core": 1e3 * t_used * cores / done, "check_lnprob0": float(vals[0])}
 
 
+def config1_cpu(seed, n_walk=24, n_steps=50):
+    """BASELINE configs[0] on the host: emcee's stretch move (oracle/stretch_oracle.py, the restatement of the absent
+    emcee) over the LSODA port, proposals of a half-step mapped over a process pool as synth_mcmc.py:178-185 does."""
+    import multiprocessing as mp
+
+    from oracle import lsoda_port as lp
+    from oracle import stretch_oracle as so
+    g = np.load(os.path.join(ROOT, "tests", "golden", "golden_synth.npz"))
+    x, y, yerr = g["Humped_x"], g["Humped_y"], g["Humped_yerr"]
+    cores = usable_cores()
+    rng = np.random.default_rng(seed + 24)
+    p0 = np.array(TRUTH["Humped"]) + 1.0e-4 * rng.standard_normal((n_walk, 6))
+    ctx = mp.get_context("fork")
+    with ctx.Pool(min(cores, n_walk), initializer=lp._pool_init, initargs=(lp.grid("L"), x, y, yerr)) as pool:
+        pool.map(lp._pool_eval, list(p0[:min(cores, n_walk)]))   # warm the workers
+        t0 = time.perf_counter()
+        _, _, acc = so.run_batched(p0, n_steps, seed, batch_fn=lambda P: pool.map(lp._pool_eval, list(P)))
+        dt = time.perf_counter() - t0
+    evals = n_walk * (n_steps + 1)
+    return p0, {"seconds": dt, "evals": evals, "evals_per_sec": evals / dt, "cores": min(cores, n_walk),
+                "acceptance_fraction": float(acc.mean() / n_steps),
+                "what": f"{n_walk} walkers x {n_steps} steps, stretch move (oracle/stretch_oracle.py) over oracle/lsoda_port.py "
+                        f"(reference cost structure), half-steps of {n_walk // 2} proposals over multiprocessing.Pool"}
+
+
+# ---------------------------------------------------------------- self-launch (N > 1 without a launcher)
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(n, argv):
+    """Start one child per rank (this process has not touched the GPU and never will), wait, propagate failure.
+    stdout is inherited, so rank 0's JSON line is this process's output."""
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc, alive, t_fail = 0, set(range(n)), None
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and rc == 0:
+                rc, t_fail = code, time.monotonic()
+                print(f"bench.py: rank {r} exited with code {code}", file=sys.stderr)
+        if t_fail is not None and alive and time.monotonic() - t_fail > 20.0:
+            for r in alive:                                   # the peers of a dead rank would wait in a collective for ever
+                procs[r].kill()
+            t_fail = time.monotonic() + 1e9
+        time.sleep(0.05)
+    return rc if rc >= 0 else 1
+
+
+# ---------------------------------------------------------------- helpers
+def read_sclk_mhz():
+    """Current shader clock of GPU 0 in MHz from sysfs (None if unreadable on this box)."""
+    for p in sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk")):
+        try:
+            for line in open(p).read().splitlines():
+                if line.rstrip().endswith("*"):
+                    return float(line.split(":")[1].strip().split("M")[0])
+        except (OSError, ValueError, IndexError):
+            continue
+    return None
+
+
 def config5_datasets(g):
-    """Eleven light curves of 8 ... 1 944 points: the four seeded synthetic sets (50 points), the three long sets of
-    tests/golden/golden_longlc.npz (112 / 410 / 1 944: real SGRB lengths) and four short ones (8 / 63 / 64 /
-    65 points) drawn around the four types' model curves."""
+    """Light curves of 8 ... 1 944 points: the four seeded synthetic sets (50 points), the three long sets of
+    tests/golden/golden_longlc.npz (112 / 410 / 1 944: real SGRB lengths), four short ones (8 / 63 / 64 /
+    65 points) drawn around the four types' model curves and, when the fixture is present, the two light curves of
+    tests/golden/golden_swift.npz whose time stamps are those of real Swift observations (densely clustered early)."""
     from magprop_amd import model_lum
     gl = np.load(os.path.join(ROOT, "tests", "golden", "golden_longlc.npz"))
     sets = [(g[t + "_x"], g[t + "_y"], g[t + "_yerr"]) for t in TYPES]
@@ -123,109 +213,60 @@ def config5_datasets(g):
         x[0], x[-1] = tarr[0], tarr[-1]
         y0 = np.interp(x, tarr, lc)
         sets.append((x, y0 + rng.normal(0, 0.2 * y0), 0.2 * y0))
+    sw = os.path.join(ROOT, "tests", "golden", "golden_swift.npz")
+    if os.path.exists(sw):
+        gs = np.load(sw)
+        sets += [tuple(gs[k + "_ds"]) for k in ("swift_060614", "swift_051016B") if k + "_ds" in gs]
     return sets
 
 
-def main():
-    # The contract is ONE JSON line on stdout.  Native libraries write banners there too (RCCL prints its version block
-    # on stdout when a communicator is created), so everything but the result line is sent to stderr at fd level.
-    sys.stdout.flush()
-    json_out = os.fdopen(os.dup(1), "w")
-    os.dup2(2, 1)
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5], help="BASELINE.json workload (see the docstring)")
-    ap.add_argument("--nwalk", type=int, default=None, help="walkers per GPU (overrides the preset; weak scaling)")
-    ap.add_argument("--grb", default=None, choices=list(TRUTH))
-    ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
-                    help="strong: the preset's walkers are the TOTAL (8 192 for --config 2) and are sharded over the GPUs")
-    ap.add_argument("--curve", action="store_true", help="mode B: also write the model light curve to HBM")
-    ap.add_argument("--spread", type=float, default=1.0e-4, help="walkers at truth + spread*randn (synth_mcmc.py:175-176)")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--seed", type=int, default=20261003)
-    ap.add_argument("--spin-up", type=int, default=300,
-                    help="untimed launches before the W warmup steps: the CPU-baseline leg leaves the GPU idle for ~15 s and "
-                         "the first few dozen launches after that run at idle clocks (a 20-step timed region read 8 %% low)")
-    ap.add_argument("--no-mcmc", action="store_true", help="skip the ensemble-sampler leg")
-    ap.add_argument("--no-extra", action="store_true", help="skip the prior-wide / burnt-in kernel timings and the golden check")
-    ap.add_argument("--mcmc-steps", type=int, default=100)
-    ap.add_argument("--overlap", type=int, default=1, choices=[0, 1],
-                    help="1: the all-gather of one pass overlaps the next pass's kernel (independent batches); 0: serialised")
-    ap.add_argument("--always-gather", action="store_true",
-                    help="diagnostic: run the RCCL all-gather even at N=1 (group of one) to time the collective path")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="process-group backend; gloo is for rehearsing N>1 on a one-GPU box (ranks share the card, "
-                         "rows are gathered through host memory) and is never a reported configuration")
-    a = ap.parse_args()
+class Ctx:
+    """What every leg of one rank shares: device, process group, golden data, command-line switches."""
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched through torch.distributed.run (see the docstring)")
-        a.gpus = world
 
-    # ---- workload
-    grb = a.grb or {2: "Humped", 3: "Classic", 4: "Humped", 5: "Humped"}[a.config]
-    preset_walkers = {2: 1024, 3: 4096, 4: 8192, 5: 4096}[a.config]
-    scaling = a.scaling or ("strong" if a.config in (4, 5) else "weak")
-    if a.nwalk is not None:
-        n_global = a.nwalk * world if scaling == "weak" else a.nwalk
-    elif scaling == "weak":
-        n_global = preset_walkers * world
-    else:
-        n_global = 8192 if a.config == 2 else preset_walkers
-
-    cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        cpu = cpu_baseline(grb, a.cpu_seconds, a.seed)          # before any GPU initialisation (forks)
-
+def run_passes(c, config, scaling, steps, warmup, curve=False, nwalk=None, grb=None, spin_up=0):
+    """The timed loop of the contract over one workload: W untimed + K timed passes bracketed by barrier + synchronize,
+    max over ranks.  Returns the figures of the leg (rank-local kernel times; whole-job rate)."""
     import torch
     import torch.distributed as dist
-    if not torch.cuda.is_available():
-        sys.exit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    dev_index = local_rank % torch.cuda.device_count()           # == local_rank except in the gloo rehearsal
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
-    if world > 1:
-        if a.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)       # RCCL over xGMI
-        else:
-            dist.init_process_group("gloo")
 
-    from magprop_amd import EnsembleSampler, LogProb
-    from magprop_amd.distributed import DistributedEnsembleSampler, HipShardEngine, ShardedLnprob, shard_range
-    g = np.load(os.path.join(ROOT, "tests", "golden", "golden_synth.npz"))
+    from magprop_amd import LogProb
+    from magprop_amd.distributed import ShardedLnprob, shard_range
+    a, dev, world, rank, g = c.a, c.dev, c.world, c.rank, c.g
+    grb = grb or {2: "Humped", 3: "Classic", 4: "Humped", 5: "Humped"}[config]
+    preset = {2: 1024, 3: 4096, 4: 8192, 5: 4096}[config]
+    if nwalk is not None:
+        n_global = nwalk * world if scaling == "weak" else nwalk
+    elif scaling == "weak":
+        n_global = preset * world
+    else:
+        n_global = 8192 if config == 2 else preset
     x, y, yerr = g[grb + "_x"], g[grb + "_y"], g[grb + "_yerr"]
-    total = a.warmup + a.steps
+    total = warmup + steps
     gen = torch.Generator(device=dev).manual_seed(a.seed)        # same seed on every rank: replicated proposals
     ds_global = None
-    if a.config == 5:
+    if config == 5:
         sets = config5_datasets(g)
-        lp = LogProb(*sets[0], device=dev_index)
+        lp = LogProb(*sets[0], device=c.dev_index)
         for s_ in sets[1:]:
             lp.add_dataset(*s_)
         nw = n_global // 4
         truth = torch.tensor([TRUTH[t] for t in TYPES], dtype=torch.float64, device=dev).repeat_interleave(nw, dim=0)
         rng5 = np.random.default_rng(a.seed)
         ids = np.empty(n_global, dtype=np.int32)
-        for k in range(4):   # half of every type's walkers on its own seeded set, the others over the seven further sets
+        for k in range(4):   # half of every type's walkers on its own seeded set, the others over the further sets
             ids[k * nw:(k + 1) * nw] = np.where(np.arange(nw) < nw // 2, k, rng5.integers(4, len(sets), nw))
         ds_global = torch.from_numpy(ids).to(dev)
         n_obs_desc = sorted(len(s_[0]) for s_ in sets)
     else:
-        lp = LogProb(x, y, yerr, device=dev_index)
+        lp = LogProb(x, y, yerr, device=c.dev_index)
         truth = torch.tensor(TRUTH[grb], dtype=torch.float64, device=dev)
         n_obs_desc = int(x.size)
     props = truth + a.spread * torch.randn(total, n_global, 6, dtype=torch.float64, device=dev, generator=gen)
     lo, hi, per = shard_range(n_global, rank, world)
     n_local = hi - lo
     ds_local = ds_global[lo:hi].contiguous() if ds_global is not None else None
-    ltot = torch.empty(n_local, 10001, dtype=torch.float64, device=dev) if a.curve else None
+    ltot = torch.empty(n_local, 10001, dtype=torch.float64, device=dev) if curve else None
     status = torch.zeros(max(n_local, 1), dtype=torch.int32, device=dev)
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(total)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(total)]
@@ -242,7 +283,7 @@ def main():
         i = step_idx[0]
         if out is None:
             out = torch.empty(p.shape[0], dtype=torch.float64, device=dev)
-        timed = i % EVENT_EVERY == 0 or i == a.warmup      # HIP events around every 4th launch: each pair costs ~2 us of stream time
+        timed = i % EVENT_EVERY == 0 or i == warmup       # HIP events around every 4th launch: each pair costs ~2 us of stream time
         if timed:
             ev0[i].record(stream)
         launch(p, out, ds_local, status)
@@ -250,13 +291,7 @@ def main():
             ev1[i].record(stream)
         return out
 
-    if world == 1 and a.always_gather:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     sharded = ShardedLnprob(eval_local, via_host=(a.backend == "gloo"), writes_out=True, always_gather=a.always_gather)
-    checksum = torch.zeros((), dtype=torch.float64, device=dev)
-
     # every pass keeps its full lnprob vector: the check sum over all of them is taken after the timed region (the hot
     # path of an ensemble loop does not reduce its log-posteriors; a per-pass reduction would only delay the next launch)
     results = torch.empty(total, per * world, dtype=torch.float64, device=dev)
@@ -283,37 +318,199 @@ def main():
             full = sharded.finish(pending)
         return full
 
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    if n_local > 0 and a.spin_up > 0:                           # bring the clocks up (untimed, before the warmup steps)
+    if n_local > 0 and spin_up > 0:                             # bring the clocks up (untimed, before the warmup steps)
         spin_out = torch.empty(n_local, dtype=torch.float64, device=dev)
-        for _ in range(a.spin_up):
+        for _ in range(spin_up):
             launch(props[0][lo:hi], spin_out, ds_local, status)
         torch.cuda.synchronize(dev)
-    loop(0, a.warmup)                                          # same ops as the timed loop (lazy kernel loads happen here)
-    fence()
+    loop(0, warmup)                                            # same ops as the timed loop (lazy kernel loads happen here)
+    c.fence()
     t0 = time.perf_counter()
-    full = loop(a.warmup, total)
+    full = loop(warmup, total)
     t_host = time.perf_counter() - t0                           # host-side enqueue time (diagnostic)
-    fence()
+    c.fence()
     dt = time.perf_counter() - t0
-    checksum += results[a.warmup:total, :n_global].sum()        # all timed passes, after the clock has stopped
+    checksum = float(results[warmup:total, :n_global].sum().item())   # all timed passes, after the clock has stopped
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
-    kern_ms = np.array([ev0[i].elapsed_time(ev1[i]) for i in range(a.warmup, total) if i % EVENT_EVERY == 0 or i == a.warmup])
-    n_flag = int((status[:n_local] != 0).sum().item())
-    first = float(full[0].item())
+    kern_ms = np.array([ev0[i].elapsed_time(ev1[i]) for i in range(warmup, total) if i % EVENT_EVERY == 0 or i == warmup])
+    n_simd = lp.handle.n_simd
+    pc = 2 * n_local <= n_simd and not curve
+    variant = ("curve kernel, " if curve else "") + ("producer/consumer pair of wavefronts" if pc
+                                                      else "4 steps per lane" if n_local <= n_simd else "2 steps per lane")
+    if config == 5:
+        workload = (f"BASELINE config 5: four GRB types x {n_global // 4} walkers at truth+{a.spread:g}*randn, {len(n_obs_desc)} light "
+                    f"curves of {n_obs_desc} points selected per walker, {n_global} walkers in one launch per pass")
+    else:
+        workload = (f"BASELINE config {config}: {grb} synthetic dataset (N_obs=50), {n_local} walkers per GPU "
+                    f"({n_global} walkers total), walkers at truth+{a.spread:g}*randn")
+    workload += f", 10001-point grid, mode {'B (lnprob + model light curve written to HBM)' if curve else 'A (lnprob only)'}"
+    kavg = float(kern_ms.mean()) * 1e-3
+    bytes_eval = BYTES_PER_EVAL_A + (BYTES_LTOT if curve else 0)
+    achieved = bytes_eval * n_local / kavg / 1e9
+    fig = c.pmc.get("curve" if curve else ("config5" if config == 5 else "lnprob"), {}).get(str(n_local), {})
+    traffic, flops = fig.get("traffic_bytes"), fig.get("fp64_flops")
+    res = {
+        "value": n_global * steps / dt, "ms_per_step": 1e3 * dt / steps, "steps": steps, "warmup": warmup, "scaling": scaling,
+        "workload": workload, "baseline_config": config, "n_walk_per_gpu": n_local, "n_walk_total": n_global,
+        "n_obs": n_obs_desc, "kernel_variant": variant, "sweep_tol": lp.handle.sweep_tol,
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "kernel": "mp::lnprob_pc_kernel" if pc else "mp::lnprob_kernel",
+                     "kernel_ms_avg": 1e3 * kavg, "kernel_ms_min": float(kern_ms.min()),
+                     "algorithmic_bytes_per_eval": bytes_eval, "evals_per_launch": n_local,
+                     "note": "latency-bound fp64 VALU recurrence: neither HBM nor MFMA binds; see valu"},
+        "valu": {"bound": "fp64 VALU issue", "unit": "TFLOP/s", "fp64_flops_per_launch_pmc": flops,
+                 "achieved": None if flops is None else flops / kavg / 1e12, "peak": FP64_VALU_PEAK_TFLOPS,
+                 "frac": None if flops is None else flops / kavg / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                 "note": "flops executed = 64 x (2 FMA + MUL + ADD) fp64 instructions counted by rocprofv3 PMC for this "
+                         "launch size (profiles/pmc_figures.json) / kernel time measured here"},
+        "kernel_evals_per_sec_per_gpu": n_local / kavg, "host_enqueue_ms_per_step": 1e3 * t_host / steps,
+        "check": {"lnprob0": float(full[0].item()), "n_not_ok": int((status[:n_local] != 0).sum().item()), "checksum": checksum},
+    }
+    c.last = {"lp": lp, "props": props, "launch": launch, "stream": stream, "truth": truth, "gen": gen, "x": x, "y": y,
+              "yerr": yerr, "grb": grb, "n_global": n_global, "n_local": n_local, "lo": lo, "hi": hi, "status": status}
+    return res
+
+
+def brief(r):
+    """A sub-leg as it appears under `configs`."""
+    return {k: r[k] for k in ("value", "ms_per_step", "steps", "scaling", "workload", "n_walk_per_gpu", "n_walk_total",
+                              "kernel_variant", "kernel_evals_per_sec_per_gpu")} | {
+        "kernel_ms_avg": r["roofline"]["kernel_ms_avg"],
+        "roofline": {k: r["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel",
+                                                   "algorithmic_bytes_per_eval")},
+        "valu": {k: r["valu"][k] for k in ("achieved", "peak", "frac", "fp64_flops_per_launch_pmc")},
+        "n_not_ok": r["check"]["n_not_ok"]}
+
+
+def main():
+    # The contract is ONE JSON line on stdout.  Native libraries write banners there too (RCCL prints its version block
+    # on stdout when a communicator is created), so everything but the result line is sent to stderr at fd level.
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5], help="BASELINE.json workload (see the docstring)")
+    ap.add_argument("--nwalk", type=int, default=None, help="walkers per GPU (overrides the preset; weak scaling)")
+    ap.add_argument("--grb", default=None, choices=list(TRUTH))
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
+                    help="strong: the preset's walkers are the TOTAL (8 192 for --config 2) and are sharded over the GPUs")
+    ap.add_argument("--curve", action="store_true", help="mode B: also write the model light curve to HBM")
+    ap.add_argument("--spread", type=float, default=1.0e-4, help="walkers at truth + spread*randn (synth_mcmc.py:175-176)")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--seed", type=int, default=20261003)
+    ap.add_argument("--spin-up", type=int, default=300,
+                    help="untimed launches before the W warmup steps: the CPU-baseline leg leaves the GPU idle for ~15 s and "
+                         "the first few dozen launches after that run at idle clocks (a 20-step timed region read 8 %% low)")
+    ap.add_argument("--no-mcmc", action="store_true", help="skip the ensemble-sampler leg")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="skip the prior-wide / burnt-in kernel timings, the golden check, the other configs and the sustained leg")
+    ap.add_argument("--mcmc-steps", type=int, default=100)
+    ap.add_argument("--sustained-seconds", type=float, default=2.0)
+    ap.add_argument("--overlap", type=int, default=1, choices=[0, 1],
+                    help="1: the all-gather of one pass overlaps the next pass's kernel (independent batches); 0: serialised")
+    ap.add_argument("--always-gather", action="store_true",
+                    help="diagnostic: run the RCCL all-gather even at N=1 (group of one) to time the collective path")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend; gloo is for rehearsing N>1 on a one-GPU box (ranks share the card, "
+                         "rows are gathered through host memory) and is never a reported configuration")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher check: every rank joins the process group over gloo, all-reduces a one and rank 0 prints "
+                         "{\"dry_run\": true, \"ranks_seen\": N}; no GPU work (runs on a box without a GPU)")
+    a = ap.parse_args()
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a.gpus, sys.argv[1:]))            # before anything here has touched the GPU
+
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    a.gpus = world                                              # under a launcher the launcher's world size rules
+
+    if a.dry_run:
+        import torch
+        import torch.distributed as dist
+        if os.environ.get("MAGPROP_BENCH_FAIL_RANK") == str(rank):
+            sys.exit(7)                                         # test hook: a rank that dies before the rendezvous
+        seen = 1
+        if world > 1:
+            dist.init_process_group("gloo")
+            t = torch.ones(1)
+            dist.all_reduce(t)
+            seen = int(t.item())
+            dist.destroy_process_group()
+        if rank == 0:
+            json_out.write(json.dumps({"dry_run": True, "n_gpus": world, "ranks_seen": seen}) + "\n")
+            json_out.flush()
+        return
+
+    scaling = a.scaling or ("strong" if a.config in (4, 5) else "weak")
+    grb = a.grb or {2: "Humped", 3: "Classic", 4: "Humped", 5: "Humped"}[a.config]
+    headline = a.config == 2 and not a.curve and a.nwalk is None and a.scaling is None   # the driver's invocation
+    cpu = c1 = p0_c1 = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(grb, a.cpu_seconds, a.seed)          # before any GPU initialisation (forks)
+        if headline and not a.no_extra:
+            p0_c1, c1 = config1_cpu(a.seed)
+
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    n_dev = torch.cuda.device_count()
+    if world > 1 and a.backend == "nccl" and n_dev < world:
+        sys.exit(f"bench.py --gpus {world}: only {n_dev} GPU(s) visible (RCCL needs one per rank; --backend gloo rehearses on fewer)")
+    c = Ctx()
+    c.a, c.rank, c.world = a, rank, world
+    c.dev_index = local_rank % n_dev                            # == local_rank except in the gloo rehearsal
+    torch.cuda.set_device(c.dev_index)
+    c.dev = dev = torch.device("cuda", c.dev_index)
+    ranks_seen = 1
+    if world > 1:
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)       # RCCL over xGMI
+        else:
+            dist.init_process_group("gloo")
+        ones = torch.ones(1, dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
+        dist.all_reduce(ones)                                   # the collective path really spans `world` ranks
+        ranks_seen = int(ones.item())
+    elif a.always_gather:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+    c.fence = fence
+    c.g = g = np.load(os.path.join(ROOT, "tests", "golden", "golden_synth.npz"))
+    try:
+        c.pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_figures.json")))   # from the committed rocprofv3 PMC summaries
+    except Exception:  # noqa: BLE001
+        c.pmc = {}
+
+    from magprop_amd import EnsembleSampler
+    from magprop_amd.distributed import DistributedEnsembleSampler, HipShardEngine
+
+    # ---- the headline leg (the contract's timed region)
+    main_leg = run_passes(c, a.config, scaling, a.steps, a.warmup, curve=a.curve, nwalk=a.nwalk, grb=a.grb, spin_up=a.spin_up)
+    L = c.last
+    lp, launch, stream, truth, gen = L["lp"], L["launch"], L["stream"], L["truth"], L["gen"]
+    x, y, yerr, n_global = L["x"], L["y"], L["yerr"], L["n_global"]
 
     # ---- the same metric through the device-resident ensemble sampler: walkers x steps / s
     mcmc = None
     if not a.no_mcmc and a.config != 5 and n_global % 2 == 0:
         p0 = (truth + 1.0e-4 * torch.randn(n_global, 6, dtype=torch.float64, device=dev, generator=gen)).cpu().numpy()
-        es = EnsembleSampler(n_global, 6, x, y, yerr, seed=a.seed, device=dev_index)
+        es = EnsembleSampler(n_global, 6, x, y, yerr, seed=a.seed, device=c.dev_index)
         if world == 1:
             es.run_mcmc(p0, 5, store=False)
             tm = time.perf_counter()
@@ -340,100 +537,138 @@ def main():
                 "ms_per_step": 1e3 * tm / a.mcmc_steps, "acceptance_fraction": acc, "note": note}
         es.close()
 
-    # ---- N = 1 extras: harder inputs for the same kernel, and the reference's golden walkers
-    extra = None
+    # ---- N = 1 extras: harder inputs for the same kernel, the reference's golden walkers, sustained run, config 1
+    extra = golden = sustained = None
     if world == 1 and not a.no_extra and a.config != 5 and not a.curve:
-        def time_kernel(P_np, reps=24):
+        def time_kernel(P_np, reps=48):
+            """Same sampling as the timed loop: HIP events around every EVENT_EVERY-th of `reps` back-to-back launches."""
             P = torch.from_numpy(np.ascontiguousarray(P_np)).to(dev)
             out = torch.empty(P.shape[0], dtype=torch.float64, device=dev)
             st = torch.empty(P.shape[0], dtype=torch.int32, device=dev)
-            e0 = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
-            e1 = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
+            idx = [r for r in range(reps) if r % EVENT_EVERY == 0]
+            e0 = {r: torch.cuda.Event(enable_timing=True) for r in idx}
+            e1 = {r: torch.cuda.Event(enable_timing=True) for r in idx}
             for _ in range(3):
                 launch(P, out, None, st)
             for r in range(reps):
-                e0[r].record(stream)
+                if r in e0:
+                    e0[r].record(stream)
                 launch(P, out, None, st)
-                e1[r].record(stream)
+                if r in e0:
+                    e1[r].record(stream)
             torch.cuda.synchronize(dev)
-            ms = float(np.mean([e0[r].elapsed_time(e1[r]) for r in range(reps)]))
+            ms = float(np.mean([e0[r].elapsed_time(e1[r]) for r in idx]))
             lp.handle.lnprob_batch(P_np)                                        # host entry: records the sweeps per tile
             return {"kernel_ms": ms, "evals_per_sec": P.shape[0] / ms * 1e3, "sweeps_per_tile": lp.handle.last_mean_sweeps,
                     "not_ok": int((st != 0).sum().item())}
         rngx = np.random.default_rng(a.seed + 1)
         wide = PRIOR_LOWER + (PRIOR_UPPER - PRIOR_LOWER) * rngx.random((n_global, 6))
-        es = EnsembleSampler(n_global, 6, x, y, yerr, seed=a.seed + 2, device=dev_index)
+        es = EnsembleSampler(n_global, 6, x, y, yerr, seed=a.seed + 2, device=c.dev_index)
         burnt = es.run_mcmc(np.array(TRUTH[grb]) + 1.0e-4 * rngx.standard_normal((n_global, 6)), 500, store=False)
         es.close()
-        near = props[a.warmup].cpu().numpy()
-        extra = {"near_truth": time_kernel(near), "prior_wide": time_kernel(wide), "burnt_in_500_steps": time_kernel(burnt)}
+        near = L["props"][a.warmup].cpu().numpy()
+        extra = {"near_truth": time_kernel(near), "prior_wide": time_kernel(wide), "burnt_in_500_steps": time_kernel(burnt),
+                 "note": "HIP events around every 4th of 48 back-to-back launches, as in the timed loop (roofline.kernel_ms_avg)"}
         Pg, tight, ref = g[grb + "_pars"], g[grb + "_lnprob_tight"], g[grb + "_lnprob"]
+        noise = g[grb + "_lsoda_noise_idx"] if grb + "_lsoda_noise_idx" in g else np.zeros(0, dtype=int)
         og = lp(Pg)
         fin = np.isfinite(tight)
+        plain = fin.copy()
+        plain[noise] = False                                    # enumerated LSODA-noise points: judged against the tight run only
         golden = {"walkers": int(len(Pg)), "status_agrees": bool(np.array_equal(np.isfinite(og), np.isfinite(ref))),
                   "max_rel_dev_vs_reference_tight_lsoda": float(np.max(np.abs(og[fin] - tight[fin]) / np.abs(tight[fin]))),
-                  "max_rel_dev_vs_reference_default_lsoda": float(np.max(np.abs(og[fin] - ref[fin]) / np.abs(ref[fin]))),
-                  "tolerance": "1e-7 + 1e-7|ref| (tight), 1e-5 + 2e-5|ref| (default LSODA noise)",
-                  "pass": bool(np.all(np.abs(og[fin] - tight[fin]) <= 1e-7 + 1e-7 * np.abs(tight[fin])))}
+                  "max_rel_dev_vs_reference_default_lsoda": float(np.max(np.abs(og[plain] - ref[plain]) / np.abs(ref[plain]))),
+                  "lsoda_noise_points": int(len(noise)),
+                  "tolerance": f"{TIGHT_ATOL:g} + {TIGHT_RTOL:g}|ref| (tight LSODA, every point), {REF_ATOL:g} + {REF_RTOL:g}|ref| "
+                               "(default LSODA, every point but the enumerated LSODA-noise ones)",
+                  "pass": bool(np.all(np.abs(og[fin] - tight[fin]) <= TIGHT_ATOL + TIGHT_RTOL * np.abs(tight[fin])) and
+                               np.all(np.abs(og[plain] - ref[plain]) <= REF_ATOL + REF_RTOL * np.abs(ref[plain])))}
+        if headline and a.sustained_seconds > 0:
+            props, n_local = L["props"], L["n_local"]
+            per_pass = main_leg["roofline"]["kernel_ms_avg"] * 1e-3
+            n_pass = int(a.sustained_seconds * 1.05 / per_pass) + 1
+            outs = torch.empty(8, n_local, dtype=torch.float64, device=dev)
+            clk0 = read_sclk_mhz()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for i in range(n_pass):
+                launch(props[i % props.shape[0]], outs[i % 8], None, L["status"])
+            t_enq = time.perf_counter() - t0
+            clk1 = read_sclk_mhz()                               # the queue still holds most of the passes here
+            torch.cuda.synchronize(dev)
+            dts = time.perf_counter() - t0
+            clk2 = read_sclk_mhz()
+            sustained = {"seconds": dts, "passes": n_pass, "evals_per_sec": n_pass * n_local / dts, "ms_per_pass": 1e3 * dts / n_pass,
+                         "host_enqueue_seconds": t_enq, "sclk_mhz": {"before": clk0, "during": clk1, "after": clk2},
+                         "what": f"{n_pass} back-to-back passes of the headline workload ({n_local} walkers), no events, one "
+                                 "synchronisation at the end"}
+    config1 = None
+    if world == 1 and headline and not a.no_extra:
+        rng1 = np.random.default_rng(a.seed + 24)
+        p0 = p0_c1 if p0_c1 is not None else np.array(TRUTH["Humped"]) + 1.0e-4 * rng1.standard_normal((24, 6))
+        es = EnsembleSampler(24, 6, g["Humped_x"], g["Humped_y"], g["Humped_yerr"], seed=a.seed, device=c.dev_index)
+        es.run_mcmc(p0, 2, store=False)                         # first launches of this batch size
+        t0 = time.perf_counter()
+        es.run_mcmc(p0, 50, store=True)
+        dth = time.perf_counter() - t0
+        config1 = {"hip_sampler": {"seconds": dth, "evals": 24 * 51, "evals_per_sec": 24 * 51 / dth,
+                                   "acceptance_fraction": float(es.acceptance_fraction.mean()),
+                                   "what": "magprop_amd.EnsembleSampler(24, 6).run_mcmc(p0, 50) with the chain copied back to the host"},
+                   "cpu_port": c1, "workload": "BASELINE configs[0]: Humped, N_walk=24, N_step=50 (1 224 evaluations)"}
+        es.close()
+
+    # ---- the other BASELINE workloads through the same loop
+    configs = None
+    if headline and not a.no_extra:
+        ss, sw, su = min(a.steps, 40), min(a.warmup, 5), min(a.spin_up, 60)
+
+        def sub(config, scal, **kw):
+            r = brief(run_passes(c, config, scal, ss, sw, spin_up=su, **kw))
+            c.last["lp"].handle.close()                         # the leg's handle (stream, grid, datasets) is not needed again
+            c.last = None
+            return r
+        if world == 1:
+            configs = {"3": sub(3, "weak"), "4_one_gpu": sub(4, "strong"), "5": sub(5, "strong"),
+                       "curve": sub(2, "weak", curve=True)}
+        else:
+            configs = {"4_strong": sub(4, "strong"), "5_strong": sub(5, "strong")}
 
     if rank == 0:
-        evals = n_global * a.steps
-        value = evals / dt
-        kavg = float(kern_ms.mean()) * 1e-3
-        bytes_eval = BYTES_PER_EVAL_A + (BYTES_LTOT if a.curve else 0)
-        achieved = bytes_eval * n_local / kavg / 1e9
-        traffic = flops_launch = None
-        fig_key = "curve" if a.curve else ("config5" if a.config == 5 else "lnprob")
-        tf = os.path.join(ROOT, "profiles", "pmc_figures.json")     # from the committed rocprofv3 PMC summaries
-        if os.path.exists(tf):
-            try:
-                fig = json.load(open(tf)).get(fig_key, {}).get(str(n_local), {})
-                traffic, flops_launch = fig.get("traffic_bytes"), fig.get("fp64_flops")
-            except Exception:  # noqa: BLE001
-                traffic = flops_launch = None
-        n_simd = lp.handle.n_simd
-        variant = ("curve kernel, " if a.curve else "") + ("producer/consumer pair of wavefronts" if (2 * n_local <= n_simd and not a.curve)
-                                                            else "4 steps per lane" if n_local <= n_simd else "2 steps per lane")
-        if a.config == 5:
-            workload = (f"BASELINE config 5: four GRB types x {n_global // 4} walkers at truth+{a.spread:g}*randn, eleven light curves "
-                        f"of {n_obs_desc} points selected per walker, {n_global} walkers in one launch per pass")
+        r = main_leg
+        if world == 1:
+            par = "single GPU, no collective (one process, one launch per pass)"
         else:
-            workload = (f"BASELINE config {a.config}: {grb} synthetic dataset (N_obs=50), {n_local} walkers per GPU "
-                        f"({n_global} walkers total), walkers at truth+{a.spread:g}*randn")
-        workload += f", 10001-point grid, mode {'B (lnprob + model light curve written to HBM)' if a.curve else 'A (lnprob only)'}"
+            par = (f"walker-shard x{world} + {'RCCL' if a.backend == 'nccl' else 'gloo (rehearsal)'} all-gather(lnprob)" +
+                   (", gather of pass i overlapped with kernel of pass i+1" if a.overlap else ""))
+        if world == 1 and a.always_gather:
+            par = "single GPU + RCCL all-gather(lnprob) in a group of one (diagnostic)"
         out = {
-            "metric": "walker_lnprob_evals_per_sec", "value": value, "unit": "evals/s", "n_gpus": world,
-            "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
+            "metric": "walker_lnprob_evals_per_sec", "value": r["value"], "unit": "evals/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": r["ms_per_step"], "higher_is_better": True,
             "scaling": scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": workload, "baseline_config": a.config,
-                       "n_walk_per_gpu": n_local, "n_walk_total": n_global, "n_grid": 10001, "n_obs": n_obs_desc,
-                       "variant": "synth", "kernel_variant": variant, "sweep_tol": lp.handle.sweep_tol,
-                       "parallelism": f"walker-shard x{world} + {'RCCL' if a.backend == 'nccl' else 'gloo (rehearsal)'} all-gather(lnprob)" + (", gather of pass i overlapped with kernel of pass i+1" if (world > 1 and a.overlap) else "")},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "mp::lnprob_kernel" if (a.curve or 2 * n_local > n_simd) else "mp::lnprob_pc_kernel",
-                         "kernel_ms_avg": 1e3 * kavg, "kernel_ms_min": float(kern_ms.min()),
-                         "algorithmic_bytes_per_eval": bytes_eval, "evals_per_launch": n_local,
-                         "note": "latency-bound fp64 VALU recurrence: neither HBM nor MFMA binds; see valu"},
-            "valu": {"bound": "fp64 VALU issue", "unit": "TFLOP/s",
-                     "fp64_flops_per_launch_pmc": flops_launch,
-                     "achieved": None if flops_launch is None else flops_launch / kavg / 1e12,
-                     "peak": FP64_VALU_PEAK_TFLOPS,
-                     "frac": None if flops_launch is None else flops_launch / kavg / 1e12 / FP64_VALU_PEAK_TFLOPS,
-                     "note": "flops executed = 64 x (2 FMA + MUL + ADD) fp64 instructions counted by rocprofv3 PMC for this "
-                             "launch size (profiles/pmc_figures.json) / kernel time measured here"},
-            "kernel_evals_per_sec_per_gpu": n_local / kavg, "spin_up_launches": a.spin_up,
-            "host_enqueue_ms_per_step": 1e3 * t_host / a.steps,
-            "check": {"lnprob0": first, "n_not_ok": n_flag, "checksum": float(checksum.item())},
+            "config": {"workload": r["workload"], "baseline_config": a.config,
+                       "n_walk_per_gpu": r["n_walk_per_gpu"], "n_walk_total": r["n_walk_total"], "n_grid": 10001,
+                       "n_obs": r["n_obs"], "variant": "synth", "kernel_variant": r["kernel_variant"],
+                       "sweep_tol": r["sweep_tol"], "parallelism": par},
+            "roofline": r["roofline"], "valu": r["valu"],
+            "kernel_evals_per_sec_per_gpu": r["kernel_evals_per_sec_per_gpu"], "spin_up_launches": a.spin_up,
+            "host_enqueue_ms_per_step": r["host_enqueue_ms_per_step"], "ranks_seen": ranks_seen,
+            "check": r["check"],
         }
         if extra is not None:
             out["kernel_ms"] = extra
             out["check"]["golden"] = golden
+        if sustained is not None:
+            out["sustained"] = sustained
+        if configs is not None:
+            out["configs"] = configs
+        if config1 is not None:
+            out["config1"] = config1
         if mcmc is not None:
             out["ensemble_sampler"] = mcmc
         if cpu is not None:
             out["cpu_baseline"] = cpu
-            out["speedup_vs_cpu_baseline"] = value / cpu["value"]
+            out["speedup_vs_cpu_baseline"] = r["value"] / cpu["value"]
         json_out.write(json.dumps(out) + "\n")
         json_out.flush()
     if world > 1:

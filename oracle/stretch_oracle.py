@@ -11,7 +11,8 @@ requirements.txt:4); its published algorithm (Goodman & Weare 2010; emcee's RedB
 
 The product's fused HIP kernel uses Philox4x32-10 streams keyed by (seed; step, half, walker); this file uses
 the same generator so that, for a target both sides compute identically (the isotropic unit Gaussian test
-target), the chains agree bit for bit.  Only tests/ may import this module.
+target), the chains agree bit for bit.  Only tests/ and the CPU-baseline legs of bench.py (config 1 timed on the host cores) may
+import this module.
 """
 import numpy as np
 
@@ -92,14 +93,49 @@ def run(pos, n_steps, seed, a=2.0, lnprob_fn=gaussian_lnprob, n_ensembles=1):
     return chain, chain_lnp, acc
 
 
+def run_batched(pos, n_steps, seed, a=2.0, batch_fn=None, n_ensembles=1):
+    """`run` with the log-posteriors of a half-step evaluated in ONE call, batch_fn(proposals[m, ndim]) -> m values
+    (the proposals of a half only read the other half, so the chain is the one `run` produces): what emcee does with
+    a pool (code/synthetic_datasets/synth_mcmc.py:178-185).  Returns chain, chain_lnp, n_accepted."""
+    pos = np.array(pos, dtype=np.float64)
+    n_total, ndim = pos.shape
+    n = n_total // n_ensembles
+    half_n = n // 2
+    lnp = np.array(batch_fn(pos), dtype=np.float64)
+    acc = np.zeros(n_total, dtype=np.int64)
+    chain = np.empty((n_steps, n_total, ndim))
+    chain_lnp = np.empty((n_steps, n_total))
+    for step in range(n_steps):
+        perms = [split(seed, step, e, n) for e in range(n_ensembles)]
+        for half in range(2):
+            rows = halfstep_rows(pos, lnp, perms, seed, step, half, 0, half_n * n_ensembles, n, a, lnprob_fn=None,
+                                 batch_fn=batch_fn)
+            apply_rows(pos, lnp, acc, perms, half, rows, n, chain[step], chain_lnp[step])
+    return chain, chain_lnp, acc
+
+
 # ---------------------------------------------------------------- the walker-sharded protocol (include/magprop_amd.h:
 # mp_sampler_halfstep_shard / mp_sampler_halfstep_apply), restated on numpy arrays
-def halfstep_rows(pos, lnp, perms, seed, step, half, lo, hi, n, a=2.0, lnprob_fn=gaussian_lnprob):
+def halfstep_rows(pos, lnp, perms, seed, step, half, lo, hi, n, a=2.0, lnprob_fn=gaussian_lnprob, batch_fn=None):
     """Outcome rows (proposal, lnprob, accepted, status) of slots [lo, hi) of the active half, all ensembles flattened;
-    `perms[e]` = this step's split of ensemble e (n walkers each).  Reads pos / lnp, changes nothing."""
+    `perms[e]` = this step's split of ensemble e (n walkers each).  Reads pos / lnp, changes nothing.
+    batch_fn(proposals) evaluates all the slots' proposals in one call instead of lnprob_fn one by one."""
     ndim = pos.shape[1]
     half_n = n // 2
     rows = np.zeros((hi - lo, ndim + 3))
+    new_all = None
+    if batch_fn is not None:
+        props = np.empty((hi - lo, ndim))
+        for gs in range(lo, hi):
+            e, slot = divmod(gs, half_n)
+            base, perm = e * n, perms[e]
+            k = base + perm[half * half_n + slot]
+            r = philox4x32_10(seed & M32, seed >> 32, step, half, k, 0)
+            n_comp = n - half_n
+            j = base + perm[(1 - half) * half_n + min(int(u01(r[0], r[1]) * n_comp), n_comp - 1)]
+            zr = (a - 1.0) * u01(r[2], r[3]) + 1.0
+            props[gs - lo] = pos[j] - (pos[j] - pos[k]) * (zr * zr / a)
+        new_all = np.asarray(batch_fn(props), dtype=np.float64)
     for gs in range(lo, hi):
         e, slot = divmod(gs, half_n)
         base, perm = e * n, perms[e]
@@ -112,7 +148,7 @@ def halfstep_rows(pos, lnp, perms, seed, step, half, lo, hi, n, a=2.0, lnprob_fn
         zr = (a - 1.0) * u01(r[2], r[3]) + 1.0
         zz = zr * zr / a
         prop = pos[j] - (pos[j] - pos[k]) * zz
-        new = lnprob_fn(prop)
+        new = lnprob_fn(prop) if new_all is None else new_all[gs - lo]
         lnpdiff = (ndim - 1.0) * np.log(zz) + new - lnp[k]
         with np.errstate(divide="ignore"):
             accept = lnpdiff > np.log(u01(r2[0], r2[1]))

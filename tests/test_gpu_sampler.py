@@ -4,7 +4,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import TRUTHS, TYPES
+from conftest import ROOT, TRUTHS, TYPES
 
 pytestmark = pytest.mark.gpu
 
@@ -345,3 +345,27 @@ def test_sharded_entry_points_in_one_process_and_fbad(gsynth, tmp_path):
     lp_ = LogProb(x, y, yerr)
     out, st = lp_.handle.lnprob_batch(rows, want_status=True)
     assert np.all((st == 1) | (st == 2)) and np.all(out == -np.inf)
+
+
+def test_bench_self_launch_two_ranks():
+    """`python bench.py --gpus 2 --backend gloo` with no launcher around it: bench.py starts its own two rank processes
+    (they share this box's one card), and rank 0 prints ONE valid line for n_gpus = 2 that carries the sharded-sampler
+    leg and the strong-scaling legs of configs 4 and 5."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "6",
+                        "--warmup", "2", "--spin-up", "10", "--mcmc-steps", "6", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["steps"] == 6 and d["scaling"] == "weak"
+    assert d["config"]["n_walk_total"] == 2048 and d["config"]["n_walk_per_gpu"] == 1024
+    assert d["value"] > 0 and d["check"]["n_not_ok"] == 0
+    assert d["ensemble_sampler"]["walkers"] == 2048 and 0.2 < d["ensemble_sampler"]["acceptance_fraction"] < 0.8
+    assert d["configs"]["4_strong"]["n_walk_total"] == 8192 and d["configs"]["4_strong"]["n_walk_per_gpu"] == 4096
+    assert d["configs"]["5_strong"]["n_walk_total"] == 4096 and d["configs"]["5_strong"]["n_not_ok"] == 0
+    assert "gloo" in d["config"]["parallelism"]
