@@ -53,7 +53,7 @@
 extern "C" {
 #endif
 
-#define MP_ABI_VERSION 2
+#define MP_ABI_VERSION 3
 
 /* return codes */
 #define MP_OK 0
@@ -69,6 +69,9 @@ extern "C" {
 #define MP_STATUS_FLAG 1      /* break-up limit reached: the reference's LSODA 'flag'   */
 #define MP_STATUS_NONFINITE 2 /* state or chi^2 went non-finite                         */
 #define MP_STATUS_PRIOR 3     /* outside the prior box, model never evaluated           */
+#define MP_STATUS_BADDATASET 4 /* ds_id names no registered light curve (out of range or never set): lnprob = -inf.  The   */
+                              /* host-buffer entry rejects such a batch with MP_EINVAL; the device-pointer entries cannot */
+                              /* read the ids and report it per walker instead                                            */
 
 /* limits */
 #define MP_MAX_NDIM 9        /* 6 physics parameters + up to dipeff, propeff, f_beam */
@@ -125,6 +128,8 @@ int mp_destroy(mp_handle *h);
  * Register (or replace) observed light curve `ds_id` (0 <= ds_id < MP_MAX_DATASETS):
  * x = times [s], y = luminosity [1e50 erg/s], yerr = 1-sigma errors; host pointers.
  * Returns MP_ERANGE if any x lies outside [tgrid[0], tgrid[n_grid-1]].
+ * Registering a NEW slot appends to the device-resident arrays (only the new light curve is uploaded, nothing waits
+ * for the device unless the arrays have to grow); REPLACING a slot waits for the device first.
  */
 int mp_set_dataset(mp_handle *h, int ds_id, const double *x, const double *y, const double *yerr, int n_obs);
 
@@ -201,11 +206,15 @@ int mp_sampler_run(mp_sampler *s, int n_steps, double *chain, double *chain_lnpr
 int mp_sampler_get_state(mp_sampler *s, double *pos, double *lnprob, int64_t *n_accepted, int64_t *steps_done);
 /*
  * Proposals inside the prior whose model evaluation failed ('flag' / non-finite): what the reference's lnprob appends
- * to its `fbad` file (code/synthetic_datasets/mcmc_eqns.py:72-79).  *n_bad = how many there were since the sampler was
- * created; up to max_rows of the first 4096 are copied to pars[max_rows][ndim] (sampler coordinates).  Returns the
- * number of rows copied (>= 0) or a negative MP_E* code.
+ * to its `fbad` file (code/synthetic_datasets/mcmc_eqns.py:72-79).  The kernels collect them in a device-side window of
+ * MP_BAD_WINDOW rows which the library drains into a host-side log (after every chunk of mp_sampler_run and in this
+ * call), so the log holds every failed proposal unless more than MP_BAD_WINDOW of them arrive between two drains.
+ * *n_bad = how many there were since the sampler was created (exact); *n_logged (optional) = rows in the log;
+ * rows [first_row, first_row + max_rows) of the log are copied to pars[max_rows][ndim] (sampler coordinates).
+ * Returns the number of rows copied (>= 0) or a negative MP_E* code.
  */
-int mp_sampler_get_bad(mp_sampler *s, double *pars, int max_rows, int64_t *n_bad);
+#define MP_BAD_WINDOW 65536
+int mp_sampler_get_bad(mp_sampler *s, int64_t first_row, double *pars, int max_rows, int64_t *n_bad, int64_t *n_logged);
 
 /*
  * Walker-sharded ensembles (one process per GPU; the reference's counterpart is emcee's pool.map over

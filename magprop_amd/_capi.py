@@ -15,7 +15,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MAGPROP_AMD_LIB") or os.path.join(_PKG, "libmagprop_amd.so")  # override: A/B builds
 
 MP_OK, MP_EINVAL, MP_EHIP, MP_ERANGE, MP_ENODEV, MP_ESTATE = 0, -1, -2, -3, -4, -5
-STATUS_OK, STATUS_FLAG, STATUS_NONFINITE, STATUS_PRIOR = 0, 1, 2, 3
+STATUS_OK, STATUS_FLAG, STATUS_NONFINITE, STATUS_PRIOR, STATUS_BADDATASET = 0, 1, 2, 3, 4
 MAX_NDIM = 9
 MAX_DATASETS = 64
 
@@ -27,7 +27,7 @@ EXPORTS = (
     "mp_sampler_get_bad", "mp_sampler_n_slots", "mp_sampler_row_doubles", "mp_sampler_halfstep_shard",
     "mp_sampler_halfstep_apply", "mp_sampler_state_ptrs", "mp_sweep_tol", "mp_n_simd", "mp_last_sweeps",
 )
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class MagpropAmdError(RuntimeError):
@@ -96,7 +96,16 @@ def lib():
     except OSError as exc:
         raise MagpropAmdError(f"cannot load {LIB_PATH}: {exc}") from exc
     dp, ip, vp = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_void_p
-    L.mp_abi_version.restype = C.c_int
+    # the ABI check comes before any other symbol is touched: a stale build must fail with the rebuild hint, not with an
+    # AttributeError on a symbol it does not have yet
+    try:
+        L.mp_abi_version.restype = C.c_int
+        abi = L.mp_abi_version()
+    except AttributeError:
+        abi = None
+    if abi != ABI_VERSION:
+        raise MagpropAmdError(f"{LIB_PATH} has ABI version {abi}, this binding expects {ABI_VERSION}: "
+                              "rebuild it (python -c 'import __graft_entry__ as g; g.build()')")
     L.mp_last_error.restype = C.c_char_p
     L.mp_cfg_synth.argtypes = [C.POINTER(ModelCfg)]
     L.mp_cfg_synth.restype = None
@@ -130,15 +139,12 @@ def lib():
     L.mp_n_simd.argtypes = [vp]
     L.mp_last_sweeps.argtypes = [vp, ip, C.c_int]
     L.mp_last_sweeps.restype = C.c_int
-    L.mp_sampler_get_bad.argtypes = [vp, dp, C.c_int, i64p]
+    L.mp_sampler_get_bad.argtypes = [vp, C.c_int64, dp, C.c_int, i64p, i64p]
     L.mp_sampler_n_slots.argtypes = [vp]
     L.mp_sampler_row_doubles.argtypes = [vp]
     L.mp_sampler_halfstep_shard.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp]
     L.mp_sampler_halfstep_apply.argtypes = [vp, C.c_int, vp, vp, vp, vp]
     L.mp_sampler_state_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
-    if L.mp_abi_version() != ABI_VERSION:
-        raise MagpropAmdError(f"{LIB_PATH} has ABI version {L.mp_abi_version()}, this binding expects {ABI_VERSION}: "
-                              "rebuild it (python -c 'import __graft_entry__ as g; g.build()')")
     for name in ("mp_destroy", "mp_set_dataset", "mp_set_prior", "mp_lnprob_batch", "mp_lnprob_batch_dev",
                  "mp_model_lc", "mp_rhs_batch", "mp_synchronize", "mp_device", "mp_n_grid", "mp_sampler_destroy",
                  "mp_sampler_set_positions", "mp_sampler_run", "mp_sampler_get_state", "mp_sampler_get_bad",

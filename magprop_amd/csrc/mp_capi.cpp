@@ -114,6 +114,10 @@ struct mp_handle {
     DevBuf<double> d_tgrid, d_obs_dx, d_obs_idt, d_obs_y, d_obs_yerr;
     DevBuf<int32_t> d_obs_g, d_tile_ptr;
     DevBuf<mp::DsDesc> d_ds;
+    // The packed observation arrays are an append-only arena: a new light curve goes behind the last one (obs_used /
+    // tp_used entries are live or stale), a replaced one leaves its old entries behind as garbage until the next rebuild.
+    size_t obs_used = 0, tp_used = 0;
+    std::vector<mp::DsDesc> desc;   // host mirror of d_ds
     // workspace of the host-buffer entry points
     DevBuf<double> w_pars, w_lnprob, w_curves;
     DevBuf<int32_t> w_dsid, w_status, w_sweeps;
@@ -151,46 +155,10 @@ int launch_lnprob_ordered(mp_handle *h, const mp::LaunchArgs &a, hipStream_t st)
 }
 }  // namespace
 
-static int upload_datasets(mp_handle *h) {
-    std::vector<mp::DsDesc> desc(MP_MAX_DATASETS, mp::DsDesc{0, 0, 0, 0});
-    std::vector<int32_t> g, tp;
-    std::vector<double> dx, idt, y, ye;
-    int n_ds = 0;
-    for (int d = 0; d < MP_MAX_DATASETS; ++d) {
-        const HostDataset &s = h->ds[d];
-        if (!s.set) continue;
-        n_ds = d + 1;
-        desc[d].n_obs = (int32_t)s.g.size();
-        desc[d].obs_off = (int32_t)g.size();
-        desc[d].tile_off = (int32_t)tp.size();
-        g.insert(g.end(), s.g.begin(), s.g.end());
-        dx.insert(dx.end(), s.dx.begin(), s.dx.end());
-        idt.insert(idt.end(), s.idt.begin(), s.idt.end());
-        y.insert(y.end(), s.y.begin(), s.y.end());
-        ye.insert(ye.end(), s.yerr.begin(), s.yerr.end());
-        tp.insert(tp.end(), s.tile_ptr.begin(), s.tile_ptr.end());
-    }
-    // unset slots below n_ds point at an empty bucket table so a stray ds_id reads zeros, not garbage
-    const int32_t empty_off = (int32_t)tp.size();
-    tp.insert(tp.end(), (size_t)h->n_tiles + 1, 0);
-    for (int d = 0; d < n_ds; ++d)
-        if (!h->ds[d].set) desc[d].tile_off = empty_off;
-    HIP_TRY(hipDeviceSynchronize());  // nothing in flight may still read the old buffers
-    int rc;
-    if ((rc = h->d_obs_g.ensure(g.size())) || (rc = h->d_obs_dx.ensure(dx.size())) ||
-        (rc = h->d_obs_idt.ensure(idt.size())) || (rc = h->d_obs_y.ensure(y.size())) ||
-        (rc = h->d_obs_yerr.ensure(ye.size())) || (rc = h->d_tile_ptr.ensure(tp.size())) ||
-        (rc = h->d_ds.ensure(desc.size())))
-        return rc;
-    if (!g.empty()) {
-        HIP_TRY(hipMemcpy(h->d_obs_g.p, g.data(), g.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(h->d_obs_dx.p, dx.data(), dx.size() * sizeof(double), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(h->d_obs_idt.p, idt.data(), idt.size() * sizeof(double), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(h->d_obs_y.p, y.data(), y.size() * sizeof(double), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(h->d_obs_yerr.p, ye.data(), ye.size() * sizeof(double), hipMemcpyHostToDevice));
-    }
-    HIP_TRY(hipMemcpy(h->d_tile_ptr.p, tp.data(), tp.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(h->d_ds.p, desc.data(), desc.size() * sizeof(mp::DsDesc), hipMemcpyHostToDevice));
+static void publish_datasets(mp_handle *h) {
+    int n_ds = 0, extra = 0;
+    for (int d = 0; d < MP_MAX_DATASETS; ++d)
+        if (h->ds[d].set) { n_ds = d + 1; extra = std::max(extra, (int)h->ds[d].g.size() - 64); }
     h->sh.ds = h->d_ds.p;
     h->sh.n_ds = n_ds;
     h->sh.tile_ptr = h->d_tile_ptr.p;
@@ -199,9 +167,57 @@ static int upload_datasets(mp_handle *h) {
     h->sh.obs_idt = h->d_obs_idt.p;
     h->sh.obs_y = h->d_obs_y.p;
     h->sh.obs_yerr = h->d_obs_yerr.p;
-    int extra = 0;
-    for (int d = 0; d < n_ds; ++d) extra = std::max(extra, desc[d].n_obs - 64);
     h->sh.scratch_stride = (extra + 63) / 64 * 64;
+}
+
+// Copy light curve d behind the arena's last entry and publish its descriptor (slots never set keep n_obs = 0, which
+// the kernels answer with MP_STATUS_BADDATASET).  Nothing in flight reads the target regions: no synchronisation.
+static int append_dataset(mp_handle *h, int d) {
+    const HostDataset &s = h->ds[d];
+    const size_t n = s.g.size(), o = h->obs_used, t = h->tp_used;
+    HIP_TRY(hipMemcpy(h->d_obs_g.p + o, s.g.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->d_obs_dx.p + o, s.dx.data(), n * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->d_obs_idt.p + o, s.idt.data(), n * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->d_obs_y.p + o, s.y.data(), n * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->d_obs_yerr.p + o, s.yerr.data(), n * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->d_tile_ptr.p + t, s.tile_ptr.data(), s.tile_ptr.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    h->desc[d] = mp::DsDesc{(int32_t)n, (int32_t)o, (int32_t)t, 0};
+    HIP_TRY(hipMemcpy(h->d_ds.p + d, &h->desc[d], sizeof(mp::DsDesc), hipMemcpyHostToDevice));
+    h->obs_used = o + n;
+    h->tp_used = t + s.tile_ptr.size();
+    return MP_OK;
+}
+
+// Rebuild the arena from the host copies (first use, growth, or a replaced slot): waits for the device, because
+// kernels in flight may still read the old buffers, and leaves room for the sets to come.
+static int rebuild_datasets(mp_handle *h) {
+    size_t n_obs = 0, n_tp = 0;
+    for (int d = 0; d < MP_MAX_DATASETS; ++d)
+        if (h->ds[d].set) { n_obs += h->ds[d].g.size(); n_tp += h->ds[d].tile_ptr.size(); }
+    HIP_TRY(hipDeviceSynchronize());
+    const size_t cap_obs = std::max<size_t>(2 * n_obs, 4096), cap_tp = std::max<size_t>(2 * n_tp, 8 * ((size_t)h->n_tiles + 1));
+    int rc;
+    if ((rc = h->d_obs_g.ensure(cap_obs)) || (rc = h->d_obs_dx.ensure(cap_obs)) || (rc = h->d_obs_idt.ensure(cap_obs)) ||
+        (rc = h->d_obs_y.ensure(cap_obs)) || (rc = h->d_obs_yerr.ensure(cap_obs)) || (rc = h->d_tile_ptr.ensure(cap_tp)) ||
+        (rc = h->d_ds.ensure(MP_MAX_DATASETS)))
+        return rc;
+    h->desc.assign(MP_MAX_DATASETS, mp::DsDesc{0, 0, 0, 0});
+    HIP_TRY(hipMemset(h->d_ds.p, 0, MP_MAX_DATASETS * sizeof(mp::DsDesc)));
+    h->obs_used = h->tp_used = 0;
+    for (int d = 0; d < MP_MAX_DATASETS; ++d)
+        if (h->ds[d].set && (rc = append_dataset(h, d))) return rc;
+    publish_datasets(h);
+    return MP_OK;
+}
+
+// After h->ds[d] has been (re)set on the host.
+static int upload_dataset(mp_handle *h, int d, bool replaced) {
+    const HostDataset &s = h->ds[d];
+    const bool fits = h->d_ds.p && h->obs_used + s.g.size() <= h->d_obs_g.cap && h->tp_used + s.tile_ptr.size() <= h->d_tile_ptr.cap;
+    if (replaced || !fits) return rebuild_datasets(h);
+    const int rc = append_dataset(h, d);
+    if (rc) return rc;
+    publish_datasets(h);
     return MP_OK;
 }
 
@@ -332,7 +348,10 @@ mp_handle *mp_create(const mp_model_cfg *cfg, const double *tgrid, int n_grid, i
         if (v > 0.0 && v < 1.0) s.sweep_tol = v;
     }
     s.ultra_tol = std::min(1.0e-5, 100.0 * s.sweep_tol);
-    if (const char *e = std::getenv("MAGPROP_AMD_ULTRA_TOL")) s.ultra_tol = std::atof(e);   // experiments only (0 disables)
+    if (const char *e = std::getenv("MAGPROP_AMD_ULTRA_TOL")) {   // experiments only (0 disables); kept inside [0, 1e-4]
+        const double v = std::atof(e);
+        if (v >= 0.0 && v <= 1.0e-4) s.ultra_tol = v;
+    }
     s.inv_q = 1.0 / q;
     {   // exponential Adams-Moulton quadrature matrix for nodes t_{j+1}, t_j, t_{j-1}, t_{j-2}:
         // W[k][m] = m! * [theta^m] l_k(theta), l_k the Lagrange basis on theta = 1, 0, -1/q, -(1/q + 1/q^2)
@@ -352,7 +371,7 @@ mp_handle *mp_create(const mp_model_cfg *cfg, const double *tgrid, int n_grid, i
             for (int m = 0; m < 4; ++m) s.eamW[k][m] = fact[m] * co[m] / denom;
         }
     }
-    if (upload_datasets(h) != MP_OK) {
+    if (rebuild_datasets(h) != MP_OK) {
         mp_destroy(h);
         return nullptr;
     }
@@ -404,9 +423,10 @@ int mp_set_dataset(mp_handle *h, int ds_id, const double *x, const double *y, co
         d.tile_ptr[(size_t)(g / mp::kTile) + 1] += 1;
     }
     for (size_t k = 1; k < d.tile_ptr.size(); ++k) d.tile_ptr[k] += d.tile_ptr[k - 1];
+    const bool replaced = h->ds[ds_id].set;
     h->ds[ds_id] = std::move(d);
     DeviceScope scope(h->device);
-    return upload_datasets(h);
+    return upload_dataset(h, ds_id, replaced);
 }
 
 int mp_set_prior(mp_handle *h, const double *lower, const double *upper, int ndim, uint32_t log_mask) {
@@ -618,7 +638,25 @@ struct mp_sampler {
     hipEvent_t win_copied[2] = {nullptr, nullptr};
     int64_t win_id[2] = {-1, -1};
     bool ext_stream_work = false;   // half-steps were enqueued on a caller's stream since the last device-wide wait
+    // failed proposals (the reference's fbad file): the device window d_bad is drained into this log
+    std::vector<double> bad_log;    // [rows][ndim]
+    int64_t n_bad = 0;              // exact count since creation (rows beyond the window between two drains are counted, not kept)
 };
+
+// Move the device window of failed proposals into the host log and reset it.  The caller has made sure that no kernel
+// of this sampler is in flight.
+static int drain_bad(mp_sampler *s) {
+    uint32_t cnt = 0;
+    HIP_TRY(hipMemcpy(&cnt, s->d_bad_count.p, sizeof cnt, hipMemcpyDeviceToHost));
+    if (cnt == 0) return MP_OK;
+    const size_t cap = s->d_bad.cap / (size_t)s->ndim, rows = std::min<size_t>(cnt, cap);
+    const size_t old = s->bad_log.size();
+    s->bad_log.resize(old + rows * (size_t)s->ndim);
+    HIP_TRY(hipMemcpy(s->bad_log.data() + old, s->d_bad.p, rows * s->ndim * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(s->d_bad_count.p, 0, sizeof(uint32_t)));
+    s->n_bad += (int64_t)cnt;
+    return MP_OK;
+}
 
 // random split of every ensemble for step `step` (emcee's randomize_split): Fisher-Yates, counter (step, ensemble, i, 'split')
 static void draw_split(const mp_sampler *s, uint64_t step64, int32_t *perm) {
@@ -690,7 +728,7 @@ mp_sampler *mp_sampler_create(mp_handle *h, int n_walkers, int n_ensembles, int 
     std::vector<int32_t> ds(nt, 0);
     for (int e = 0; e < n_ensembles; ++e)
         for (int k = 0; k < n_walkers; ++k) ds[(size_t)e * n_walkers + k] = ens_ds_id ? ens_ds_id[e] : 0;
-    constexpr size_t kBadRows = 4096;   // failed proposals kept for mp_sampler_get_bad (the count itself is exact)
+    constexpr size_t kBadRows = MP_BAD_WINDOW;   // device window of failed proposals between two drains (drain_bad)
     if (s->d_pos.ensure(nt * ndim) || s->d_lnprob.ensure(nt) || s->d_acc.ensure(nt) || s->d_dsid.ensure(nt) ||
         s->d_status.ensure(nt) || s->d_bad.ensure(kBadRows * ndim) || s->d_bad_count.ensure(1) ||
         hipMemcpy(s->d_dsid.p, ds.data(), nt * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess ||
@@ -759,8 +797,9 @@ int mp_sampler_run(mp_sampler *s, int n_steps, double *chain, double *chain_lnpr
     Lock lock(h->mu);
     DeviceScope scope(h->device);
     const size_t nt = (size_t)s->n_total, row = nt * s->ndim;
-    // chunks of steps so that the device-resident chain slab stays below ~256 MB (and the splits below ~64 MB)
-    const size_t perm_cap = std::max<size_t>(1, ((size_t)16 << 20) / nt);
+    // chunks of steps so that the device-resident chain slab stays below ~256 MB, the splits below ~64 MB, and the
+    // window of failed proposals (drained after every chunk) overflows only if more than 1 in 32 proposals fails
+    const size_t perm_cap = std::max<size_t>(1, std::min<size_t>((size_t)16 << 20, (size_t)32 * MP_BAD_WINDOW) / nt);
     const int chunk_max = (int)std::min<size_t>(
         (size_t)std::max(n_steps, 1),
         chain ? std::max<size_t>(1, std::min<size_t>(perm_cap, (256u << 20) / (row * sizeof(double)))) : perm_cap);
@@ -806,6 +845,7 @@ int mp_sampler_run(mp_sampler *s, int n_steps, double *chain, double *chain_lnpr
             h->scratch_busy = true;
         }
         HIP_TRY(hipStreamSynchronize(h->stream));
+        if ((rc = drain_bad(s))) return rc;
         s->steps_done += (uint64_t)chunk;
         done += chunk;
     }
@@ -898,18 +938,19 @@ int mp_sampler_state_ptrs(mp_sampler *s, double **d_pos, double **d_lnprob) {
     return MP_OK;
 }
 
-int mp_sampler_get_bad(mp_sampler *s, double *pars, int max_rows, int64_t *n_bad) {
-    if (!s || max_rows < 0 || (max_rows > 0 && !pars)) return fail(MP_EINVAL, "mp_sampler_get_bad: bad argument");
+int mp_sampler_get_bad(mp_sampler *s, int64_t first_row, double *pars, int max_rows, int64_t *n_bad, int64_t *n_logged) {
+    if (!s || max_rows < 0 || first_row < 0 || (max_rows > 0 && !pars)) return fail(MP_EINVAL, "mp_sampler_get_bad: bad argument");
     mp_handle *h = s->h;
     Lock lock(h->mu);
     DeviceScope scope(h->device);
     HIP_TRY(hipDeviceSynchronize());
-    uint32_t cnt = 0;
-    HIP_TRY(hipMemcpy(&cnt, s->d_bad_count.p, sizeof cnt, hipMemcpyDeviceToHost));
-    if (n_bad) *n_bad = (int64_t)cnt;
-    const size_t cap = s->d_bad.cap / (size_t)s->ndim;
-    const size_t rows = std::min<size_t>(std::min<size_t>(cnt, cap), (size_t)max_rows);
-    if (rows) HIP_TRY(hipMemcpy(pars, s->d_bad.p, rows * s->ndim * sizeof(double), hipMemcpyDeviceToHost));
+    const int rc = drain_bad(s);
+    if (rc) return rc;
+    const int64_t logged = (int64_t)(s->bad_log.size() / (size_t)s->ndim);
+    if (n_bad) *n_bad = s->n_bad;
+    if (n_logged) *n_logged = logged;
+    const int64_t rows = std::max<int64_t>(0, std::min<int64_t>(logged - first_row, (int64_t)max_rows));
+    if (rows) std::memcpy(pars, s->bad_log.data() + (size_t)first_row * s->ndim, (size_t)rows * s->ndim * sizeof(double));
     return (int)rows;
 }
 

@@ -396,8 +396,12 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
         }
     }
 
+    // A walker whose ds_id names no registered light curve (out of range, or a slot never set: n_obs = 0) must not
+    // pass as a perfect fit (chi^2 = 0): lnprob = -inf with its own status, on every entry point.
     const int dsid = a.ds_id ? a.ds_id[walker] : 0;
-    const DsDesc dsd = sh.ds ? sh.ds[(dsid >= 0 && dsid < sh.n_ds) ? dsid : 0] : DsDesc{0, 0, 0, 0};
+    const bool ds_in_range = sh.ds != nullptr && dsid >= 0 && dsid < sh.n_ds;
+    const DsDesc dsd = ds_in_range ? sh.ds[dsid] : DsDesc{0, 0, 0, 0};
+    if (a.want_chi2 && dsd.n_obs <= 0) status = MP_STATUS_BADDATASET;
     const int32_t *tptr = sh.tile_ptr + dsd.tile_off;
     // The first 64 observations of the walker's light curve live in registers, one per lane (time-sorted;
     // every synthetic set has 50).  Longer light curves park the states they need in the walker's scratch rows.

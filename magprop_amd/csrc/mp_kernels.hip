@@ -215,7 +215,7 @@ __global__ __launch_bounds__(PC ? 128 : 64) void stretch_kernel(const DevShared 
                 for (int i = 0; i < g.ndim; ++i) c[i] = accept ? prop[i] : g.pos[(size_t)k * g.ndim + i];
                 g.chain_lnp[(size_t)g.chain_row * g.n_total + k] = accept ? lnp : lnp_old;
             }
-            if (g.bad_log && status != MP_STATUS_OK && status != MP_STATUS_PRIOR) {
+            if (g.bad_log && (status == MP_STATUS_FLAG || status == MP_STATUS_NONFINITE)) {
                 // the reference appends such parameter sets to its `fbad` file (code/synthetic_datasets/mcmc_eqns.py:72-79)
                 const unsigned slot_b = atomicAdd(g.bad_count, 1u);
                 if (slot_b < g.bad_cap)
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void stretch_apply_kernel(const StretchArgs g)
         g.chain_lnp[(size_t)g.chain_row * g.n_total + k] = accept ? u[g.ndim] : lnp_old;
     }
     const int status = (int)u[g.ndim + 2];
-    if (g.bad_log && status != MP_STATUS_OK && status != MP_STATUS_PRIOR) {
+    if (g.bad_log && (status == MP_STATUS_FLAG || status == MP_STATUS_NONFINITE)) {
         const unsigned slot_b = atomicAdd(g.bad_count, 1u);
         if (slot_b < g.bad_cap)
             for (int i = 0; i < g.ndim; ++i) g.bad_log[(size_t)slot_b * g.ndim + i] = u[i];

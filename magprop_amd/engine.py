@@ -1,4 +1,5 @@
 """Handle / dataset caches shared by the reference-shaped front ends (funcs, mcmc_eqns, synth, LogProb)."""
+import contextlib
 import hashlib
 import threading
 
@@ -33,6 +34,7 @@ class Engine:
         self._order = []      # LRU of digests
         self._prior_key = None
         self.lock = threading.Lock()
+        self.pins = 0         # callers between use()'s entry and exit (guarded by the module lock): never evicted
 
     def dataset_slot(self, x, y, yerr):
         x = np.ascontiguousarray(x, dtype=np.float64)
@@ -61,19 +63,42 @@ class Engine:
             self._prior_key = key
 
 
-def engine(cfg, GRBtype=None, device=-1):
-    """Cached Engine for (model configuration, grid, device)."""
+def engine(cfg, GRBtype=None, device=-1, _pin=False):
+    """Cached Engine for (model configuration, grid, device).  The least recently used engines beyond MAX_ENGINES are
+    closed, except those a caller currently holds through use().  Front ends that evaluate go through use(); a bare
+    engine() is a look-up for single-threaded callers (tests, introspection)."""
     key = (_cfg_key(cfg), "S" if GRBtype == "S" else "L", int(device))
     with _lock:
         e = _handles.pop(key, None)
         if e is None:
-            while len(_handles) >= MAX_ENGINES:
-                old = _handles.pop(next(iter(_handles)))
-                with old.lock:                       # a caller still inside the old engine finishes first
-                    old.handle.close()
+            for k in [k for k, v in _handles.items() if v.pins == 0][:max(0, len(_handles) - MAX_ENGINES + 1)]:
+                _handles.pop(k).handle.close()       # nobody is inside an unpinned engine
             e = Engine(cfg, grid(GRBtype), device)
         _handles[key] = e                            # most recently used last
+        if _pin:
+            e.pins += 1
         return e
+
+
+@contextlib.contextmanager
+def use(cfg, GRBtype=None, device=-1):
+    """`with engine.use(cfg, ...) as eng:` — the cached Engine, pinned against eviction and with its lock held for the
+    duration of the block (the pin is taken under the module lock, so another thread's engine() for a ninth
+    configuration can never close the handle between look-up and use; the module lock is not held while waiting)."""
+    while True:
+        e = engine(cfg, GRBtype, device, _pin=True)  # look-up (or creation) and pin in one critical section
+        e.lock.acquire()
+        if getattr(e.handle, "_h", True) is not None:
+            break
+        e.lock.release()                             # closed by clear() while this thread waited: take a fresh one
+        with _lock:
+            e.pins -= 1
+    try:
+        yield e
+    finally:
+        e.lock.release()
+        with _lock:
+            e.pins -= 1
 
 
 def clear():

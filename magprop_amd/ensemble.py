@@ -65,6 +65,7 @@ class EnsembleSampler:
         self.iteration = 0
         self.fbad = fbad
         self._bad_written = 0
+        self._warned_bad = False
 
     def close(self):
         if getattr(self, "_s", None):
@@ -104,26 +105,40 @@ class EnsembleSampler:
         return self.get_last_sample()[0]
 
     # ---- failed proposals (the reference's fbad file)
-    def get_bad(self, max_rows=4096):
-        """(n_bad, pars[rows, ndim]): how many proposals inside the prior failed in the model so far, and the first
-        up to 4096 of them in sampler coordinates."""
-        buf = np.empty((max_rows, self.ndim))
-        n_bad = C.c_int64(0)
-        rows = self._L.mp_sampler_get_bad(self._s, buf.ctypes.data_as(C.POINTER(C.c_double)), int(max_rows), C.byref(n_bad))
-        if rows < 0:
-            _capi.check(rows, "mp_sampler_get_bad")
-        return int(n_bad.value), buf[:rows].copy()
+    def get_bad(self, first_row=0, max_rows=None):
+        """(n_bad, pars[rows, ndim]): how many proposals inside the prior failed in the model so far (exact), and rows
+        [first_row, first_row + max_rows) of the library's log of them, in sampler coordinates.  The log misses rows only
+        if more than MP_BAD_WINDOW (65 536) proposals failed between two drains; a warning says so."""
+        n_bad, n_logged = C.c_int64(0), C.c_int64(0)
+        rc = self._L.mp_sampler_get_bad(self._s, 0, None, 0, C.byref(n_bad), C.byref(n_logged))
+        if rc < 0:
+            _capi.check(rc, "mp_sampler_get_bad")
+        want = max(0, n_logged.value - int(first_row))
+        if max_rows is not None:
+            want = min(want, int(max_rows))
+        buf = np.empty((want, self.ndim))
+        if want:
+            rows = self._L.mp_sampler_get_bad(self._s, int(first_row), buf.ctypes.data_as(C.POINTER(C.c_double)), want,
+                                              None, None)
+            if rows < 0:
+                _capi.check(rows, "mp_sampler_get_bad")
+            buf = buf[:rows]
+        if n_logged.value < n_bad.value and not self._warned_bad:
+            import warnings
+            warnings.warn(f"{n_bad.value - n_logged.value} of {n_bad.value} failed proposals are missing from the fbad log "
+                          "(more than 65 536 failed between two drains)", RuntimeWarning)
+            self._warned_bad = True
+        return int(n_bad.value), buf
 
     def _flush_fbad(self):
         if self.fbad is None or self._target != 0:
             return
-        _, rows = self.get_bad()
-        new = rows[self._bad_written:]
+        _, new = self.get_bad(first_row=self._bad_written)
         if len(new):
             with open(self.fbad, "a") as f:
                 for r in new:
                     f.write(", ".join(f"{v}" for v in r) + "\n")
-            self._bad_written = len(rows)
+            self._bad_written += len(new)
 
     # ---- walker-sharded driving (magprop_amd.distributed.DistributedEnsembleSampler); device pointers as ints
     @property

@@ -23,8 +23,7 @@ def _curve(cfg, pars, xdata, GRBtype, device, dipeff, propeff, f_beam):
     # the efficiencies and the beaming fraction travel as parameters 7-9 of the kernel (the 9-parameter form of
     # magnetar/mcmc_eqns.py:31-34), not in the handle's configuration: a scan over them reuses one cached handle
     pars = np.concatenate([pars, [float(dipeff), float(propeff), float(f_beam)]])
-    eng = engine.engine(cfg, GRBtype, device)
-    with eng.lock:
+    with engine.use(cfg, GRBtype, device) as eng:
         status, out = eng.handle.model_lc(pars)
     if status != _capi.STATUS_OK:
         return "flag"  # magnetar/funcs.py:153-154
@@ -69,8 +68,7 @@ def _rhs(cfg, y, t, B, MdiscI, RdiscI, epsilon, delta, device):
     tt = np.broadcast_to(t, (n,))
     cols = [np.broadcast_to(np.asarray(v, dtype=np.float64), (n,)) for v in (B, 1.0, MdiscI, RdiscI, epsilon, delta)]
     pars = np.stack(cols, axis=1)                      # P (column 1) does not enter the right-hand side
-    eng = engine.engine(cfg, None, device)
-    with eng.lock:
+    with engine.use(cfg, None, device) as eng:
         out = eng.handle.rhs_batch(pars, tt, yy)
     return out[0] if single else out
 

@@ -60,9 +60,8 @@ def _evaluate(pars, data, GRBtype, lower, upper, log_mask, device=-1, want_statu
     p2 = np.atleast_2d(p)
     if not 6 <= p2.shape[1] <= 9:
         raise ValueError("pars must have 6, 7, 8 or 9 entries")
-    eng = engine.engine(_capi.cfg_lib(), GRBtype, device)
     x, y, yerr = _columns(data)
-    with eng.lock:
+    with engine.use(_capi.cfg_lib(), GRBtype, device) as eng:
         slot = eng.dataset_slot(x, y, yerr)
         eng.set_prior(lower, upper, log_mask)
         out, st = eng.handle.lnprob_batch(p2, ds_id=slot, want_status=True)

@@ -19,8 +19,7 @@ def _evaluate(pars, x, y, yerr, lower, upper, device=-1, want_status=False):
     p2 = np.atleast_2d(p)
     if p2.shape[1] != 6:
         raise ValueError("pars must have 6 entries: B, P, log10 MdiscI, log10 RdiscI, log10 epsilon, log10 delta")
-    eng = engine.engine(_capi.cfg_synth(), None, device)
-    with eng.lock:
+    with engine.use(_capi.cfg_synth(), None, device) as eng:
         slot = eng.dataset_slot(x, y, yerr)
         eng.set_prior(lower, upper, LOG_MASK)
         out, st = eng.handle.lnprob_batch(p2, ds_id=slot, want_status=True)

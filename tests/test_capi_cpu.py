@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/magprop_amd.h but not exported"
     assert set(names) == set(_capi.EXPORTS)
-    assert L.mp_abi_version() == _capi.ABI_VERSION == 2
+    assert L.mp_abi_version() == _capi.ABI_VERSION == 3
 
 
 def test_cfg_struct_layout_and_presets():
@@ -162,6 +162,39 @@ def test_engine_cache_is_bounded(monkeypatch):
     assert len(made) == engine.MAX_ENGINES + 4 and len(closed) == 4 and first.handle not in closed
     engine.clear()
     assert len(closed) == len(made)
+
+
+def test_engine_in_use_is_never_evicted(monkeypatch):
+    """An engine a caller is inside (engine.use) survives any number of look-ups for other configurations, from other
+    threads too; once released it is evicted like any other."""
+    import threading
+    closed = []
+
+    class FakeHandle:
+        _h = 1
+
+        def __init__(self, cfg, tgrid, device):
+            pass
+
+        def close(self):
+            closed.append(self)
+            self._h = None
+
+    monkeypatch.setattr(_capi, "Handle", FakeHandle)
+    engine.clear()
+    with engine.use(_capi.cfg_synth(k=0.5)) as held:
+        def sweep():
+            for i in range(engine.MAX_ENGINES + 5):
+                engine.engine(_capi.cfg_synth(alpha=0.01 * (i + 1)))
+        t = threading.Thread(target=sweep)
+        t.start()
+        t.join()
+        assert held.handle not in closed and held.pins == 1 and len(closed) >= 5
+    assert held.pins == 0
+    for i in range(engine.MAX_ENGINES + 1):
+        engine.engine(_capi.cfg_synth(cs7=0.1 * (i + 1)))
+    assert held.handle in closed
+    engine.clear()
 
 
 def test_only_the_checkers_touch_the_oracle():

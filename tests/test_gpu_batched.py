@@ -308,3 +308,73 @@ def test_one_handle_from_several_threads_and_streams(gsynth, tarr):
     torch.cuda.synchronize(dev)
     for w, o in zip(want, outs):
         assert np.array_equal(w, o.cpu().numpy())
+
+
+# ---------------------------------------------------------------- datasets: bad ids, incremental registration
+def test_bad_dataset_id_is_never_a_perfect_fit(gsynth):
+    """Device-pointer entry (the ids live in HBM, the host cannot validate them): a walker whose ds_id is out of range or
+    names a slot that was never set gets lnprob = -inf and MP_STATUS_BADDATASET — not chi^2 = 0 — on both kernel
+    families, and its neighbours are unaffected.  The host-buffer entry rejects the same batch with ValueError."""
+    import torch
+    from magprop_amd import LogProb, _capi
+    x, y, yerr = gsynth["Humped_x"], gsynth["Humped_y"], gsynth["Humped_yerr"]
+    lp = LogProb(x, y, yerr)
+    lp.handle.set_dataset(5, gsynth["Classic_x"], gsynth["Classic_y"], gsynth["Classic_yerr"])   # slots 1-4 stay unset
+    rng = np.random.default_rng(5)
+    for n in (96, 1200):                                        # producer/consumer pair; 2-steps-per-lane kernel
+        P = np.array(TRUTHS["Humped"]) + 1.0e-3 * rng.standard_normal((n, 6))
+        ids = np.where(np.arange(n) % 2 == 0, 0, 5).astype(np.int32)
+        bad = {3: -1, 10: 40, 11: 64, 20: 1000000, 21: 2, 50: 4, n - 1: -2147483648}
+        want = lp(P, ds_id=ids)
+        for i, v in bad.items():
+            ids[i] = v
+        dP, dI = torch.from_numpy(P).cuda(), torch.from_numpy(ids).cuda()
+        st = torch.full((n,), -7, dtype=torch.int32, device="cuda")
+        out = lp.lnprob_device(dP, ds_id=dI, status=st).cpu().numpy()
+        st = st.cpu().numpy()
+        idx = np.array(sorted(bad))
+        assert np.all(out[idx] == -np.inf) and np.all(st[idx] == _capi.STATUS_BADDATASET)
+        ok = np.ones(n, bool)
+        ok[idx] = False
+        assert np.array_equal(out[ok], want[ok]) and np.all(st[ok] == 0) and np.all(np.isfinite(out[ok]))
+        with pytest.raises(ValueError):
+            lp(P, ds_id=ids)
+    # out-of-prior walkers with a bad id still report the dataset problem (a usage error outranks the prior)
+    P = np.tile(TRUTHS["Humped"], (64, 1))
+    P[:, 5] = 3.5
+    st = torch.zeros(64, dtype=torch.int32, device="cuda")
+    out = lp.lnprob_device(torch.from_numpy(P).cuda(), ds_id=torch.full((64,), 9, dtype=torch.int32, device="cuda"), status=st)
+    assert np.all(out.cpu().numpy() == -np.inf) and np.all(st.cpu().numpy() == _capi.STATUS_BADDATASET)
+
+
+def test_registering_64_datasets_is_incremental(gsynth, tarr):
+    """mp_set_dataset for a NEW slot appends (only the new light curve travels, no device-wide wait unless the arena
+    grows): 64 registrations take milliseconds and every slot evaluates as a handle holding that set alone does;
+    replacing a slot and growing past the arena's capacity keep every other slot intact."""
+    import time
+    import magprop_amd as mpa
+    from magprop_amd import LogProb
+    rng = np.random.default_rng(64)
+    base = mpa.model_lum(CANON["Humped"])[1]
+    sets = [_long_set(rng, tarr, base, int(m)) for m in rng.integers(8, 400, 64)]
+    sets[40] = _long_set(rng, tarr, base, 1944)                 # forces the arena (and the scratch rows) to grow midway
+    lp = LogProb(*sets[0])
+    t0 = time.perf_counter()
+    for s in sets[1:]:
+        lp.add_dataset(*s)
+    dt = time.perf_counter() - t0
+    print(f"63 mp_set_dataset calls: {1e3 * dt:.1f} ms")
+    assert dt < 1.0
+    P = np.array(TRUTHS["Humped"]) + 1.0e-3 * rng.standard_normal((64, 6))
+    got = lp(P, ds_id=np.arange(64, dtype=np.int32))
+    for k in (0, 1, 17, 39, 40, 41, 63):
+        alone = LogProb(*sets[k])
+        assert np.isclose(alone(P[k:k + 1])[0], got[k], rtol=1e-9, atol=0.0), k     # (kernel builds with / without scratch rows)
+    # replace slot 17 by another light curve: slot 17 changes, the others do not
+    lp.handle.set_dataset(17, *sets[3])
+    again = lp(P, ds_id=np.arange(64, dtype=np.int32))
+    keep = np.arange(64) != 17
+    assert np.array_equal(again[keep], got[keep])
+    assert np.isclose(again[17], LogProb(*sets[3])(P[17:18])[0], rtol=1e-9, atol=0.0) and again[17] != got[17]
+    with pytest.raises(ValueError):
+        lp.add_dataset(*sets[0])                                # a 65th set: MP_MAX_DATASETS

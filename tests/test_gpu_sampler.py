@@ -338,7 +338,7 @@ def test_sharded_entry_points_in_one_process_and_fbad(gsynth, tmp_path):
     b.run_mcmc(None, 10)
     assert np.array_equal(b.get_chain(), a.get_chain()[25:])
     n_bad, rows = a.get_bad()
-    assert n_bad == b.get_bad()[0] and n_bad > 0 and len(rows) == min(n_bad, 4096)
+    assert n_bad == b.get_bad()[0] and n_bad > 0 and len(rows) == n_bad
     logged = np.loadtxt(fbad, delimiter=",", ndmin=2)
     assert logged.shape == (len(rows), 6) and np.allclose(logged, rows, rtol=1e-15)
     # every logged row is inside the prior and fails in the model (status flag / non-finite), as in the reference
