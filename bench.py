@@ -184,16 +184,32 @@ def self_launch(n, argv):
 
 
 # ---------------------------------------------------------------- helpers
-def read_sclk_mhz():
-    """Current shader clock of GPU 0 in MHz from sysfs (None if unreadable on this box)."""
-    for p in sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk")):
+def read_sclk_mhz(pci=None):
+    """Current shader clock in MHz from sysfs (pp_dpm_sclk, the starred level) of the card at PCI address `pci`
+    ("dddd:bb:dd.f"; a box of this pool sees the sysfs nodes of all eight cards of its host, so the card has to be
+    matched).  None if the card cannot be identified or the node is unreadable."""
+    if pci is None:
+        return None
+    for p in sorted(glob.glob("/sys/class/drm/card*/device")):
         try:
-            for line in open(p).read().splitlines():
+            if os.path.basename(os.path.realpath(p)).lower() != pci.lower():
+                continue
+            for line in open(os.path.join(p, "pp_dpm_sclk")).read().splitlines():
                 if line.rstrip().endswith("*"):
-                    return float(line.split(":")[1].strip().split("M")[0])
+                    return float(line.split(":")[1].strip().lower().split("mhz")[0])
         except (OSError, ValueError, IndexError):
             continue
     return None
+
+
+def device_pci_address(dev_index):
+    """"dddd:bb:dd.0" of a torch device, or None."""
+    try:
+        import torch
+        pr = torch.cuda.get_device_properties(dev_index)
+        return f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+    except Exception:  # noqa: BLE001
+        return None
 
 
 def config5_datasets(g):
@@ -588,18 +604,24 @@ def main():
             per_pass = main_leg["roofline"]["kernel_ms_avg"] * 1e-3
             n_pass = int(a.sustained_seconds * 1.05 / per_pass) + 1
             outs = torch.empty(8, n_local, dtype=torch.float64, device=dev)
-            clk0 = read_sclk_mhz()
+            pci = device_pci_address(c.dev_index)
+            clk0 = read_sclk_mhz(pci)
             torch.cuda.synchronize(dev)
+            import threading
+            mid = []
+            timer = threading.Timer(0.5 * a.sustained_seconds, lambda: mid.append(read_sclk_mhz(pci)))   # halfway through
+            timer.start()
             t0 = time.perf_counter()
             for i in range(n_pass):
                 launch(props[i % props.shape[0]], outs[i % 8], None, L["status"])
-            t_enq = time.perf_counter() - t0
-            clk1 = read_sclk_mhz()                               # the queue still holds most of the passes here
+            t_enq = time.perf_counter() - t0                     # (the launch queue applies back-pressure: ~ the GPU time)
             torch.cuda.synchronize(dev)
+            timer.join()
+            clk1 = mid[0] if mid else None
             dts = time.perf_counter() - t0
-            clk2 = read_sclk_mhz()
+            clk2 = read_sclk_mhz(pci)
             sustained = {"seconds": dts, "passes": n_pass, "evals_per_sec": n_pass * n_local / dts, "ms_per_pass": 1e3 * dts / n_pass,
-                         "host_enqueue_seconds": t_enq, "sclk_mhz": {"before": clk0, "during": clk1, "after": clk2},
+                         "host_enqueue_seconds": t_enq, "sclk_mhz": {"before": clk0, "during": clk1, "after": clk2, "pci": pci},
                          "what": f"{n_pass} back-to-back passes of the headline workload ({n_local} walkers), no events, one "
                                  "synchronisation at the end"}
     config1 = None

@@ -67,6 +67,9 @@ def lib():
         L.mpo_lnlike.restype = C.c_double
         L.mpo_lnlike.argtypes = [C.POINTER(Cfg), dp, C.c_int, dp, C.c_int, dp, dp, dp, C.c_int,
                                  C.POINTER(C.c_int)]
+        L.mpo_lnprob_batch_mode.restype = None
+        L.mpo_lnprob_batch_mode.argtypes = [C.POINTER(Cfg), dp, C.c_int, C.c_int, dp, dp, C.c_int, C.c_uint32,
+                                            dp, C.c_int, dp, dp, dp, C.c_int, dp, ip, C.c_int, C.c_int, ip]
         L.mpo_lnprob_batch.restype = None
         L.mpo_lnprob_batch.argtypes = [C.POINTER(Cfg), dp, C.c_int, C.c_int, dp, dp, C.c_int, C.c_uint32,
                                        dp, C.c_int, dp, dp, dp, C.c_int, dp, ip]
@@ -127,8 +130,11 @@ def lnlike(cfg, pars, tgrid, x, y, yerr):
     return ll, st.value
 
 
-def lnprob_batch(cfg, pars, tgrid, x, y, yerr, lower=None, upper=None, log_mask=0):
-    """(lnprob[n], status[n]) in sampler coordinates (box prior + un-logging per log_mask)."""
+def lnprob_batch(cfg, pars, tgrid, x, y, yerr, lower=None, upper=None, log_mask=0, mode="fixed", spl=4, want_tiles=False):
+    """(lnprob[n], status[n]) in sampler coordinates (box prior + un-logging per log_mask).  mode "fixed": every grid
+    interval is a step (after the sub-stepped first 32 intervals); "adaptive": tiles of 64*spl steps over 1, 2 or 4
+    intervals, the product default (mp_oracle.c mpo_trajectory_mode).  want_tiles: also [n][3] = tile solves, tiles cut
+    short or redone, steps kept."""
     pars = np.atleast_2d(np.ascontiguousarray(pars, dtype=np.float64))
     nw, nd = pars.shape
     t, tp = _d(tgrid)
@@ -145,7 +151,9 @@ def lnprob_batch(cfg, pars, tgrid, x, y, yerr, lower=None, upper=None, log_mask=
         npr = lo.size
     out = np.empty(nw)
     st = np.empty(nw, dtype=np.int32)
-    lib().mpo_lnprob_batch(C.byref(cfg), pars.ctypes.data_as(C.POINTER(C.c_double)), nw, nd, lop, hip, npr,
-                           C.c_uint32(log_mask), tp, t.size, xp, yp, ep, x.size,
-                           out.ctypes.data_as(C.POINTER(C.c_double)), st.ctypes.data_as(C.POINTER(C.c_int32)))
-    return out, st
+    tiles = np.zeros((nw, 3), dtype=np.int32)
+    lib().mpo_lnprob_batch_mode(C.byref(cfg), pars.ctypes.data_as(C.POINTER(C.c_double)), nw, nd, lop, hip, npr,
+                                C.c_uint32(log_mask), tp, t.size, xp, yp, ep, x.size,
+                                out.ctypes.data_as(C.POINTER(C.c_double)), st.ctypes.data_as(C.POINTER(C.c_int32)),
+                                {"fixed": 0, "adaptive": 1}[mode], int(spl), tiles.ctypes.data_as(C.POINTER(C.c_int32)))
+    return (out, st, tiles) if want_tiles else (out, st)

@@ -266,21 +266,6 @@ int mpo_trajectory_etd4rk(const mpo_cfg *c, const double *pars, int ndim, const 
     return status;
 }
 
-/* phi_1..4(z): Taylor below |z| = 0.5, closed forms above */
-static void phi1234(double z, double *ez, double ph[4]) {
-    if (fabs(z) < 0.5) {
-        double s = 0.0, term = 1.0 / 24.0;
-        for (int k = 0; k < 22; ++k) { s += term; term *= z / (double)(k + 5); }
-        ph[3] = s; ph[2] = z * s + 1.0 / 6.0; ph[1] = z * ph[2] + 0.5; ph[0] = z * ph[1] + 1.0; *ez = z * ph[0] + 1.0;
-    } else {
-        *ez = exp(z);
-        ph[0] = expm1(z) / z;
-        ph[1] = (ph[0] - 1.0) / z;
-        ph[2] = (ph[1] - 0.5) / z;
-        ph[3] = (ph[2] - 1.0 / 6.0) / z;
-    }
-}
-
 /*
  * Quadrature matrix of the exponential Adams-Moulton step on a geometric grid of ratio q.
  * Nodes (in units of the step h_j, origin t_j): t_{j+1}, t_j, t_{j-1}, t_{j-2}  ->  1, 0, -1/q, -(1/q + 1/q^2).
@@ -306,85 +291,302 @@ void mpo_eam4_weights(double q, double Wm[4][4]) {
     }
 }
 
+/* phi_1..phi_K(z): Taylor below |z| = 0.5, closed forms above */
+static void phi_upto(double z, double *ez, double *ph, int K) {
+    if (fabs(z) < 0.5) {
+        double s = 0.0, term = 1.0;
+        for (int i = 2; i <= K; ++i) term /= (double)i;                       /* 1/K! */
+        for (int k = 0; k < 30; ++k) { s += term; term *= z / (double)(k + K + 1); }
+        ph[K - 1] = s;
+        for (int j = K - 2; j >= 0; --j) {
+            double fact = 1.0;
+            for (int i = 2; i <= j + 1; ++i) fact *= (double)i;               /* (j+1)! */
+            ph[j] = z * ph[j + 1] + 1.0 / fact;
+        }
+        *ez = z * ph[0] + 1.0;
+    } else {
+        *ez = exp(z);
+        ph[0] = expm1(z) / z;
+        double fact = 1.0;
+        for (int j = 1; j < K; ++j) { ph[j] = (ph[j - 1] - 1.0 / fact) / z; fact *= (double)(j + 1); }
+    }
+}
+
 /*
- * PRODUCTION SCHEME (the one the HIP kernel implements): exponential Adams-Moulton of order 4 on the
- * geometric output grid, one step per grid interval.
- *   Mdisc_{j+1} = e^{-z} Mdisc_j + h sum_m phi_{m+1}(-z) sum_k Wm[k][m] Mdotfb(t_{j+1-k}),        z = h/tvisc
- *   omega_{j+1} = e^{h lam} omega_j + h sum_m phi_{m+1}(h lam) sum_k Wm[k][m] (f_{j+1-k} - lam omega_{j+1-k})
- * with f_p = omega_dot(Mdisc_p, omega_p) and lam = d(omega_dot)/d(omega) frozen at the NEW point
- * (t_{j+1}, omega_{j+1}): implicit in omega_{j+1}, solved by fixed-point iteration (contraction ~ h*|d lam|).
- * History before the first grid point: Mdotfb is analytic (the grid is continued geometrically backwards);
- * for (f, omega) the two missing points are the linear continuation in the step index through points 0 and 1.
- * Failure ('flag'): the rotation parameter of any iterate at a grid point exceeds 0.27.
- * nsub > 1 refines the grid geometrically (convergence studies only).
+ * Quadrature matrix of the order-K exponential Adams-Moulton step on a geometric grid of ratio q: nodes (in units of the
+ * step h_j, origin t_j) t_{j+1}, t_j, t_{j-1}, ... -> 1, 0, -1/q, -(1/q + 1/q^2), ...;  W[k*K + m] = m! [theta^m] l_k(theta).
  */
-int mpo_trajectory(const mpo_cfg *c, const double *pars, int ndim, const double *tgrid, int n,
-                   int nsub, double *Mout, double *Wout) {
+void mpo_eam_weights(double q, int K, double *W) {
+    double x[8];
+    x[0] = 1.0; x[1] = 0.0;
+    { double acc = 0.0, f = 1.0; for (int k = 2; k < K; ++k) { f /= q; acc -= f; x[k] = acc; } }
+    for (int k = 0; k < K; ++k) {
+        double c[8] = {1.0, 0, 0, 0, 0, 0, 0, 0};
+        int deg = 0;
+        double denom = 1.0;
+        for (int j = 0; j < K; ++j) {
+            if (j == k) continue;
+            for (int m = deg + 1; m >= 1; --m) c[m] = c[m - 1] - x[j] * c[m];
+            c[0] = -x[j] * c[0];
+            ++deg;
+            denom *= x[k] - x[j];
+        }
+        double fact = 1.0;
+        for (int m = 0; m < K; ++m) { if (m > 1) fact *= (double)m; W[k * K + m] = fact * c[m] / denom; }
+    }
+}
+
+/* cubic Hermite on [0, 1] (theta), step h: value from the end values y0, y1 and end derivatives d0, d1 */
+static double hermite(double th, double h, double y0, double d0, double y1, double d1) {
+    const double D = y1 - y0;
+    return y0 + th * (h * d0 + th * ((3.0 * D - h * (2.0 * d0 + d1)) + th * (h * (d0 + d1) - 2.0 * D)));
+}
+static double hermite_d(double th, double h, double y0, double d0, double y1, double d1) {   /* d/dt of the same cubic */
+    const double D = y1 - y0;
+    return (h * d0 + th * (2.0 * (3.0 * D - h * (2.0 * d0 + d1)) + th * 3.0 * (h * (d0 + d1) - 2.0 * D))) / h;
+}
+
+/* which smooth branch of the right-hand side a state is on: bit 0 = Alfven radius capped at k*Rlc
+ * (code/synthetic_datasets/funcs.py:109-110), bit 1 = Rm >= R (the torque-arm branch, :133-138) */
+static int branch_flags(const mpo_cfg *c, const wk *w, double Mdisc, double omega) {
+    double Rm_u = pow(w->mu, 4.0 / 7.0) * pow(w->GM, -1.0 / 7.0) * pow((c->rm_massflow_factor * Mdisc) / w->tvisc, -2.0 / 7.0);
+    int capped = Rm_u >= c->k * (C_ / omega);
+    double Rm = capped ? c->k * C_ / omega : Rm_u;
+    return capped | ((Rm >= R_) ? 2 : 0);
+}
+
+/*
+ * PRODUCTION SCHEME (what the HIP kernels implement): exponential Adams-Moulton of order 5 for omega
+ * (order 4 for the linear Mdisc equation, whose source is analytic) on geometric grids:
+ *   Mdisc_{j+1} = e^{-z} Mdisc_j + h sum_m phi_{m+1}(-z) sum_k W4[k][m] Mdotfb(t_{j+1-k}),          z = h/tvisc
+ *   omega_{j+1} = e^{h lam} omega_j + h sum_m phi_{m+1}(h lam) sum_k W5[k][m] (f_{j+1-k} - lam omega_{j+1-k})
+ * with f_p = omega_dot(Mdisc_p, omega_p) and lam = d(omega_dot)/d(omega) frozen at the NEW point (implicit in omega_{j+1},
+ * solved by fixed-point iteration).  The integration proceeds in TILES of 64*spl steps (one wavefront, spl steps per lane
+ * on the GPU); the step of a tile is a fixed multiple of the output grid's:
+ *   - the first 32 grid intervals are covered with 1/8-interval sub-steps (the spin-up transient of heavy discs around
+ *     strongly magnetised stars is faster than the output grid at t = 1 s);
+ *   - mode 0 (FIXED): every later tile steps over single grid intervals;
+ *   - mode 1 (ADAPTIVE, the product default): tiles step over 1, 2 or 4 grid intervals.  A tile at stride > 1 is kept only up
+ *     to the first lane in which (a) the solution changes the smooth branch of the right-hand side (Alfven-radius cap, torque
+ *     arm: a kink no multistep formula can cross at a coarse step) or (b) the smoothness indicator h |4th difference of
+ *     (f - lam omega)| / omega exceeds stride_tol; what follows is redone at stride 1.  Values at skipped grid points come
+ *     from the cubic Hermite interpolant of (omega, f) / (Mdisc, dMdisc/dt) over the step (error ~ (h/t)^4 / 384).
+ * History for a tile whose step differs from its predecessor's: the same Hermite interpolant on the predecessor's steps
+ * (exact where the points coincide).  Start-up: Mdotfb is analytic (grid continued backwards); the missing (f, omega)
+ * points continue points 0 and 1 linearly.  Failure ('flag'): the rotation parameter of an iterate at a step end exceeds
+ * 0.27 in a tile at stride <= 1; at a coarser stride the tile is redone finer first.
+ */
+typedef struct { double t, M, dM, w, f; } mpo_node;
+typedef struct {
+    int tiles, tiles_pre, tiles_s1, tiles_s2, tiles_s4, tiles_cut;   /* tile solves by kind; tiles not (fully) kept */
+    int steps_kept;
+} mpo_stats;
+
+#define MPO_PRE_FINE 32   /* grid intervals covered by the sub-stepped tiles */
+#define MPO_PRE_SUB 8     /* sub-steps per grid interval there */
+#define MPO_MIN_KEEP 8    /* a coarse tile is kept if at least this many lanes precede the first offending one */
+
+/* omega, f, Mdisc, dMdisc/dt at time t <= the last accepted node (Hermite on the accepted steps; exact at nodes) */
+static int node_lookup(const mpo_node *nd, int nn, double t, double *wv, double *fv) {
+    int hi = nn - 1;
+    while (hi > 0 && nd[hi - 1].t > t * (1.0 + 1e-13)) --hi;
+    if (fabs(t / nd[hi].t - 1.0) < 1e-13) { *wv = nd[hi].w; *fv = nd[hi].f; return 1; }
+    if (hi == 0) return 0;                                    /* before the first node */
+    const mpo_node *a = &nd[hi - 1], *b = &nd[hi];
+    if (fabs(t / a->t - 1.0) < 1e-13) { *wv = a->w; *fv = a->f; return 1; }
+    const double h = b->t - a->t, th = (t - a->t) / h;
+    *wv = hermite(th, h, a->w, a->f, b->w, b->f);
+    *fv = hermite_d(th, h, a->w, a->f, b->w, b->f);
+    return 1;
+}
+
+int mpo_trajectory_mode(const mpo_cfg *c, const double *pars, int ndim, const double *tgrid, int n, int mode, int spl,
+                        double stride_tol, int max_stride, double *Mout, double *Wout, mpo_stats *stats) {
+    enum { P = 5 };
     wk w;
     walker_setup(c, pars, ndim, &w);
-    if (nsub < 1) nsub = 1;
-    const int nf = (n - 1) * nsub + 1;
-    const double q = exp(log(tgrid[n - 1] / tgrid[0]) / (double)(nf - 1));
-    double Wm[4][4];
-    mpo_eam4_weights(q, Wm);
-    double *tf = (double *)malloc(sizeof(double) * (size_t)nf);
-    if (nsub == 1) memcpy(tf, tgrid, sizeof(double) * (size_t)n);
-    else for (int i = 0; i < nf; ++i) tf[i] = (i % nsub == 0) ? tgrid[i / nsub] : tgrid[0] * pow(q, (double)i);
-    int status = MPO_OK;
-    for (int j = 0; j < n; ++j) { if (Mout) Mout[j] = NAN; if (Wout) Wout[j] = NAN; } /* undefined after a failure */
+    const int TILE = 64 * spl, nsteps = n - 1;
+    const double q = exp(log(tgrid[n - 1] / tgrid[0]) / (double)nsteps);
+    if (stride_tol <= 0.0) stride_tol = 1.0e-7;
+    if (max_stride <= 0) max_stride = 4;
+    mpo_stats st_ = {0, 0, 0, 0, 0, 0, 0};
+    for (int j = 0; j < n; ++j) { if (Mout) Mout[j] = NAN; if (Wout) Wout[j] = NAN; }
+    mpo_node *nd = (mpo_node *)malloc(sizeof(mpo_node) * (size_t)(n + MPO_PRE_FINE * MPO_PRE_SUB + TILE + 8));
+    mpo_node *tn = (mpo_node *)malloc(sizeof(mpo_node) * (size_t)(TILE + 1));
+    double *ind = (double *)malloc(sizeof(double) * (size_t)TILE);
+    int *brk = (int *)malloc(sizeof(int) * (size_t)TILE);
+    int nn = 0, status = MPO_OK;
     double M = pars[2] * MSOL_;                        /* code/synthetic_datasets/funcs.py:66-69 */
     double om = (2.0 * M_PI) / (1.0e-3 * pars[1]);
-    /* history: index 0 = point j, 1 = j-1, 2 = j-2 */
-    double Sh[3] = {mdot_fb(&w, tf[0]), mdot_fb(&w, tf[0] / q), mdot_fb(&w, tf[0] / (q * q))};
-    double fh[3] = {0.0, 0.0, 0.0}, wh[3] = {0.0, 0.0, 0.0}, rot;
-    fh[0] = omega_dot(c, &w, M, om, &rot, NULL);
-    wh[0] = om;
-    double f0 = fh[0], w0 = om, f1 = 0.0, w1 = 0.0; /* points 0 and 1, for the start-up ghosts */
-    for (int i = 0; i < nf; ++i) {
-        if (i % nsub == 0) { if (Mout) Mout[i / nsub] = M; if (Wout) Wout[i / nsub] = om; }
-        if (!(isfinite(M) && isfinite(om)) || M <= 0.0 || om <= 0.0) status = MPO_NONFINITE;
-        else if ((0.5 * w.I * om * om) / w.modW > 0.27) status = MPO_FLAG;
-        if (status != MPO_OK || i == nf - 1) break;
-        const double h = tf[i + 1] - tf[i];
-        /* ---- Mdisc */
-        const double S1 = mdot_fb(&w, tf[i + 1]);
-        double ez, ph[4];
-        phi1234(-h / w.tvisc, &ez, ph);
-        double acc = 0.0;
-        for (int m = 0; m < 4; ++m)
-            acc += ph[m] * (Wm[0][m] * S1 + Wm[1][m] * Sh[0] + Wm[2][m] * Sh[1] + Wm[3][m] * Sh[2]);
-        const double M1 = ez * M + h * acc;
-        /* ---- omega: fixed-point iteration on the implicit step */
-        double wn = om + h * fh[0], fnew = 0.0;
-        int flagged = 0;
-        for (int it = 0; it < 200; ++it) {
-            double lam, r1;
-            fnew = omega_dot(c, &w, M1, wn, &r1, &lam);
-            if (r1 > 0.27) { flagged = 1; break; }
-            double hf[2], hw[2]; /* points j-1, j-2 (ghosts during start-up) */
-            if (i == 0) { hf[0] = 2.0 * f0 - fnew; hw[0] = 2.0 * w0 - wn; hf[1] = 3.0 * f0 - 2.0 * fnew; hw[1] = 3.0 * w0 - 2.0 * wn; }
-            else if (i == 1) { hf[0] = fh[1]; hw[0] = wh[1]; hf[1] = 2.0 * f0 - f1; hw[1] = 2.0 * w0 - w1; }
-            else { hf[0] = fh[1]; hw[0] = wh[1]; hf[1] = fh[2]; hw[1] = wh[2]; }
-            const double N0 = fnew - lam * wn, N1 = fh[0] - lam * wh[0], N2 = hf[0] - lam * hw[0], N3 = hf[1] - lam * hw[1];
-            phi1234(h * lam, &ez, ph);
-            acc = 0.0;
-            for (int m = 0; m < 4; ++m) acc += ph[m] * (Wm[0][m] * N0 + Wm[1][m] * N1 + Wm[2][m] * N2 + Wm[3][m] * N3);
-            const double wnew = ez * om + h * acc;
-            const double d = fabs(wnew - wn);
-            wn = wnew;
-            if (!(d > 1e-15 * fabs(wn))) break; /* converged, or NaN */
+    double rot, fcur = omega_dot(c, &w, M, om, &rot, NULL);
+    if (!(isfinite(M) && isfinite(om)) || M <= 0.0 || om <= 0.0) status = MPO_NONFINITE;
+    else if (rot > 0.27) status = MPO_FLAG;
+    nd[nn++] = (mpo_node){tgrid[0], M, mdot_fb(&w, tgrid[0]) - M / w.tvisc, om, fcur};
+    if (Mout) Mout[0] = M;
+    if (Wout) Wout[0] = om;
+    const int pre_fine = nsteps < MPO_PRE_FINE ? nsteps : MPO_PRE_FINE;
+    int i0 = 0;          /* grid index of the tile start */
+    int sub_done = 0;    /* sub-steps of the pre-phase done */
+    int s = 1;           /* stride of the next grid tile */
+    while (status == MPO_OK && i0 < nsteps) {
+        const int pre = i0 < pre_fine;
+        int nc;
+        double Q;
+        if (pre) {
+            const int left = pre_fine * MPO_PRE_SUB - sub_done;
+            nc = left < TILE ? left : TILE;
+            Q = pow(q, 1.0 / MPO_PRE_SUB);
+            s = 1;
+        } else {
+            if (mode == 0) s = 1;
+            while (s > 1 && ((nsteps - i0) % s != 0)) s /= 2;
+            nc = ((nsteps - i0) / s < TILE) ? (nsteps - i0) / s : TILE;
+            Q = pow(q, (double)s);
         }
-        if (flagged) { status = MPO_FLAG; break; }
-        fnew = omega_dot(c, &w, M1, wn, &rot, NULL);
-        if (i == 0) { f1 = fnew; w1 = wn; }
-        Sh[2] = Sh[1]; Sh[1] = Sh[0]; Sh[0] = S1;
-        fh[2] = fh[1]; fh[1] = fh[0]; fh[0] = fnew;
-        wh[2] = wh[1]; wh[1] = wh[0]; wh[0] = wn;
-        M = M1;
-        om = wn;
+        double W5[25], W4[4][4];
+        mpo_eam_weights(Q, P, W5);
+        mpo_eam4_weights(Q, W4);
+        const double t0 = nd[nn - 1].t;
+        double Sh[3] = {mdot_fb(&w, t0), mdot_fb(&w, t0 / Q), mdot_fb(&w, t0 / (Q * Q))};
+        double fh[P], wh[P];
+        fh[0] = fcur; wh[0] = om;
+        int startup = (nn == 1);
+        for (int k = 1; k <= P - 2 && !startup; ++k)
+            if (!node_lookup(nd, nn, t0 / pow(Q, (double)k), &wh[k], &fh[k])) startup = 1;
+        const double f0 = fh[0], w0 = om;
+        double f1 = 0.0, w1 = 0.0, Mt = M, ot = om;
+        const int flags0 = branch_flags(c, &w, M, om);
+        int tstatus = MPO_OK, J;
+        for (J = 0; J < nc; ++J) {
+            double tJ1;
+            if (pre) { const int k = sub_done + J + 1; tJ1 = (k % MPO_PRE_SUB == 0) ? tgrid[k / MPO_PRE_SUB] : tgrid[0] * pow(Q, (double)k); }
+            else tJ1 = tgrid[i0 + (J + 1) * s];
+            const double tJ = (J == 0) ? t0 : tn[J - 1].t, h = tJ1 - tJ;
+            /* ---- Mdisc */
+            const double S1 = mdot_fb(&w, tJ1);
+            double ez, ph[8], acc = 0.0;
+            phi_upto(-h / w.tvisc, &ez, ph, 4);
+            for (int m = 0; m < 4; ++m) acc += ph[m] * (W4[0][m] * S1 + W4[1][m] * Sh[0] + W4[2][m] * Sh[1] + W4[3][m] * Sh[2]);
+            const double M1 = ez * Mt + h * acc;
+            /* ---- omega: fixed-point iteration on the implicit step */
+            double wn = ot + h * fh[0], fnew = 0.0, lam = 0.0, Nv[P];
+            int flagged = 0;
+            for (int it = 0; it < 200; ++it) {
+                double r1;
+                fnew = omega_dot(c, &w, M1, wn, &r1, &lam);
+                if (r1 > 0.27) { flagged = 1; break; }
+                Nv[0] = fnew - lam * wn;
+                Nv[1] = fh[0] - lam * wh[0];
+                for (int k = 1; k <= P - 2; ++k) {
+                    double hf, hw;
+                    if (startup && J < k) {   /* point j-k lies before the grid: points 0 and 1 continued linearly (point -m) */
+                        const double m_ = (double)(k - J), fp1 = (J == 0) ? fnew : f1, wp1 = (J == 0) ? wn : w1;
+                        hf = (1.0 + m_) * f0 - m_ * fp1; hw = (1.0 + m_) * w0 - m_ * wp1;
+                    } else { hf = fh[k]; hw = wh[k]; }
+                    Nv[k + 1] = hf - lam * hw;
+                }
+                phi_upto(h * lam, &ez, ph, P);
+                acc = 0.0;
+                for (int m = 0; m < P; ++m) { double g = 0.0; for (int k = 0; k < P; ++k) g += W5[k * P + m] * Nv[k]; acc += ph[m] * g; }
+                const double wnew = ez * ot + h * acc, d = fabs(wnew - wn);
+                wn = wnew;
+                if (!(d > 1e-15 * fabs(wn))) break; /* converged, or NaN */
+            }
+            if (flagged) { tstatus = MPO_FLAG; break; }
+            fnew = omega_dot(c, &w, M1, wn, &rot, NULL);
+            if (!(isfinite(M1) && isfinite(wn)) || M1 <= 0.0 || wn <= 0.0) { tstatus = MPO_NONFINITE; break; }
+            if ((0.5 * w.I * wn * wn) / w.modW > 0.27) { tstatus = MPO_FLAG; break; }
+            brk[J] = branch_flags(c, &w, M1, wn) != flags0;
+            ind[J] = (startup && J < P - 2) ? 0.0 : h * fabs(Nv[0] - 4.0 * Nv[1] + 6.0 * Nv[2] - 4.0 * Nv[3] + Nv[4]) / fabs(wn);
+            tn[J] = (mpo_node){tJ1, M1, S1 - M1 / w.tvisc, wn, fnew};
+            if (startup && J == 0) { f1 = fnew; w1 = wn; }
+            Sh[2] = Sh[1]; Sh[1] = Sh[0]; Sh[0] = S1;
+            for (int k = P - 2; k >= 1; --k) { fh[k] = fh[k - 1]; wh[k] = wh[k - 1]; }
+            fh[0] = fnew; wh[0] = wn;
+            Mt = M1; ot = wn;
+        }
+        const int nsolved = J;                       /* steps before a failure */
+        ++st_.tiles;
+        if (pre) ++st_.tiles_pre; else if (s == 1) ++st_.tiles_s1; else if (s == 2) ++st_.tiles_s2; else ++st_.tiles_s4;
+        /* ---- what is kept (lane granularity: lane l owns steps l*spl .. l*spl + spl - 1) */
+        int keep = nc, next_s = s;
+        if (pre || s == 1) {
+            if (tstatus != MPO_OK) { status = tstatus; break; }            /* a verdict only at stride <= 1 */
+        } else {
+            int first = (nsolved < nc) ? nsolved / spl : 64;
+            for (int l = 0; l < first && l * spl < nc; ++l)
+                for (int e = l * spl; e < (l + 1) * spl && e < nsolved; ++e)
+                    if (brk[e] || ind[e] > stride_tol) { if (l < first) first = l; }
+            if (first * spl >= nc) first = 64;
+            if (first < 64) {
+                ++st_.tiles_cut;
+                if (first < MPO_MIN_KEEP) { s = 1; continue; }               /* nothing worth keeping: redo at stride 1 */
+                keep = first * spl;
+                next_s = 1;                                                  /* the offending region gets single intervals */
+            }
+        }
+        /* ---- stride of the next tile (mode 1): coarsen when the kept steps were calm (5th-order scaling of the indicator) */
+        if (mode == 1 && !pre && keep == nc && next_s == s) {
+            double imax = 0.0, ipost = 0.0;
+            int lastbrk = -1;
+            for (int e = 0; e < keep; ++e) { if (ind[e] > imax) imax = ind[e]; if (brk[e] && lastbrk < 0) lastbrk = e / spl; }
+            if (s == 1) {
+                if (lastbrk < 0) next_s = (imax * 2048.0 < stride_tol) ? 4 : (imax * 64.0 < stride_tol) ? 2 : 1;
+                else {
+                    /* a kink inside this tile: the history of a coarse successor must lie behind it */
+                    const int first_clean = (lastbrk + 2) * spl, tail = keep - first_clean;   /* steps after the kink lane + 1 */
+                    for (int e = first_clean > 0 ? first_clean : 0; e < keep; ++e) if (ind[e] > ipost) ipost = ind[e];
+                    if (tail >= 3 * 4 + spl && ipost * 2048.0 < stride_tol) next_s = 4;
+                    else if (tail >= 3 * 2 + spl && ipost * 64.0 < stride_tol) next_s = 2;
+                    else next_s = 1;
+                }
+            } else if (s == 2) next_s = (imax * 64.0 < stride_tol) ? 4 : 2;
+            if (next_s > max_stride) next_s = max_stride;
+        }
+        if (pre) next_s = 1;
+        /* ---- commit the kept steps: nodes, and the grid points they contain */
+        mpo_node prev = nd[nn - 1];
+        for (J = 0; J < keep; ++J) {
+            if (pre) {
+                const int k = sub_done + J + 1;
+                if (k % MPO_PRE_SUB == 0) { if (Mout) Mout[k / MPO_PRE_SUB] = tn[J].M; if (Wout) Wout[k / MPO_PRE_SUB] = tn[J].w; }
+            } else {
+                const int ib = i0 + J * s;
+                const double h = tn[J].t - prev.t;
+                for (int i = 1; i < s; ++i) {
+                    const double th = (tgrid[ib + i] - prev.t) / h;
+                    if (Mout) Mout[ib + i] = hermite(th, h, prev.M, prev.dM, tn[J].M, tn[J].dM);
+                    if (Wout) Wout[ib + i] = hermite(th, h, prev.w, prev.f, tn[J].w, tn[J].f);
+                }
+                if (Mout) Mout[ib + s] = tn[J].M;
+                if (Wout) Wout[ib + s] = tn[J].w;
+            }
+            nd[nn++] = tn[J];
+            prev = tn[J];
+        }
+        st_.steps_kept += keep;
+        if (pre) { sub_done += keep; i0 = sub_done / MPO_PRE_SUB; } else i0 += keep * s;
+        M = tn[keep - 1].M; om = tn[keep - 1].w; fcur = tn[keep - 1].f;
+        s = next_s;
     }
-    free(tf);
+    free(nd); free(tn); free(ind); free(brk);
+    if (status != MPO_OK) for (int j = 0; j < n; ++j) { if (Mout) Mout[j] = NAN; if (Wout) Wout[j] = NAN; }
+    if (stats) *stats = st_;
     return status;
+}
+
+/* The FIXED production scheme (mode 0).  nsub > 1: every step refined geometrically nsub-fold (convergence studies). */
+int mpo_trajectory(const mpo_cfg *c, const double *pars, int ndim, const double *tgrid, int n,
+                   int nsub, double *Mout, double *Wout) {
+    if (nsub <= 1) return mpo_trajectory_mode(c, pars, ndim, tgrid, n, 0, 4, 0.0, 1, Mout, Wout, NULL);
+    const int nf = (n - 1) * nsub + 1;
+    const double q = exp(log(tgrid[n - 1] / tgrid[0]) / (double)(nf - 1));
+    double *tf = (double *)malloc(sizeof(double) * 3 * (size_t)nf), *Mf = tf + nf, *Wf = tf + 2 * nf;
+    for (int i = 0; i < nf; ++i) tf[i] = (i % nsub == 0) ? tgrid[i / nsub] : tgrid[0] * pow(q, (double)i);
+    const int st = mpo_trajectory_mode(c, pars, ndim, tf, nf, 0, 4, 0.0, 1, Mf, Wf, NULL);
+    for (int j = 0; j < n; ++j) { if (Mout) Mout[j] = Mf[(size_t)j * nsub]; if (Wout) Wout[j] = Wf[(size_t)j * nsub]; }
+    free(tf);
+    return st;
 }
 
 /* luminosities at one grid point, in erg/s (not yet /1e50) */
@@ -445,10 +647,11 @@ static double interp_lin(const double *xp, const double *fp, int n, double x) {
 }
 
 /* lnlike for PHYSICAL parameters.  *status: MPO_OK / MPO_FLAG / MPO_NONFINITE.  -inf on failure. */
-double mpo_lnlike(const mpo_cfg *c, const double *pars, int ndim, const double *tgrid, int n,
-                  const double *x, const double *y, const double *yerr, int nobs, int *status) {
+double mpo_lnlike_mode(const mpo_cfg *c, const double *pars, int ndim, const double *tgrid, int n,
+                       const double *x, const double *y, const double *yerr, int nobs, int *status, int mode, int spl,
+                       mpo_stats *stats) {
     double *M = (double *)malloc(sizeof(double) * 3 * (size_t)n), *W = M + n, *L = M + 2 * n;
-    int st = mpo_trajectory(c, pars, ndim, tgrid, n, 1, M, W);
+    int st = mpo_trajectory_mode(c, pars, ndim, tgrid, n, mode, spl, 0.0, 0, M, W, stats);
     double ll = -INFINITY;
     if (st == MPO_OK) {
         wk w;
@@ -468,29 +671,53 @@ double mpo_lnlike(const mpo_cfg *c, const double *pars, int ndim, const double *
     return ll;
 }
 
+double mpo_lnlike(const mpo_cfg *c, const double *pars, int ndim, const double *tgrid, int n,
+                  const double *x, const double *y, const double *yerr, int nobs, int *status) {
+    return mpo_lnlike_mode(c, pars, ndim, tgrid, n, x, y, yerr, nobs, status, 0, 4, NULL);
+}
+
 /*
  * lnprob in sampler coordinates: inclusive box prior, un-log the coordinates in log_mask, lnlike.
- * nprior = 0 disables the prior.
+ * nprior = 0 disables the prior.  mode / spl: mpo_trajectory_mode (0 = fixed steps, 1 = adaptive stride; lanes own spl steps).
  */
-double mpo_lnprob(const mpo_cfg *c, const double *pars, int ndim, const double *lower, const double *upper,
-                  int nprior, uint32_t log_mask, const double *tgrid, int n,
-                  const double *x, const double *y, const double *yerr, int nobs, int *status) {
+double mpo_lnprob_mode(const mpo_cfg *c, const double *pars, int ndim, const double *lower, const double *upper,
+                       int nprior, uint32_t log_mask, const double *tgrid, int n,
+                       const double *x, const double *y, const double *yerr, int nobs, int *status, int mode, int spl,
+                       mpo_stats *stats) {
     double p[9];
+    if (stats) memset(stats, 0, sizeof *stats);
     for (int i = 0; i < nprior; ++i) {
         if (!(pars[i] >= lower[i]) || !(pars[i] <= upper[i])) { if (status) *status = MPO_PRIOR; return -INFINITY; }
     }
     for (int i = 0; i < ndim; ++i) p[i] = (log_mask >> i) & 1u ? pow(10.0, pars[i]) : pars[i];
-    return mpo_lnlike(c, p, ndim, tgrid, n, x, y, yerr, nobs, status);
+    return mpo_lnlike_mode(c, p, ndim, tgrid, n, x, y, yerr, nobs, status, mode, spl, stats);
+}
+
+double mpo_lnprob(const mpo_cfg *c, const double *pars, int ndim, const double *lower, const double *upper,
+                  int nprior, uint32_t log_mask, const double *tgrid, int n,
+                  const double *x, const double *y, const double *yerr, int nobs, int *status) {
+    return mpo_lnprob_mode(c, pars, ndim, lower, upper, nprior, log_mask, tgrid, n, x, y, yerr, nobs, status, 0, 4, NULL);
+}
+
+/* tiles[nwalk][3] (optional): tile solves, tiles cut short or redone, steps kept */
+void mpo_lnprob_batch_mode(const mpo_cfg *c, const double *pars, int nwalk, int ndim, const double *lower,
+                           const double *upper, int nprior, uint32_t log_mask, const double *tgrid, int n,
+                           const double *x, const double *y, const double *yerr, int nobs,
+                           double *lnprob, int32_t *status, int mode, int spl, int32_t *tiles) {
+    for (int i = 0; i < nwalk; ++i) {
+        int st = 0;
+        mpo_stats ss;
+        lnprob[i] = mpo_lnprob_mode(c, pars + (size_t)i * ndim, ndim, lower, upper, nprior, log_mask, tgrid, n,
+                                    x, y, yerr, nobs, &st, mode, spl, &ss);
+        if (status) status[i] = st;
+        if (tiles) { tiles[3 * i] = ss.tiles; tiles[3 * i + 1] = ss.tiles_cut; tiles[3 * i + 2] = ss.steps_kept; }
+    }
 }
 
 void mpo_lnprob_batch(const mpo_cfg *c, const double *pars, int nwalk, int ndim, const double *lower,
                       const double *upper, int nprior, uint32_t log_mask, const double *tgrid, int n,
                       const double *x, const double *y, const double *yerr, int nobs,
                       double *lnprob, int32_t *status) {
-    for (int i = 0; i < nwalk; ++i) {
-        int st = 0;
-        lnprob[i] = mpo_lnprob(c, pars + (size_t)i * ndim, ndim, lower, upper, nprior, log_mask, tgrid, n,
-                               x, y, yerr, nobs, &st);
-        if (status) status[i] = st;
-    }
+    mpo_lnprob_batch_mode(c, pars, nwalk, ndim, lower, upper, nprior, log_mask, tgrid, n, x, y, yerr, nobs, lnprob, status,
+                          0, 4, NULL);
 }

@@ -23,11 +23,43 @@ TRUTHS = {  # synth_mcmc.py:16-21 (sampler coordinates)
     "Stuttering": [1.0, 5.0, -5.0, 2.0, -1.0, 2.0],
 }
 
-# |lnprob - reference| tolerances.  The reference integrates with LSODA at
-# rtol = atol ~ 1.5e-8 and its own lnprob carries up to 1.4e-5 relative integrator noise; against the
-# same reference code run with a tight integrator (rtol = atol = 1e-12) the agreement is <= 6e-8 relative (median 3e-12).
-REF_ATOL, REF_RTOL = 1.0e-5, 2.0e-5
+# |lnprob - reference| tolerances: SURVEY.md 8(c)'s contract 1e-5 + 2e-6 |ref| against the
+# reference as it runs (LSODA at rtol = atol ~ 1.5e-8), 1e-7 + 1e-7 |ref| against the same reference code run with a
+# tight integrator (rtol = atol = 1e-12; observed <= 6e-8, median 3e-12).  At 9 of the ~7 500 golden points the
+# reference's OWN two runs differ by more than the contract (up to 1.4e-5 relative: LSODA noise); the fixtures
+# enumerate them (`*lsoda_noise_idx`, tests/golden/make_golden.py make_tight) and they are judged against the tight
+# value only.
+REF_ATOL, REF_RTOL = 1.0e-5, 2.0e-6
 TIGHT_ATOL, TIGHT_RTOL = 1.0e-7, 1.0e-7
+# model light curves at every (decimated) grid point: SURVEY.md 8(c)'s rtol 1e-6 against the tight-integrator run; the
+# default-integrator curves carry up to 2.2e-6 of LSODA noise themselves (L ~ omega^4), stated bound 5e-6
+LC_TIGHT_RTOL, LC_REF_RTOL = 1.0e-6, 5.0e-6
+
+
+def noise_mask(g, n, key="lsoda_noise_idx"):
+    """Boolean mask of the fixture's enumerated LSODA-noise points."""
+    m = np.zeros(n, dtype=bool)
+    m[np.asarray(g[key], dtype=int)] = True
+    return m
+
+
+def assert_vs_reference(out, ref, ok, tight=None, noise=None):
+    """out against the reference's values at the points `ok`: the default-integrator contract everywhere but at the
+    enumerated noise points, the tight-integrator bound wherever a tight value exists (it must at every noise point)."""
+    out, ref = np.asarray(out), np.asarray(ref)
+    plain = ok if noise is None else ok & ~noise
+    d = np.abs(out[plain] - ref[plain])
+    lim = REF_ATOL + REF_RTOL * np.abs(ref[plain])
+    assert np.all(d <= lim), f"worst {np.max(d / lim):.2f} x the default-LSODA contract at {np.nonzero(plain)[0][np.argmax(d / lim)]}"
+    if tight is not None:
+        m = ok & np.isfinite(tight)
+        d = np.abs(out[m] - tight[m])
+        lim = TIGHT_ATOL + TIGHT_RTOL * np.abs(tight[m])
+        assert np.all(d <= lim), f"worst {np.max(d / lim):.2f} x the tight-LSODA bound at {np.nonzero(m)[0][np.argmax(d / lim)]}"
+        if noise is not None:
+            assert np.all(np.isfinite(tight[ok & noise]))
+    else:
+        assert noise is None or not np.any(ok & noise)
 
 
 def pytest_configure(config):

@@ -21,6 +21,9 @@ What is called (paths relative to /root/reference):
 removed; see tight_lsoda).
 Outputs: golden_synth.npz, golden_lib.npz, golden_flagscan.npz, golden_corners.npz, golden_libscan.npz, golden_longlc.npz,
 golden_flagscan2.npz, golden_libscan2.npz, golden_rhs.npz, golden_libkw.npz, MANIFEST.json.
+`--only tight` (make_tight) adds to the scan fixtures the tight-integrator value of EVERY successful point and the
+enumerated LSODA-noise points (`*lsoda_noise_idx`): where the reference's default run is itself off by more than the
+SURVEY.md 8(c) contract 1e-5 + 2e-6 |ref|.
 """
 import argparse
 import contextlib
@@ -92,6 +95,137 @@ def tight_lsoda(tol=1.0e-12, mxstep=100000):
         yield
     finally:
         sf.odeint = orig
+
+
+@contextlib.contextmanager
+def tight_lsoda_lib(tol=1.0e-12, mxstep=100000):
+    """The same for the library variant: magnetar/funcs.py:150-151 calls the odeint its module imported."""
+    mod = sys.modules["magnetar.funcs"]
+    orig = mod.odeint
+
+    def wrapped(func, y0, t, **kw):
+        kw.update(rtol=tol, atol=tol, mxstep=mxstep)
+        return orig(func, y0, t, **kw)
+    mod.odeint = wrapped
+    try:
+        yield
+    finally:
+        mod.odeint = orig
+
+
+# SURVEY.md 8(c) contract against the reference at its DEFAULT integrator tolerance: |d| <= 1e-5 + 2e-6 |ref|.
+# Where the reference's own two runs (default vs rtol = atol = 1e-12) differ by more than 0.9 of that, the default value
+# is LSODA noise: such points are enumerated per fixture (`*lsoda_noise_idx`) and the tests judge them against the tight
+# value only (every point with a tight value is held to 1e-7 + 1e-7 |tight| anyway).
+REF_ATOL, REF_RTOL = 1.0e-5, 2.0e-6
+
+
+def noise_idx(default, tight):
+    default, tight = np.asarray(default, float), np.asarray(tight, float)
+    both = np.isfinite(default) & np.isfinite(tight)
+    bad = both & (np.abs(default - tight) > 0.9 * (REF_ATOL + REF_RTOL * np.abs(default)))
+    return np.nonzero(bad)[0].astype(np.int32)
+
+
+def _tight_synth_one(job):
+    p, x, y, yerr = job
+    with tight_lsoda():
+        return synth_lnprob(p, x, y, yerr)[0]
+
+
+def _tight_lib_one(job):
+    p, x, y, yerr, kind = job
+    with tight_lsoda_lib():
+        return _libscan_one((p, x, y, yerr, kind))[0]
+
+
+def _tight_lib_lnlike_one(job):
+    import pandas as pd
+    row, x, y, yerr, kind = job
+    p = row[np.isfinite(row)]
+    with tight_lsoda_lib():
+        return lib.lnlike(p, pd.DataFrame({"t": x, "Lum50": y, "Lum50err": yerr}), kind)
+
+
+def _resave(name, extra):
+    path = os.path.join(HERE, name)
+    g = dict(np.load(path))
+    g.update(extra)
+    np.savez_compressed(path, **g)
+
+
+def make_tight():
+    """Second pass over the scan fixtures: the reference re-run with a tight integrator at EVERY successful point
+    (`*_tight`), and the enumerated LSODA-noise points of each fixture.  Existing arrays are kept as they are."""
+    import multiprocessing as mp
+    os.chdir(REF)
+    report = {}
+    with mp.Pool(8) as pool:
+        def tight_synth(P, st, sets, ds=None):
+            jobs = [(P[i], *(sets[ds[i]] if ds is not None else sets)) for i in range(len(P)) if st[i] == 0]
+            out = np.full(len(P), np.nan)
+            out[st == 0] = pool.map(_tight_synth_one, jobs, chunksize=8)
+            return np.where(np.isfinite(out), out, np.nan)       # a point the tight run flags: no tight value
+        # golden_synth: tight values exist; lists per type
+        g = np.load(os.path.join(HERE, "golden_synth.npz"))
+        extra = {}
+        for name in TYPES:
+            extra[f"{name}_lsoda_noise_idx"] = noise_idx(g[f"{name}_lnprob"], g[f"{name}_lnprob_tight"])
+            report[f"synth/{name}"] = len(extra[f"{name}_lsoda_noise_idx"])
+        with tight_lsoda():                                   # light curves: canonical sets and the prior-wide ones
+            for name in TYPES:
+                extra[f"{name}_lc_tight"] = sf.model_lum(np.array(GRB_PARS[name]))[:, ::DECIM]
+            extra["wide_lc_tight"] = np.array([quiet(sf.model_lum, p)[1:, ::DECIM] for p in g["wide_pars_physical"]])
+        _resave("golden_synth.npz", extra)
+        # prior-wide scans, Humped then the other three datasets
+        g = np.load(os.path.join(HERE, "golden_flagscan.npz"))
+        hs = synth_dataset("Humped", SEED0)[1:]
+        t = tight_synth(g["pars"], g["status"], hs)
+        keep = np.isfinite(g["lnprob_tight"])
+        assert np.array_equal(t[keep], g["lnprob_tight"][keep])   # the 400 values of the first pass reproduce
+        _resave("golden_flagscan.npz", {"lnprob_tight": t, "lsoda_noise_idx": noise_idx(g["lnprob"], t)})
+        report["flagscan"] = int(len(noise_idx(g["lnprob"], t)))
+        g = np.load(os.path.join(HERE, "golden_flagscan2.npz"))
+        sets = [synth_dataset(nm, SEED0 + 1 + i)[1:] for i, nm in enumerate(["Classic", "Sloped", "Stuttering"])]
+        t = tight_synth(g["pars"], g["status"], sets, g["ds"])
+        _resave("golden_flagscan2.npz", {"lnprob_tight": t, "lsoda_noise_idx": noise_idx(g["lnprob"], t)})
+        report["flagscan2"] = int(len(noise_idx(g["lnprob"], t)))
+        g = np.load(os.path.join(HERE, "golden_corners.npz"))
+        t = tight_synth(g["pars"], g["status"], hs)
+        _resave("golden_corners.npz", {"lnprob_tight": t, "lsoda_noise_idx": noise_idx(g["lnprob"], t)})
+        report["corners"] = int(len(noise_idx(g["lnprob"], t)))
+        g = np.load(os.path.join(HERE, "golden_longlc.npz"))
+        extra = {}
+        for n in (112, 410, 1944):
+            extra[f"synth{n}_lsoda_noise_idx"] = noise_idx(g[f"synth{n}_lnprob"], g[f"synth{n}_lnprob_tight"])
+            report[f"longlc/synth{n}"] = len(extra[f"synth{n}_lsoda_noise_idx"])
+        x, y, yerr = g["libS1944_ds"]
+        t = np.array(pool.map(_tight_lib_lnlike_one, [(np.asarray(p, float), x, y, yerr, "S") for p in g["libS1944_pars"]]))
+        extra["libS1944_lnlike_tight"] = t
+        extra["libS1944_lsoda_noise_idx"] = noise_idx(g["libS1944_lnlike"], t)
+        report["longlc/libS1944"] = len(extra["libS1944_lsoda_noise_idx"])
+        _resave("golden_longlc.npz", extra)
+        # library variant: scans on both grids, the 6/7/8/9-parameter likelihoods
+        gl = np.load(os.path.join(HERE, "golden_lib.npz"))
+        for fname, kind in (("golden_libscan.npz", "L"), ("golden_libscan2.npz", "S")):
+            g = np.load(os.path.join(HERE, fname))
+            x, y, yerr = gl["ds_" + kind]
+            st = g["status"]
+            t = np.full(len(st), np.nan)
+            t[st == 0] = pool.map(_tight_lib_one, [(p, x, y, yerr, kind) for p, s_ in zip(g["pars_physical"], st) if s_ == 0], chunksize=8)
+            t = np.where(np.isfinite(t), t, np.nan)
+            _resave(fname, {"lnlike_tight": t, "lsoda_noise_idx": noise_idx(g["lnlike"], t)})
+            report[fname] = int(len(noise_idx(g["lnlike"], t)))
+        extra = {}
+        for kind in ("L", "S"):
+            x, y, yerr = gl["ds_" + kind]
+            t = np.array(pool.map(_tight_lib_lnlike_one, [(row, x, y, yerr, kind) for row in gl[f"lnlike_{kind}_pars"]]))
+            extra[f"lnlike_{kind}_tight"] = t
+            extra[f"lnlike_{kind}_lsoda_noise_idx"] = noise_idx(gl[f"lnlike_{kind}"], t)
+            report[f"lib/lnlike_{kind}"] = len(extra[f"lnlike_{kind}_lsoda_noise_idx"])
+        _resave("golden_lib.npz", extra)
+    print("LSODA-noise points per fixture:", report)
+    return report
 
 
 def synth_lnprob(p, x, y, yerr):
@@ -466,7 +600,7 @@ def make_longlc():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--flag-scan", type=int, default=1500)
-    ap.add_argument("--only", choices=["all", "lib", "libkw", "corners", "libscan", "longlc", "flagscan2", "libscan2", "rhs"], default="all", help="regenerate only one file")
+    ap.add_argument("--only", choices=["all", "lib", "libkw", "corners", "libscan", "longlc", "flagscan2", "libscan2", "rhs", "tight"], default="all", help="regenerate only one file")
     a = ap.parse_args()
     import scipy, pandas
     if a.only == "all":
@@ -488,6 +622,7 @@ def main():
         make_libscan2()
     if a.only in ("all", "rhs"):
         make_rhs()
+    noise_report = make_tight() if a.only in ("all", "tight") else None
     manifest = {
         "generator": "tests/golden/make_golden.py",
         "reference": "sgibson91/magprop mounted at /root/reference (magnetar v%s)" % lib.__version__
@@ -496,6 +631,10 @@ def main():
                      "pandas": pandas.__version__},
         "seed0": SEED0, "decimation": DECIM, "flag_scan_n": a.flag_scan,
     }
+    old = {}
+    if os.path.exists(os.path.join(HERE, "MANIFEST.json")):
+        old = json.load(open(os.path.join(HERE, "MANIFEST.json")))
+    manifest["lsoda_noise_points"] = noise_report if noise_report is not None else old.get("lsoda_noise_points")
     with open(os.path.join(HERE, "MANIFEST.json"), "w") as f:
         json.dump(manifest, f, indent=1)
 
