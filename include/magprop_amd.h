@@ -94,10 +94,23 @@ typedef struct mp_model_cfg {
     double f_beam;             /* default beaming fraction     (overridden per walker when ndim is 7 or 9)              */
     double nacc_lum_threshold; /* luminosity-stage break-up test: 0.27 (synth funcs.py:206) | 0.0 (magnetar/funcs.py:193) */
     int32_t lprop_gm_term;     /* 1: Lprop includes -(GM/Rm)*eta2*Mdisc/tvisc (synth funcs.py:222-223); 0: lib          */
-    int32_t reserved;
+    int32_t max_stride;        /* grid intervals a step of the solver may span: 0 = MP_MAX_STRIDE_DEFAULT (4), or 1, 2, 4.   */
+                               /* 1 = every grid interval is a step (the serial restatement oracle/mp_oracle.c mode 0)       */
     double sweep_tol;          /* relative change of omega at the step ends that ends the Newton sweeps of a tile of the   */
                                /* time-parallel solver; 0 = MP_SWEEP_TOL_DEFAULT.  What it buys and costs: DESIGN.md 3     */
+    double stride_tol;         /* smoothness indicator h |4th difference of (f - lambda omega)| / omega above which a tile   */
+                               /* stepping over 2 or 4 grid intervals is cut back to single intervals; 0 =                   */
+                               /* MP_STRIDE_TOL_DEFAULT                                                                      */
 } mp_model_cfg;
+
+/* Stride adaptivity of the solver: where the solution is smooth on the scale of the output grid the
+ * order-5 formula steps over 2 or 4 grid intervals at once and the states at the skipped grid points come from the cubic
+ * Hermite interpolant of the step (<= 1e-11 relative); tiles that contain a kink of the right-hand side (Alfven-radius
+ * cap, torque arm) or a fast transient are redone over single intervals.  Measured on the 6 256 golden prior-wide points:
+ * same maximum deviation from the reference's tight-integrator values as with max_stride = 1 (5e-8), 13 instead of 40
+ * tiles per walker. */
+#define MP_MAX_STRIDE_DEFAULT 4
+#define MP_STRIDE_TOL_DEFAULT 1.0e-7
 
 /* The sweeps contract by 1e-2..1e-3 per pass, so a tile whose last correction was <= 1e-7 relative is converged to
  * <= 4.5e-9 relative in lnprob (measured over the golden clouds and the prior-wide scans, tools/tol_scan.py) — 10x below
@@ -249,8 +262,12 @@ void *mp_stream(const mp_handle *h); /* the handle's own hipStream_t */
 int mp_n_grid(const mp_handle *h);
 /* mean Newton sweeps per tile of the most recent host-buffer batch (diagnostic) */
 double mp_last_mean_sweeps(const mp_handle *h);
+/* mean number of tiles solved per walker (kept or redone) in that batch: 40 / 79 with max_stride = 1 (4 / 2 steps per lane) */
+double mp_last_mean_tiles(const mp_handle *h);
 /* total Newton sweeps of every walker of that batch (all tiles; 0 for walkers that never started); returns the count copied */
 int mp_last_sweeps(const mp_handle *h, int32_t *out, int n);
+/* tiles solved (kept or redone) by every walker of that batch; returns the count copied */
+int mp_last_tiles(const mp_handle *h, int32_t *out, int n);
 double mp_sweep_tol(const mp_handle *h); /* the tolerance in force (cfg.sweep_tol or the default) */
 int mp_n_simd(const mp_handle *h);       /* SIMDs of the handle's device: batch-size thresholds of the kernel variants */
 

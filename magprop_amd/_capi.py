@@ -22,10 +22,10 @@ MAX_DATASETS = 64
 EXPORTS = (
     "mp_abi_version", "mp_last_error", "mp_cfg_synth", "mp_cfg_lib", "mp_create", "mp_destroy",
     "mp_set_dataset", "mp_set_prior", "mp_lnprob_batch", "mp_lnprob_batch_dev", "mp_model_lc", "mp_rhs_batch",
-    "mp_synchronize", "mp_device", "mp_stream", "mp_n_grid", "mp_last_mean_sweeps",
+    "mp_synchronize", "mp_device", "mp_stream", "mp_n_grid", "mp_last_mean_sweeps", "mp_last_mean_tiles",
     "mp_sampler_create", "mp_sampler_destroy", "mp_sampler_set_positions", "mp_sampler_run", "mp_sampler_get_state",
     "mp_sampler_get_bad", "mp_sampler_n_slots", "mp_sampler_row_doubles", "mp_sampler_halfstep_shard",
-    "mp_sampler_halfstep_apply", "mp_sampler_state_ptrs", "mp_sweep_tol", "mp_n_simd", "mp_last_sweeps",
+    "mp_sampler_halfstep_apply", "mp_sampler_state_ptrs", "mp_sweep_tol", "mp_n_simd", "mp_last_sweeps", "mp_last_tiles",
 )
 ABI_VERSION = 3
 
@@ -39,7 +39,7 @@ class ModelCfg(C.Structure):
     _fields_ = [(n, C.c_double) for n in (
         "inertia_factor", "rm_massflow_factor", "n_ode", "n_lum", "alpha", "cs7", "k",
         "dipeff", "propeff", "f_beam", "nacc_lum_threshold")] + [
-        ("lprop_gm_term", C.c_int32), ("reserved", C.c_int32), ("sweep_tol", C.c_double)]
+        ("lprop_gm_term", C.c_int32), ("max_stride", C.c_int32), ("sweep_tol", C.c_double), ("stride_tol", C.c_double)]
 
 
 def build(force=False, verbose=False):
@@ -134,11 +134,15 @@ def lib():
     L.mp_sampler_get_state.argtypes = [vp, dp, dp, i64p, i64p]
     L.mp_last_mean_sweeps.argtypes = [vp]
     L.mp_last_mean_sweeps.restype = C.c_double
+    L.mp_last_mean_tiles.argtypes = [vp]
+    L.mp_last_mean_tiles.restype = C.c_double
     L.mp_sweep_tol.argtypes = [vp]
     L.mp_sweep_tol.restype = C.c_double
     L.mp_n_simd.argtypes = [vp]
     L.mp_last_sweeps.argtypes = [vp, ip, C.c_int]
     L.mp_last_sweeps.restype = C.c_int
+    L.mp_last_tiles.argtypes = [vp, ip, C.c_int]
+    L.mp_last_tiles.restype = C.c_int
     L.mp_sampler_get_bad.argtypes = [vp, C.c_int64, dp, C.c_int, i64p, i64p]
     L.mp_sampler_n_slots.argtypes = [vp]
     L.mp_sampler_row_doubles.argtypes = [vp]
@@ -173,12 +177,15 @@ def check(rc, what):
 SWEEP_TOL_DEFAULT, SWEEP_TOL_STRICT = 1.0e-7, 1.0e-9   # include/magprop_amd.h MP_SWEEP_TOL_*
 DEFAULT_SWEEP_TOL = 0.0   # what cfg_synth()/cfg_lib() put into mp_model_cfg.sweep_tol (0 = the library default); the test
                           # suite sets SWEEP_TOL_STRICT here for its kernel-vs-serial-restatement comparisons
+DEFAULT_MAX_STRIDE = 0    # likewise mp_model_cfg.max_stride (0 = the library default, adaptive up to 4 grid intervals per
+                          # step); the strict test mode sets 1: every grid interval a step, the scheme of the serial restatement
 
 
 def cfg_synth(**kw):
     c = ModelCfg()
     lib().mp_cfg_synth(C.byref(c))
     c.sweep_tol = DEFAULT_SWEEP_TOL
+    c.max_stride = DEFAULT_MAX_STRIDE
     for k, v in kw.items():
         setattr(c, k, v)
     return c
@@ -188,6 +195,7 @@ def cfg_lib(**kw):
     c = ModelCfg()
     lib().mp_cfg_lib(C.byref(c))
     c.sweep_tol = DEFAULT_SWEEP_TOL
+    c.max_stride = DEFAULT_MAX_STRIDE
     for k, v in kw.items():
         setattr(c, k, v)
     return c
@@ -308,10 +316,21 @@ class Handle:
     def last_mean_sweeps(self):
         return self._L.mp_last_mean_sweeps(self._h)
 
+    @property
+    def last_mean_tiles(self):
+        """Tiles solved per walker in the most recent host-buffer batch (kept or redone)."""
+        return self._L.mp_last_mean_tiles(self._h)
+
     def last_sweeps(self, n):
         """Total Newton sweeps (over all tiles) of each of the first n walkers of the most recent host-buffer batch."""
         out = np.zeros(n, dtype=np.int32)
         m = self._L.mp_last_sweeps(self._h, _iptr(out), int(n))
+        return out[:max(m, 0)]
+
+    def last_tiles(self, n):
+        """Tiles solved (kept or redone) by each of the first n walkers of the most recent host-buffer batch."""
+        out = np.zeros(n, dtype=np.int32)
+        m = self._L.mp_last_tiles(self._h, _iptr(out), int(n))
         return out[:max(m, 0)]
 
     @property
@@ -320,6 +339,6 @@ class Handle:
 
     @property
     def n_simd(self):
-        """SIMDs of the device: batches up to n_simd/2 walkers run the producer/consumer pair, up to n_simd the
-        4-steps-per-lane kernel, larger ones the 2-steps-per-lane kernel (mp_device.h)."""
+        """SIMDs of the device: batches up to n_simd walkers run the 4-steps-per-lane kernel, larger ones the
+        2-steps-per-lane kernel (mp_device.h)."""
         return self._L.mp_n_simd(self._h)

@@ -111,6 +111,7 @@ struct mp_handle {
     HostDataset ds[MP_MAX_DATASETS];
     mp::DevShared sh{};
     // device copies of the shared data
+    DevBuf<double> d_wtab;
     DevBuf<double> d_tgrid, d_obs_dx, d_obs_idt, d_obs_y, d_obs_yerr;
     DevBuf<int32_t> d_obs_g, d_tile_ptr;
     DevBuf<mp::DsDesc> d_ds;
@@ -121,11 +122,12 @@ struct mp_handle {
     // workspace of the host-buffer entry points
     DevBuf<double> w_pars, w_lnprob, w_curves;
     DevBuf<int32_t> w_dsid, w_status, w_sweeps;
+    double last_mean_tiles = 0.0;
     DevBuf<unsigned char> w_io;   // mp_lnprob_batch: [pars | ds_id] in, [lnprob | status | sweeps] out, one copy each way
     PinnedBuf h_io;
     DevBuf<double> w_scratch;   // DevShared::obs_scratch (only allocated once a light curve longer than 64 points is set)
     double last_mean_sweeps = 0.0;
-    std::vector<int32_t> last_sweeps;   // per walker, most recent host-buffer batch (diagnostic)
+    std::vector<int32_t> last_sweeps, last_tiles;   // per walker, most recent host-buffer batch (diagnostic)
     // Threading / stream contract (include/magprop_amd.h): every entry point that takes a handle or a sampler holds
     // `mu` for its duration.  The scratch rows are indexed by walker, so two launches that use them must not overlap:
     // each records `scratch_done` on its stream and the next one, if it runs on another stream, waits for it there.
@@ -242,12 +244,12 @@ const char *mp_last_error(void) { return g_err.c_str(); }
 
 void mp_cfg_synth(mp_model_cfg *c) {
     if (!c) return;
-    *c = mp_model_cfg{0.35, 3.0, 10.0, 10.0, 0.1, 1.0, 0.9, 1.0, 1.0, 1.0, 0.27, 1, 0, 0.0};
+    *c = mp_model_cfg{0.35, 3.0, 10.0, 10.0, 0.1, 1.0, 0.9, 1.0, 1.0, 1.0, 0.27, 1, 0, 0.0, 0.0};
 }
 
 void mp_cfg_lib(mp_model_cfg *c) {
     if (!c) return;
-    *c = mp_model_cfg{0.8, 1.0, 1.0, 1.0, 0.1, 1.0, 0.9, 0.05, 0.4, 1.0, 0.0, 0, 0, 0.0};
+    *c = mp_model_cfg{0.8, 1.0, 1.0, 1.0, 0.1, 1.0, 0.9, 0.05, 0.4, 1.0, 0.0, 0, 0, 0.0, 0.0};
 }
 
 mp_handle *mp_create(const mp_model_cfg *cfg, const double *tgrid, int n_grid, int device) {
@@ -267,9 +269,10 @@ mp_handle *mp_create(const mp_model_cfg *cfg, const double *tgrid, int n_grid, i
         fail(MP_EINVAL, "mp_create: tgrid must be positive");
         return nullptr;
     }
+    // the kernels generate the step end times themselves, t_i = t_0 q^i: the grid has to be geometric to rounding
     for (int i = 1; i < n_grid; ++i)
-        if (std::fabs(tgrid[i] / (tgrid[i - 1] * q) - 1.0) > 1.0e-9) {
-            fail(MP_EINVAL, "mp_create: tgrid must be log-spaced (np.logspace); ratio breaks at index %d", i);
+        if (std::fabs(tgrid[i] / (tgrid[0] * std::exp((double)i * std::log(q))) - 1.0) > 1.0e-12) {
+            fail(MP_EINVAL, "mp_create: tgrid must be log-spaced (np.logspace); it leaves t0*q^i at index %d", i);
             return nullptr;
         }
     if (!(cfg->inertia_factor > 0) || !(cfg->alpha > 0) || !(cfg->cs7 > 0) || !(cfg->k > 0) ||
@@ -279,6 +282,11 @@ mp_handle *mp_create(const mp_model_cfg *cfg, const double *tgrid, int n_grid, i
     }
     if (!(cfg->sweep_tol >= 0.0) || cfg->sweep_tol > 1.0e-3) {
         fail(MP_EINVAL, "mp_create: cfg.sweep_tol must be 0 (library default) or in (0, 1e-3]");
+        return nullptr;
+    }
+    if (!(cfg->stride_tol >= 0.0) || cfg->stride_tol > 1.0e-3 ||
+        !(cfg->max_stride == 0 || cfg->max_stride == 1 || cfg->max_stride == 2 || cfg->max_stride == 4)) {
+        fail(MP_EINVAL, "mp_create: cfg.max_stride must be 0, 1, 2 or 4 and cfg.stride_tol 0 or in (0, 1e-3]");
         return nullptr;
     }
     int count = 0;
@@ -330,47 +338,87 @@ mp_handle *mp_create(const mp_model_cfg *cfg, const double *tgrid, int n_grid, i
     s.sqrtR = std::sqrt(mp::kR);
     s.crm_unit = std::pow(1.0e15 * mp::kR * mp::kR * mp::kR, 4.0 / 7.0) * std::pow(s.GM, -1.0 / 7.0) *
                  std::pow(cfg->rm_massflow_factor, -2.0 / 7.0);
-    s.q = q;
+    s.t0 = tgrid[0];
+    const double lnq = std::log(tgrid[n_grid - 1] / tgrid[0]) / (double)(n_grid - 1);
+    s.lnq8 = lnq / 8.0;
+    s.pre_fine = std::min(32, n_grid - 1);                         // oracle/mp_oracle.c MPO_PRE_FINE
     s.sweep_tol = cfg->sweep_tol > 0.0 ? cfg->sweep_tol : MP_SWEEP_TOL_DEFAULT;
+    s.stride_tol = cfg->stride_tol > 0.0 ? cfg->stride_tol : MP_STRIDE_TOL_DEFAULT;
+    {
+        int ms = cfg->max_stride > 0 ? cfg->max_stride : MP_MAX_STRIDE_DEFAULT;
+        if (const char *e = std::getenv("MAGPROP_AMD_MAX_STRIDE")) {   // experiments only
+            const int v = std::atoi(e);
+            if (v == 1 || v == 2 || v == 4) ms = v;
+        }
+        s.max_kind = ms == 1 ? 1 : (ms == 2 ? 2 : 3);
+    }
     s.n_simd = std::max(1, prop.multiProcessorCount) * 4;         // 4 SIMDs per CU (1 024 on MI355X)
     s.force_spl = 0;
     if (const char *e = std::getenv("MAGPROP_AMD_SPL")) {          // experiments only
         const int v = std::atoi(e);
         if (v == 2 || v == 4) s.force_spl = v;
     }
-    s.force_pc = 0;
-    if (const char *e = std::getenv("MAGPROP_AMD_PC")) {           // experiments only
-        const int v = std::atoi(e);
-        if (v == 1 || v == -1) s.force_pc = v;
-    }
     if (const char *e = std::getenv("MAGPROP_AMD_SWEEP_TOL")) {   // experiments only
         const double v = std::atof(e);
         if (v > 0.0 && v < 1.0) s.sweep_tol = v;
+    }
+    if (const char *e = std::getenv("MAGPROP_AMD_STRIDE_TOL")) {  // experiments only
+        const double v = std::atof(e);
+        if (v > 0.0 && v < 1.0e-3) s.stride_tol = v;
     }
     s.ultra_tol = std::min(1.0e-5, 100.0 * s.sweep_tol);
     if (const char *e = std::getenv("MAGPROP_AMD_ULTRA_TOL")) {   // experiments only (0 disables); kept inside [0, 1e-4]
         const double v = std::atof(e);
         if (v >= 0.0 && v <= 1.0e-4) s.ultra_tol = v;
     }
-    s.inv_q = 1.0 / q;
-    {   // exponential Adams-Moulton quadrature matrix for nodes t_{j+1}, t_j, t_{j-1}, t_{j-2}:
-        // W[k][m] = m! * [theta^m] l_k(theta), l_k the Lagrange basis on theta = 1, 0, -1/q, -(1/q + 1/q^2)
-        const double x[4] = {1.0, 0.0, -1.0 / q, -(1.0 / q + 1.0 / (q * q))};
-        const double fact[4] = {1.0, 1.0, 2.0, 6.0};
-        for (int k = 0; k < 4; ++k) {
-            double co[4] = {1.0, 0.0, 0.0, 0.0};
+    // Constants of the four tile kinds: steps over 1/8, 1, 2, 4 grid intervals (mp_device.h StrideK).
+    // Quadrature matrices of the exponential Adams-Moulton formulas on nodes t_{j+1}, t_j, t_{j-1}, ... of a geometric
+    // grid of ratio Q (in units of the step, origin t_j: 1, 0, -1/Q, -(1/Q + 1/Q^2), ...):
+    // W[k][m] = m! * [theta^m] l_k(theta), l_k the Lagrange basis on the nodes.
+    auto quad_weights = [](double Q, int K, double *W) {
+        double x[8];
+        x[0] = 1.0; x[1] = 0.0;
+        { double acc = 0.0, f = 1.0; for (int k = 2; k < K; ++k) { f /= Q; acc -= f; x[k] = acc; } }
+        for (int k = 0; k < K; ++k) {
+            double co[8] = {1.0, 0, 0, 0, 0, 0, 0, 0};
             int deg = 0;
             double denom = 1.0;
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < K; ++j) {
                 if (j == k) continue;
                 for (int m = deg + 1; m >= 1; --m) co[m] = co[m - 1] - x[j] * co[m];
                 co[0] = -x[j] * co[0];
                 ++deg;
                 denom *= x[k] - x[j];
             }
-            for (int m = 0; m < 4; ++m) s.eamW[k][m] = fact[m] * co[m] / denom;
+            double fact = 1.0;
+            for (int m = 0; m < K; ++m) { if (m > 1) fact *= (double)m; W[k * K + m] = fact * co[m] / denom; }
         }
+    };
+    std::vector<double> wtab(4 * (size_t)mp::kWtabStride, 0.0);
+    for (int kind = 0; kind < 4; ++kind) {
+        mp::StrideK &K = s.sk[kind];
+        const double lnQ = kind == 0 ? lnq / 8.0 : lnq * (double)(1 << (kind - 1));
+        K.lnQ = lnQ;
+        K.inv_Q = std::exp(-lnQ);
+        K.one_m_invQ = -std::expm1(-lnQ);
+        const int ns = kind == 0 ? 1 : (1 << (kind - 1));
+        for (int i = 0; i < 4; ++i) K.theta[i] = (i < ns && ns > 1) ? std::expm1(lnq * (double)i) / std::expm1(lnQ) : 0.0;
+        double W4[16], W5[25];
+        quad_weights(std::exp(lnQ), 4, W4);
+        quad_weights(std::exp(lnQ), 5, W5);
+        double *T = wtab.data() + (size_t)kind * mp::kWtabStride;
+        for (int k = 0; k < 5; ++k)
+            for (int m = 0; m < 5; ++m) T[6 * k + m] = W5[k * 5 + m];
+        for (int k = 0; k < 4; ++k)
+            for (int m = 0; m < 4; ++m) T[mp::kWtabW4 + 4 * m + k] = W4[k * 4 + m];
     }
+    if (h->d_wtab.ensure(wtab.size()) != MP_OK ||
+        hipMemcpy(h->d_wtab.p, wtab.data(), wtab.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
+        fail(MP_EHIP, "mp_create: cannot upload the quadrature tables");
+        mp_destroy(h);
+        return nullptr;
+    }
+    s.wtab = h->d_wtab.p;
     if (rebuild_datasets(h) != MP_OK) {
         mp_destroy(h);
         return nullptr;
@@ -382,6 +430,7 @@ int mp_destroy(mp_handle *h) {
     if (!h) return MP_OK;
     DeviceScope scope(h->device);
     (void)hipDeviceSynchronize();
+    h->d_wtab.release();
     h->d_tgrid.release(); h->d_obs_dx.release(); h->d_obs_idt.release(); h->d_obs_y.release();
     h->d_obs_yerr.release(); h->d_obs_g.release(); h->d_tile_ptr.release(); h->d_ds.release();
     h->w_pars.release(); h->w_lnprob.release(); h->w_curves.release();
@@ -490,7 +539,7 @@ int mp_lnprob_batch(mp_handle *h, const double *pars, const int32_t *ds_id, int 
     // one staging block each way: [pars n*ndim f64 | ds_id n i32] in, [lnprob n f64 | status n i32 | sweeps n i32] out
     const size_t in_pars = sizeof(double) * (size_t)n * ndim, in_ids = ds_id ? sizeof(int32_t) * (size_t)n : 0;
     const size_t in_bytes = (in_pars + in_ids + 7) & ~(size_t)7;
-    const size_t out_bytes = (sizeof(double) + 2 * sizeof(int32_t)) * (size_t)n;
+    const size_t out_bytes = (sizeof(double) + 4 * sizeof(int32_t)) * (size_t)n;   // lnprob | status | sweeps | tiles (+ pad)
     if ((rc = h->w_io.ensure(in_bytes + out_bytes)) || (rc = h->h_io.ensure(in_bytes + out_bytes)) ||
         (ltot_out && (rc = h->w_curves.ensure((size_t)n * ng))) || (rc = ensure_scratch(h, n)))
         return rc;
@@ -509,6 +558,7 @@ int mp_lnprob_batch(mp_handle *h, const double *pars, const int32_t *ds_id, int 
     a.lnprob = (double *)d_out;
     a.status = (int32_t *)(d_out + sizeof(double) * (size_t)n);
     a.sweeps = a.status + n;
+    a.tiles = a.sweeps + n;
     a.ltot = ltot_out ? h->w_curves.p : nullptr;   // rows of walkers that fail are NaN-filled by the kernel
     if ((rc = launch_lnprob_ordered(h, a, st))) return rc;
     HIP_TRY(hipMemcpyAsync(h_out, d_out, out_bytes, hipMemcpyDeviceToHost, st));
@@ -516,16 +566,16 @@ int mp_lnprob_batch(mp_handle *h, const double *pars, const int32_t *ds_id, int 
         HIP_TRY(hipMemcpyAsync(ltot_out, h->w_curves.p, sizeof(double) * (size_t)n * ng, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     std::memcpy(lnprob_out, h_out, sizeof(double) * (size_t)n);
-    const int32_t *status = (const int32_t *)(h_out + sizeof(double) * (size_t)n), *sweeps = status + n;
+    const int32_t *status = (const int32_t *)(h_out + sizeof(double) * (size_t)n), *sweeps = status + n, *tiles = sweeps + n;
     if (status_out) std::memcpy(status_out, status, sizeof(int32_t) * (size_t)n);
-    double tot = 0.0;
+    double tot = 0.0, tot_tiles = 0.0;
     int cnt = 0;
     h->last_sweeps.assign(sweeps, sweeps + n);
+    h->last_tiles.assign(tiles, tiles + n);
     for (int i = 0; i < n; ++i)
-        if (status[i] == MP_STATUS_OK) { tot += sweeps[i]; ++cnt; }
-    const int ktile = mp::kTile * (h->sh.force_spl ? h->sh.force_spl : mp::kernel_spl(h->sh, n));
-    const int kernel_tiles = ((int)h->tgrid.size() - 1 + ktile - 1) / ktile;
-    h->last_mean_sweeps = cnt ? tot / ((double)cnt * kernel_tiles) : 0.0;
+        if (status[i] == MP_STATUS_OK) { tot += sweeps[i]; tot_tiles += tiles[i]; ++cnt; }
+    h->last_mean_sweeps = tot_tiles > 0.0 ? tot / tot_tiles : 0.0;
+    h->last_mean_tiles = cnt ? tot_tiles / (double)cnt : 0.0;
     return MP_OK;
 }
 
@@ -972,10 +1022,17 @@ int mp_device(const mp_handle *h) { return h ? h->device : -1; }
 void *mp_stream(const mp_handle *h) { return h ? (void *)h->stream : nullptr; }
 int mp_n_grid(const mp_handle *h) { return h ? (int)h->tgrid.size() : 0; }
 double mp_last_mean_sweeps(const mp_handle *h) { return h ? h->last_mean_sweeps : 0.0; }
+double mp_last_mean_tiles(const mp_handle *h) { return h ? h->last_mean_tiles : 0.0; }
 int mp_last_sweeps(const mp_handle *h, int32_t *out, int n) {
     if (!h || !out || n < 0) return fail(MP_EINVAL, "mp_last_sweeps: bad argument");
     const int m = std::min<int>(n, (int)h->last_sweeps.size());
     std::copy(h->last_sweeps.begin(), h->last_sweeps.begin() + m, out);
+    return m;
+}
+int mp_last_tiles(const mp_handle *h, int32_t *out, int n) {
+    if (!h || !out || n < 0) return fail(MP_EINVAL, "mp_last_tiles: bad argument");
+    const int m = std::min<int>(n, (int)h->last_tiles.size());
+    std::copy(h->last_tiles.begin(), h->last_tiles.begin() + m, out);
     return m;
 }
 double mp_sweep_tol(const mp_handle *h) { return h ? h->sh.sweep_tol : 0.0; }

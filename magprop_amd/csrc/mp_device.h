@@ -6,7 +6,8 @@
 
 namespace mp {
 
-constexpr int kTile = 64;  // observation bucket size in time steps (the kernels' tiles are 64*SPL steps)
+constexpr int kTile = 64;    // observation bucket size in grid intervals (the kernels' tiles are 64*SPL steps)
+constexpr int kTile64 = 64;  // the same, for code inside the kernels where kTile names their own tile length
 
 // physical constants, magnetar/funcs.py:7-13 (cgs)
 constexpr double kG = 6.674e-8;
@@ -22,6 +23,26 @@ struct DsDesc {
     int32_t tile_off;  // first entry of this dataset's tile_ptr[n_tiles + 1]
     int32_t pad;
 };
+
+// What a tile of the time-parallel solver needs to know about its step: tiles step over 1/8 of a grid interval (kind 0,
+// the first intervals), 1, 2 or 4 intervals (kinds 1, 2, 3).  The grid is geometric, so the ratio Q of consecutive step
+// end times, the quadrature matrices of the exponential Adams-Moulton formulas and the positions of the skipped grid
+// points inside a step are constants of the kind (host-computed, oracle/mp_oracle.c mpo_eam_weights).
+struct StrideK {
+    double lnQ;          // ln of the ratio of consecutive step end times
+    double inv_Q;        // 1/Q
+    double one_m_invQ;   // 1 - 1/Q: step length = (step end time) * this
+    double theta[4];     // time fraction of grid point i (i = 1..3) inside a step of kinds 2 and 3: (q^i - 1)/(Q - 1)
+};
+
+// The quadrature matrices of the four kinds live in a device table (DevShared::wtab) that every workgroup copies into LDS
+// once: per kind kWtabStride doubles,
+//   [6 k + m]      W5[k][m], k, m = 0..4: order-5 quadrature on nodes t_{j+1} .. t_{j-3} (omega); rows padded to 6
+//   [30 + 4 m + k] W4[k][m], k, m = 0..3: order-4 quadrature on nodes t_{j+1} .. t_{j-2} (Mdisc: the source is analytic)
+// (25 + 16 wave-uniform doubles per kind do not fit the scalar registers next to the walker constants; from LDS they are
+// read where they are used, two per broadcast ds_read_b128).
+constexpr int kWtabStride = 48;
+constexpr int kWtabW4 = 30;
 
 // Everything the kernel reads that is shared by all walkers (resident in HBM, L2-hot).
 struct DevShared {
@@ -41,7 +62,7 @@ struct DevShared {
     // bracketing observation j >= 64 in column j - 64 (written tile by tile, read by the luminosity stage)
     double *obs_scratch;
     int32_t scratch_stride;   // max over datasets of (n_obs - 64), rounded up to 64; 0 = no long light curve
-    int32_t force_pc;         // experiments: 1 = producer/consumer two-wavefront kernel, -1 = never, 0 = automatic
+    int32_t pre_fine;         // grid intervals at the start that are covered with 1/8-interval sub-steps (32, or fewer on a tiny grid)
     // prior
     double lower[MP_MAX_NDIM];
     double upper[MP_MAX_NDIM];
@@ -50,13 +71,17 @@ struct DevShared {
     // derived star constants (host-computed once from cfg)
     double GM, inertia, inv_inertia, crot /* 0.5*I/|W| */, sqrtGM, inv_sqrtGM, sqrtR;
     double crm_unit;      // (1e15 R^3)^(4/7) GM^(-1/7) f_Rm^(-2/7): Alfven-radius constant of a 1e15 G field
-    // geometric grid: ratio q = t_{j+1}/t_j and the exponential Adams-Moulton quadrature matrix for it
-    double q, inv_q;
+    // geometric grid t_i = t0 q^i
+    double t0, lnq8;      // first grid time; ln(q)/8
     double sweep_tol;     // relative change of the step-end values that ends the Newton sweeps of a tile
     double ultra_tol;     // corrections below this let the next sweep linearise omega_dot instead of evaluating it
+    double stride_tol;    // smoothness indicator above which a tile at a coarse stride is cut (cfg.stride_tol)
     int32_t n_simd;       // SIMDs of the device (multiProcessorCount x 4): batch sizes up to this get one wave per SIMD
-    int32_t force_spl;    // experiments: 0 = automatic, else steps per lane of the one-wavefront kernels (2, 4)
-    double eamW[4][4];
+    int32_t force_spl;    // experiments: 0 = automatic, else steps per lane (2, 4)
+    int32_t max_kind;     // coarsest tile kind allowed: 1, 2, 3 for cfg.max_stride 1, 2, 4
+    int32_t pad1;
+    StrideK sk[4];
+    const double *wtab;   // [4][kWtabStride] quadrature matrices of the four tile kinds
     mp_model_cfg cfg;
 };
 
@@ -71,6 +96,7 @@ struct LaunchArgs {
     double *lnprob;         // [n]
     int32_t *status;        // [n] or nullptr
     int32_t *sweeps;        // [n] or nullptr: total Newton sweeps over all tiles
+    int32_t *tiles;         // [n] or nullptr: tiles solved (kept or not)
     double *ltot;           // [n][n_grid] or nullptr   (1e50 erg/s)
     double *lprop;          // [n][n_grid] or nullptr
     double *ldip;           // [n][n_grid] or nullptr
@@ -110,9 +136,6 @@ struct StretchArgs {
 // Steps per lane of the kernel variant used for a batch of n walkers (tiles are 64*spl steps): see launch_lnprob.
 // Up to one wave per SIMD (256 CUs x 4 on MI355X) four steps per lane; beyond, two resident waves win (tools/spl_scan.sh).
 inline int kernel_spl(const DevShared &sh, int n) { return n <= sh.n_simd ? 4 : 2; }
-
-// Producer/consumer pair of wavefronts per walker: pays while every wavefront still gets a SIMD of its own.
-inline bool two_wave_pair(const DevShared &sh, int n) { return 2 * n <= sh.n_simd; }
 
 // Arguments of the batched right-hand-side evaluation (mp_kernels.hip: rhs_kernel), device pointers.
 struct RhsArgs {

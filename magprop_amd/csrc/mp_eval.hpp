@@ -1,6 +1,7 @@
-// mp_eval.hpp — evaluation of ONE walker's log-posterior on a wavefront (walker_eval; optionally fed by a producer
-// wavefront, walker_produce): physics of the reference's RHS / luminosity stage in simplified algebra and the
-// time-parallel exponential Adams-Moulton solver.  Included by mp_kernels.hip only.
+// mp_eval.hpp — evaluation of ONE walker's log-posterior on a wavefront (walker_eval): physics of the reference's RHS /
+// luminosity stage in simplified algebra and the time-parallel exponential Adams-Moulton solver with tile-level stride
+// adaptivity (serial restatement: oracle/mp_oracle.c mpo_trajectory_mode).  Included by
+// mp_kernels.hip only.
 #pragma once
 #include "mp_math.hpp"
 
@@ -33,31 +34,18 @@ struct DiscPt {
     Vd<N> qu;    // rmu^1.5/sqrt(GM): uncapped fastness = omega*qu
 };
 
-// (Mdisc/tvisc)^(-1/7): the one expensive ingredient of disc_point (the producer wavefront of the two-wavefront
-// kernel computes it and hands it over together with Mdisc)
-template <int N>
-MP_DEV Vd<N> disc_power(const Walker &w, const Vd<N> &Mdisc) {
-    Vd<N> mdot;
-    FORN mdot[i] = Mdisc[i] * w.inv_tau;
-    return pow_m1_7_fast(mdot);                                     // mdot^(-1/7)
-}
-
-template <int N>
-MP_DEV DiscPt<N> disc_from_power(const Walker &w, const Vd<N> &Mdisc, const Vd<N> &t) {
-    DiscPt<N> p;
-    FORN p.mdot[i] = Mdisc[i] * w.inv_tau;
-    FORN {
-        const double t2 = t[i] * t[i];
-        p.rmu[i] = w.Crm * t2;                                      // Crm * mdot^(-2/7)
-        p.squ[i] = w.sqrtCrm * t[i];                                // sqrt(rmu)
-        p.qu[i] = w.Crm15 * (t2 * t[i]);                            // rmu^1.5 / sqrt(GM)
-    }
-    return p;
-}
-
 template <int N>
 MP_DEV DiscPt<N> disc_point(const DevShared &sh, const Walker &w, const Vd<N> &Mdisc) {
-    return disc_from_power(w, Mdisc, disc_power(w, Mdisc));
+    DiscPt<N> p;
+    FORN p.mdot[i] = Mdisc[i] * w.inv_tau;
+    const Vd<N> t = pow_m1_7_fast(p.mdot);                              // mdot^(-1/7)
+    FORN {
+        const double t2 = t[i] * t[i];
+        p.rmu[i] = w.Crm * t2;                                          // Crm * mdot^(-2/7)
+        p.squ[i] = w.sqrtCrm * t[i];                                    // sqrt(rmu)
+        p.qu[i] = w.Crm15 * (t2 * t[i]);                                // rmu^1.5 / sqrt(GM)
+    }
+    return p;
 }
 
 // fallback accretion rate Mdotfb(t), code/synthetic_datasets/funcs.py:128
@@ -134,6 +122,15 @@ MP_DEV Vd<N> omega_rhs(const DevShared &sh, const Walker &w, const DiscPt<N> &p,
         out[i] = fma(-w.DI * om2, om[i], nacc);
     }
     return out;
+}
+
+// Which smooth branch of the right-hand side a state is on: bit 0 = Alfven radius capped at k*Rlc
+// (code/synthetic_datasets/funcs.py:109-110), bit 1 = Rm >= R (the torque-arm branch, :133-138).  Crossing either is a kink of
+// omega_dot that no multistep formula crosses at a coarse step (oracle/mp_oracle.c branch_flags).
+MP_DEV int branch_flags(const Walker &w, double rmu, double om) {
+    const bool capped = rmu * om >= w.kc;                           // rmu >= k c / omega
+    const bool big = capped ? (w.kc >= kR * om) : (rmu >= kR);
+    return (capped ? 1 : 0) | (big ? 2 : 0);
 }
 
 // luminosities (erg/s) at the lane's N grid points, reference luminosity stage
@@ -213,148 +210,69 @@ MP_DEV int walker_setup(const DevShared &sh, const LaunchArgs &a, double (&par)[
     return status;
 }
 
-// ---------------------------------------------------------------- producer / consumer pair of wavefronts
-// About half of a walker's work does not depend on omega: the Mdisc recurrence and the powers of Mdisc/tvisc the
-// omega equation reads.  The two-wavefront kernel gives that half to a PRODUCER wavefront, which runs ahead tile by tile
-// and hands (Mdisc, (Mdisc/tvisc)^(-1/7)) at every step end to the CONSUMER wavefront (predictor, Newton sweeps,
-// observations) through a two-slot LDS ring.  No barriers: two counters in LDS (tiles produced / tiles consumed) with
-// workgroup-scope release/acquire; the consumer raises `abort` when it stops early.  The arithmetic is that of the
-// one-wavefront kernel, instruction for instruction, so the results are bit-identical.
-template <int SPL>
-struct PcRing {
-    static constexpr int R = 2;
-    double M[R][SPL][64];      // Mdisc at step end lane*SPL + s of the tile in slot r: [r][s][lane] (conflict-free)
-    double T[R][SPL][64];      // (Mdisc/tvisc)^(-1/7) there
-    int produced;              // tiles published by the producer
-    int consumed;              // tiles taken over by the consumer
-    int abort;                 // consumer -> producer: stop
-};
-
-constexpr int kSpinLimit = 1 << 20;   // x s_sleep(2): far beyond any legitimate wait; a hang becomes a failed walker
-
-MP_DEV int ring_load(const int *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
-MP_DEV void ring_store(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
-
-// wait until *counter >= need; false if the partner raised abort or never came
-MP_DEV bool ring_wait(const int *counter, int need, const int *abort) {
-    for (int spin = 0; spin < kSpinLimit; ++spin) {
-        if (ring_load(counter) >= need) return true;
-        if (ring_load(abort)) return false;
-        __builtin_amdgcn_s_sleep(2);
-    }
-    return false;
-}
-
-// orders this wavefront's own LDS writes before its later LDS reads (all 64 lanes run in lockstep)
-MP_DEV void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-
-// The producer wavefront: the Mdisc phase of walker_eval (same statements), tile after tile.
-template <int SPL>
-MP_DEV void walker_produce(const DevShared &sh, const LaunchArgs &a, double (&par)[MP_MAX_NDIM], PcRing<SPL> &ring) {
-    constexpr int kSPL = SPL, kTile = 64 * SPL, R = PcRing<SPL>::R;
-    const int n_tiles = (sh.n_grid - 1 + kTile - 1) / kTile;
-    const int lane = threadIdx.x & 63;
-    const int nsteps = sh.n_grid - 1;
-    Walker w;
-    (void)walker_setup(sh, a, par, w);
-    const double t0 = sh.tgrid[0];
-    double t_s = t0;
-    double M_s = par[2] * kMsol;
-    double cS0, cS1, cS2;
-    {
-        const Vd<3> tg{{t0, t0 * sh.inv_q, t0 * sh.inv_q * sh.inv_q}};
-        const Vd<3> Sg = mdot_fb(w, tg);
-        cS0 = Sg[0]; cS1 = Sg[1]; cS2 = Sg[2];
-    }
-    double tb_next[kSPL];
-#pragma unroll
-    for (int s = 0; s < kSPL; ++s) tb_next[s] = sh.tgrid[min(lane * kSPL + s + 1, nsteps)];
-    for (int tile = 0; tile < n_tiles; ++tile) {
-        const int i0 = tile * kTile + lane * kSPL;
-        Vd<kSPL> tb, h;
-#pragma unroll
-        for (int s = 0; s < kSPL; ++s) {
-            tb[s] = tb_next[s];
-            tb_next[s] = sh.tgrid[min(i0 + kTile + s + 1, nsteps)];
-        }
-        {
-            const double ta0 = lane_prev(tb[kSPL - 1], t_s);
-#pragma unroll
-            for (int s = 0; s < kSPL; ++s) h[s] = tb[s] - (s == 0 ? ta0 : tb[s - 1]);
-        }
-        Vd<kSPL> M1;
-        double ES[kSPL + 3];
-        {
-            const Vd<kSPL> S1 = mdot_fb(w, tb);
-#pragma unroll
-            for (int s = 0; s < kSPL; ++s) ES[3 + s] = S1[s];
-            ES[2] = lane_prev(ES[kSPL + 2], cS0);
-            ES[1] = lane_prev(ES[kSPL + 1], cS1);
-            ES[0] = lane_prev(ES[kSPL + 0], cS2);
-            Vd<kSPL> zm, v0, v1, v2, v3;
-#pragma unroll
-            for (int s = 0; s < kSPL; ++s) {
-                zm[s] = -h[s] * w.inv_tau;
-                v0[s] = ES[3 + s]; v1[s] = ES[2 + s]; v2[s] = ES[1 + s]; v3[s] = ES[s];
-            }
-            const Phi<kSPL> pm = phi1234(zm);
-            const Vd<kSPL> inc = eam4_increment(sh, pm, h, v0, v1, v2, v3);
-            Vd<kSPL> am, bm;
-            double A = 1.0, B = 0.0;
-#pragma unroll
-            for (int s = 0; s < kSPL; ++s) {
-                am[s] = pm.e[s];
-                bm[s] = inc[s];
-                B = fma(am[s], B, bm[s]);
-                A = A * am[s];
-            }
-            scan_affine(A, B);
-            double Ax, Bx;
-            lane_prev_map(A, B, Ax, Bx);
-            double Mc = fma(Ax, M_s, Bx);
-#pragma unroll
-            for (int s = 0; s < kSPL; ++s) { Mc = fma(am[s], Mc, bm[s]); M1[s] = Mc; }
-        }
-        const Vd<kSPL> tp = disc_power(w, M1);
-        // publish: the slot must have been taken over by the consumer first
-        if (tile >= R && !ring_wait(&ring.consumed, tile - R + 1, &ring.abort)) return;
-        if (ring_load(&ring.abort)) return;
-        const int slot = tile % R;
-#pragma unroll
-        for (int s = 0; s < kSPL; ++s) { ring.M[slot][s][lane] = M1[s]; ring.T[slot][s][lane] = tp[s]; }
-        ring_store(&ring.produced, tile + 1);            // release: the slot's contents are visible before the counter
-        if (tile + 1 < n_tiles) {
-            constexpr int e1 = kTile - 2, e2 = kTile - 3;
-            cS0 = lane_bcast(ES[3 + kSPL - 1], 63);
-            cS1 = lane_bcast(ES[3 + e1 % kSPL], e1 / kSPL);
-            cS2 = lane_bcast(ES[3 + e2 % kSPL], e2 / kSPL);
-            t_s = lane_bcast(tb[kSPL - 1], 63);
-            M_s = lane_bcast(M1[kSPL - 1], 63);
-        }
-    }
-}
-
 constexpr int kMaxSweepsMargin = 16;  // sweeps allowed beyond the tile length (after which every step is exact)
 // A tile whose iterates keep crossing the break-up limit (rotation parameter 0.27: the accretion torque switches off,
 // code/synthetic_datasets/funcs.py:131-132) is chattering on that discontinuity and ends as a 'flag' anyway; after this
-// many sweeps with an iterate beyond the limit the verdict is taken at once instead of after tile-length sweeps
-// (a prior-wide launch used to last as long as its one chattering walker: 0.45 instead of 0.30 ms at 1 024 walkers).
+// many sweeps with an iterate beyond the limit the verdict is taken at once instead of after tile-length sweeps.
 // Not fewer: a 256-step tile that starts from a poor guess may overshoot the limit for a dozen sweeps and still converge
 // below it (5 of the 32 768 soak walkers did with a threshold of 8).
 constexpr int kChatterSweeps = 24;
+// A tile at a coarse stride is kept if at least this many lanes precede the first offending one (oracle: MPO_MIN_KEEP).
+constexpr int kMinKeepLanes = 8;
+// Sweeps a tile at a coarse stride may take: one that has not converged by then (a poor extrapolated guess across a fast
+// feature) is cheaper redone over single intervals.
+constexpr int kCoarseMaxSweeps = 6;
+
+// cubic Hermite on a step of length h (theta in [0, 1]): value, and its time derivative
+MP_DEV double hermite(double th, double h, double y0, double d0, double y1, double d1) {
+    const double D = y1 - y0;
+    return y0 + th * (h * d0 + th * ((3.0 * D - h * (2.0 * d0 + d1)) + th * (h * (d0 + d1) - 2.0 * D)));
+}
+MP_DEV double hermite_d(double th, double h, double y0, double d0, double y1, double d1) {
+    const double D = y1 - y0;
+    return (h * d0 + th * (2.0 * (3.0 * D - h * (2.0 * d0 + d1)) + th * 3.0 * (h * (d0 + d1) - 2.0 * D))) / h;
+}
+
+// The image of the last kept tile in LDS: node 0 = the tile's start point, node e + 1 = step end e.  It serves the
+// observations (mode A picks the states bracketing each observed time out of it) and, as the record of the most recent
+// steps, the multistep history of a successor tile whose step differs.
+template <int SPL>
+struct TileImage {
+    static constexpr int kN = 64 * SPL + 1;
+    double W[kN];   // omega
+    double F[kN];   // omega_dot
+    double M[kN];   // Mdisc
+    double D[kN];   // dMdisc/dt
+};
+
+// (Mdisc, omega) at position p8 (in eighths of a grid interval) inside the kept part of the image of a tile of kind
+// `kind` that started at pos8 / time t_s with steps of d8 eighths: the node itself when p8 is one, else the Hermite
+// interpolant over its step (strides 2 and 4 only; the remainder is then a whole number of grid intervals).
+template <int SPL>
+MP_DEV void image_state(const DevShared &sh, const TileImage<SPL> &im, int kind, int pos8, int d8, double t_s, int p8,
+                        double &Mv, double &Wv) {
+    const int rel = p8 - pos8, J = rel / d8, rem = rel - J * d8;
+    Mv = im.M[J];
+    Wv = im.W[J];
+    if (rem != 0) {
+        const StrideK &K = sh.sk[kind];
+        const Vd<1> e{{(double)(J + 1) * K.lnQ}};
+        const double h = t_s * exp_fast(e)[0] * K.one_m_invQ, th = K.theta[(rem >> 3) & 3];
+        Mv = hermite(th, h, im.M[J], im.D[J], im.M[J + 1], im.D[J + 1]);
+        Wv = hermite(th, h, im.W[J], im.F[J], im.W[J + 1], im.F[J + 1]);
+    }
+}
 
 // ---------------------------------------------------------------- the kernel
 // Evaluate ONE walker on the calling wavefront (all 64 lanes enter with identical arguments).
 // SPL = consecutive steps owned by one lane; a tile is 64*SPL steps.  par[] holds the sampler coordinates
 // (prior checked and log-masked coordinates un-logged here unless a.physical); walker indexes ds_id and the
-// optional curve outputs; Lbuf is the wave's LDS staging area [2*(64*SPL + 1)].
-// ROLE 0: the whole evaluation on this wavefront.  ROLE 1: consumer of a PcRing (the Mdisc phase runs on the partner
-// wavefront, walker_produce); the wavefront must then be the only user of Lbuf and must not meet workgroup barriers.
-template <bool CURVES, int SPL, bool LONG, int ROLE = 0>
-MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, double (&par)[MP_MAX_NDIM], double *Lbuf,
-                        double &lnp_out, int &status_out, int &sweeps_out, PcRing<SPL> *ring = nullptr) {
+// optional curve outputs; im / Lbuf are the wave's LDS areas (Lbuf: [2*(64*SPL + 1)], staging of the curve outputs).
+template <bool CURVES, int SPL, bool LONG>
+MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, double (&par)[MP_MAX_NDIM],
+                        TileImage<SPL> &im, double *Lbuf, double &lnp_out, int &status_out, int &sweeps_out,
+                        int &tiles_out) {
     constexpr int kSPL = SPL, kTile = 64 * SPL, kMaxSweeps = kTile + kMaxSweepsMargin;
-    const int n_tiles = (sh.n_grid - 1 + kTile - 1) / kTile;
     const int lane = threadIdx.x & 63;
 
     const int n_grid = sh.n_grid;
@@ -364,26 +282,19 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
     Walker w;
     int status = walker_setup(sh, a, par, w);
 
-    // ---- state carried from tile to tile (all wave-uniform).  Index 0 = the tile's start point P0,
-    // 1 = P0-1, 2 = P0-2: the history the multistep formulas reach back to.
-    const double t0 = sh.tgrid[0];
-    double t_s = t0;
+    // ---- state carried from tile to tile (all wave-uniform)
+    double t_s = sh.t0;
     double M_s = par[2] * kMsol;                         // initial conditions, code/synthetic_datasets/funcs.py:66-69
     double om_s = (2.0 * M_PI) / (1.0e-3 * par[1]);
-    double cS0, cS1, cS2;
-    {
-        const Vd<3> tg{{t0, t0 * sh.inv_q, t0 * sh.inv_q * sh.inv_q}};     // the grid continued backwards
-        const Vd<3> Sg = mdot_fb(w, tg);
-        cS0 = Sg[0]; cS1 = Sg[1]; cS2 = Sg[2];
-    }
-    double cf0, cf1, cf2, cw1 = om_s, cw2 = om_s, cw3 = om_s, cw4 = om_s;   // (omega_dot, omega) history; cw0 == om_s (cw3, cw4: predictor only)
+    double cf0;
+    int flags_s;
     double L_s, Lp_s, Ld_s;
     {
         const Vd<1> Mv{{M_s}}, ov{{om_s}};
         const DiscPt<1> d_s = disc_point(sh, w, Mv);
         Vd<1> rot0, dummy, Lt0, Lp0, Ld0;
         cf0 = omega_rhs<false>(sh, w, d_s, ov, rot0, dummy)[0];
-        cf1 = cf2 = cf0;
+        flags_s = branch_flags(w, d_s.rmu[0], om_s);
         if (status == MP_STATUS_OK) {
             if (!(isfinite(M_s) && isfinite(om_s)) || M_s <= 0.0 || om_s <= 0.0) status = MP_STATUS_NONFINITE;
             else if (rot0[0] > 0.27) status = MP_STATUS_FLAG;
@@ -415,16 +326,15 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
         ob_y = sh.obs_y[jj];
         ob_ye = sh.obs_yerr[jj];
     }
-    const int ob_tile = ob_g >= 0 ? ob_g / kTile : -1;
     // LONG: compiled with the scratch-row path for light curves of more than 64 points (the launcher picks this
     // variant when the handle holds such a dataset; the short variant keeps that code out of the register budget)
     const bool long_lc = (CURVES || LONG) && a.want_chi2 && dsd.n_obs > 64;
-    const bool deferred = !CURVES && a.want_chi2;               // see "luminosity and chi^2" below
+    const bool deferred = !CURVES && a.want_chi2;               // see "observations" below
     const size_t sc_stride = (size_t)sh.scratch_stride;
     double *sc = sh.obs_scratch + (size_t)walker * 4 * sc_stride;   // [4][stride]: observations 64.. of this walker
     double obM[2] = {1.0e30, 1.0e30}, obW[2] = {1.0e3, 1.0e3};  // (Mdisc, omega) at the observation's bracketing grid points
     double chi = 0.0;
-    int sweeps_total = 0;
+    int sweeps_total = 0, tiles_total = 0;
 
     if (status == MP_STATUS_OK) {
         if (CURVES && lane == 0) {
@@ -434,45 +344,86 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
             if (a.mdisc) a.mdisc[row] = M_s;
             if (a.omega) a.omega[row] = om_s;
         }
-        // Each lane owns kSPL consecutive steps of the tile: steps tile*kTile + lane*kSPL + s, s = 0..kSPL-1.
-        // Step end times are fetched one tile ahead of their use.
-        double tb_next[kSPL];
-#pragma unroll
-        for (int s = 0; s < kSPL; ++s) tb_next[s] = sh.tgrid[min(lane * kSPL + s + 1, nsteps)];
+        // ---- tile control (wave-uniform).  Positions in eighths of a grid interval: the first pre_fine intervals are
+        // covered with 1/8-interval sub-steps (kind 0), the rest with steps of 1, 2 or 4 intervals (kinds 1, 2, 3).
+        const int end8 = 8 * nsteps, pre_end8 = 8 * sh.pre_fine;
+        const int max_kind = CURVES ? 1 : sh.max_kind;         // curve outputs: every grid point is a step end
+        int pos8 = 0, kind = 1;
+        bool rec_valid = false;                  // the image holds a kept tile (the history of the next one)
+        int rec_kind = 0, rec_d8 = 1, rec_J = 0; // its kind, its step in eighths and the number of steps kept
+        // Each lane owns kSPL consecutive steps of the tile: steps lane*kSPL + s, s = 0..kSPL-1.
+        while (pos8 < end8) {
+            const bool pre = pos8 < pre_end8;
+            if (pre) kind = 0;
+            int d8 = pre ? 1 : (4 << kind);                                 // 8, 16, 32 eighths
+            const int left8 = (pre ? pre_end8 : end8) - pos8;
+            if (!pre) while (kind > 1 && (left8 % d8) != 0) { --kind; d8 >>= 1; }
+            const int nc = min(kTile, left8 / d8);                          // steps of this tile that exist
+            const StrideK &K = sh.sk[kind];
+            const int wbase = kind * kWtabStride;                           // this kind's quadrature matrices in the LDS table
+            ++tiles_total;
 
-        for (int tile = 0; tile < n_tiles; ++tile) {
-            const int i0 = tile * kTile + lane * kSPL;   // this lane's first step: tgrid[i0] -> tgrid[i0+1]
-            Vd<kSPL> tb, h;
-#pragma unroll
-            for (int s = 0; s < kSPL; ++s) {
-                tb[s] = tb_next[s];
-                tb_next[s] = sh.tgrid[min(i0 + kTile + s + 1, nsteps)];
-            }
+            // ---------------- step end times (the grid is geometric: t_k = t_s Q^k) and step lengths
+            Vd<kSPL> h, S1;
             {
-                const double ta0 = lane_prev(tb[kSPL - 1], t_s);
+                Vd<kSPL> ek, tb;
 #pragma unroll
-                for (int s = 0; s < kSPL; ++s) h[s] = tb[s] - (s == 0 ? ta0 : tb[s - 1]);   // 0 for the padding steps of the last tile
+                for (int s = 0; s < kSPL; ++s) ek[s] = (double)min(lane * kSPL + s + 1, nc) * K.lnQ;
+                const Vd<kSPL> E = exp_fast(ek);
+#pragma unroll
+                for (int s = 0; s < kSPL; ++s) {
+                    tb[s] = t_s * E[s];
+                    h[s] = (lane * kSPL + s < nc) ? tb[s] * K.one_m_invQ : 0.0;   // 0 for the padding steps of a short tile
+                }
+                S1 = mdot_fb(w, tb);
+            }
+
+            // ---------------- history at this tile's spacing: the source of Mdisc is analytic; (omega_dot, omega) at the
+            // three (predictor: four) previous points come from the record of the last kept tile
+            double cS0, cS1, cS2;
+            {
+                const Vd<3> tg{{t_s, t_s * K.inv_Q, t_s * K.inv_Q * K.inv_Q}};
+                const Vd<3> Sg = mdot_fb(w, tg);
+                cS0 = Sg[0]; cS1 = Sg[1]; cS2 = Sg[2];
+            }
+            double cf1 = cf0, cf2 = cf0, cf3 = cf0, cw1 = om_s, cw2 = om_s, cw3 = om_s, cw4 = om_s;
+            bool have4 = false, interp_hist = false;
+            const bool startup = !rec_valid;
+            if (rec_valid) {
+                // lane k-1 looks up the point k steps of this tile before its start (k = 1..4): node ja of the record,
+                // or `rem` eighths before it inside the record's step [ja - 1, ja]
+                const int o8 = (lane + 1) * d8, idx = o8 / rec_d8, rem = o8 - idx * rec_d8;
+                const int ja = rec_J - idx, jb = ja - (rem != 0 ? 1 : 0);
+                double wv = om_s, fv = cf0;
+                const bool avail = lane < 4 && jb >= 0;
+                if (avail) {
+                    wv = im.W[ja];
+                    fv = im.F[ja];
+                    if (rem != 0) {
+                        const StrideK &R = sh.sk[rec_kind];
+                        const Vd<1> e1{{-(double)rem * sh.lnq8}}, e2{{-(double)idx * R.lnQ}};
+                        const double th = (exp_fast(e1)[0] - R.inv_Q) / R.one_m_invQ;    // time fraction inside [jb, ja]
+                        const double hr = t_s * exp_fast(e2)[0] * R.one_m_invQ;
+                        wv = hermite(th, hr, im.W[jb], im.F[jb], im.W[ja], im.F[ja]);
+                        fv = hermite_d(th, hr, im.W[jb], im.F[jb], im.W[ja], im.F[ja]);
+                    }
+                }
+                const unsigned long long av = __ballot(avail);
+                interp_hist = (__ballot(avail && rem != 0) & 0xFull) != 0ull;
+                // (the record always holds the three points the formula needs: it has kMinKeepLanes lanes at least)
+                cw1 = lane_bcast(wv, 0); cf1 = lane_bcast(fv, 0);
+                cw2 = lane_bcast(wv, 1); cf2 = lane_bcast(fv, 1);
+                cw3 = lane_bcast(wv, 2); cf3 = lane_bcast(fv, 2);
+                have4 = (av & 0xFull) == 0xFull;
+                cw4 = have4 ? lane_bcast(wv, 3) : cw3;
             }
 
             // ---------------- Mdisc: exponential Adams-Moulton step (explicit: the source is known) + affine scan.
-            // E*[k]: values at the three grid points before this lane's first step (k = 0,1,2) and at its step ends (k = 3+s).
+            // ES[k]: source at the three points before this lane's first step (k = 0,1,2) and at its step ends (k = 3+s).
             Vd<kSPL> M1;
-            double ES[kSPL + 3];
             DiscPt<kSPL> d1;
-            if constexpr (ROLE == 1) {
-                // the partner wavefront has done this phase: take the tile over from the ring
-                if (!ring_wait(&ring->produced, tile + 1, &ring->abort)) { status = MP_STATUS_NONFINITE; break; }
-                const int slot = tile % PcRing<SPL>::R;
-                Vd<kSPL> tp;
-#pragma unroll
-                for (int s = 0; s < kSPL; ++s) { M1[s] = ring->M[slot][s][lane]; tp[s] = ring->T[slot][s][lane]; }
-                wave_lds_fence();                                 // the values are in registers ...
-                ring_store(&ring->consumed, tile + 1);            // ... before the slot is handed back
-                d1 = disc_from_power(w, M1, tp);
-#pragma unroll
-                for (int s = 0; s < kSPL + 3; ++s) ES[s] = 0.0;
-            } else {
-                const Vd<kSPL> S1 = mdot_fb(w, tb);
+            {
+                double ES[kSPL + 3];
 #pragma unroll
                 for (int s = 0; s < kSPL; ++s) ES[3 + s] = S1[s];
                 ES[2] = lane_prev(ES[kSPL + 2], cS0);
@@ -485,7 +436,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                     v0[s] = ES[3 + s]; v1[s] = ES[2 + s]; v2[s] = ES[1 + s]; v3[s] = ES[s];
                 }
                 const Phi<kSPL> pm = phi1234(zm);
-                const Vd<kSPL> inc = eam4_increment(sh, pm, h, v0, v1, v2, v3);
+                const Vd<kSPL> inc = eam4_increment(wbase, pm, h, v0, v1, v2, v3);
                 Vd<kSPL> am, bm;
                 double A = 1.0, B = 0.0;                  // composition of this lane's step maps
 #pragma unroll
@@ -504,15 +455,17 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 d1 = disc_point(sh, w, M1);
             }
 
-            // ---------------- omega: predictor = extrapolation of the last five grid values in the step index
+            // ---------------- omega: predictor = extrapolation of the last five values in the step index
             // (the grid is logarithmic, so power laws are smooth in the index) ...
             Vd<kSPL> wg;                                  // current guess of omega at this lane's step ends
             {
-                // Newton backward-difference extrapolation (quartic once five grid values exist)
+                // Newton backward-difference extrapolation (quartic once five values exist).  History values that were
+                // interpolated inside the record's steps (a finer successor) carry the interpolant's ~1e-11 ripple, which
+                // the higher differences would amplify by the cube / fourth power of the tile length: quadratic then.
                 const double g1 = om_s - cw1, g2 = g1 - (cw1 - cw2);
                 const double d2b = (cw1 - cw2) - (cw2 - cw3);
-                const double g3 = tile == 0 ? 0.0 : g2 - d2b;
-                const double g4 = tile == 0 ? 0.0 : g3 - (d2b - ((cw2 - cw3) - (cw3 - cw4)));
+                const double g3 = (startup || interp_hist) ? 0.0 : g2 - d2b;
+                const double g4 = (startup || interp_hist || !have4) ? 0.0 : g3 - (d2b - ((cw2 - cw3) - (cw3 - cw4)));
 #pragma unroll
                 for (int s = 0; s < kSPL; ++s) {
                     const double k = (double)(lane * kSPL + s + 1);
@@ -521,21 +474,23 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                     wg[s] = fma(k, g1, fma(c2, g2, fma(c3, g3, fma(c3 * (k + 3.0) * 0.25, g4, om_s))));
                 }
             }
-            // ... then Newton-type sweeps of the linearised step maps
-            double Ef[kSPL + 3], Ew[kSPL + 3];
+            // ... then Newton-type sweeps of the linearised step maps.
+            // E*[k]: values at the four points before this lane's first step (k = 0..3) and at its step ends (k = 4+s).
+            double Ef[kSPL + 4], Ew[kSPL + 4];
             unsigned long long flagged = 0ull, pending = ~0ull;
-            bool settled = false;    // this lane's guesses moved by < 1e-3 in the previous sweep
+            bool settled = false;    // this lane's guesses moved by < 1e-6 in the previous sweep: close enough to its solution
+                                     // for an excursion beyond the break-up limit to be the solution's, not the iteration's
             int sweep = 0, over_sweeps = 0;
-            Ew[2] = om_s;
+            Ew[3] = om_s;
             // A sweep that follows a small correction (every lane moved by < 1e-4) keeps the Jacobian lambda, e^{h lambda}
             // and the quadrature weights of the previous one and only re-evaluates omega_dot ("light" sweep): the scheme
             // may linearise about any nearby point, the result moves by ~1e-14, and the verification sweep costs a third less.
-            // A sweep that follows a FULL sweep whose correction was below ultra_tol (1e-5 at the default sweep tolerance, 1e-7 at the strict one) does
-            // not evaluate omega_dot at all: omega_dot at the new point is its linearisation about the previous one,
-            // f + lambda*(omega_new - omega_old), exact to the second order in that correction (< 5e-9 relative in omega_dot even across
-            // the propeller switch).  Such a sweep is the cheap verification pass of a tile whose first guess was good.
-            Vd<kSPL> lam, ez;
-            EamW<kSPL> cw;
+            // A sweep that follows a FULL sweep whose correction was below ultra_tol does not evaluate omega_dot at all:
+            // omega_dot at the new point is its linearisation about the previous one, f + lambda*(omega_new - omega_old),
+            // exact to the second order in that correction.  Such a sweep is the cheap verification pass of a tile whose
+            // first guess was good.
+            Vd<kSPL> lam, ez, n0, n1, n2, n3, n4;
+            EamW5<kSPL> cw;
             bool light = false, ultra = false;
             while (true) {
                 ++sweep;
@@ -546,7 +501,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                     if (__any(wild)) {   // keep the iteration alive after a wild or NaN guess (rare)
 #pragma unroll
                         for (int s = 0; s < kSPL; ++s)
-                            if (!(wg[s] > 0.0)) wg[s] = Ew[2] > 0.0 ? Ew[2] : om_s;
+                            if (!(wg[s] > 0.0)) wg[s] = Ew[3] > 0.0 ? Ew[3] : om_s;
                     }
                 }
                 Vd<kSPL> rot, f1;
@@ -554,7 +509,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 if (ultra) {
 #pragma unroll
                     for (int s = 0; s < kSPL; ++s) {
-                        f1[s] = fma(lam[s], wg[s] - Ew[3 + s], Ef[3 + s]);
+                        f1[s] = fma(lam[s], wg[s] - Ew[4 + s], Ef[4 + s]);
                         rot[s] = sh.crot * (wg[s] * wg[s]);
                     }
                 } else if (light) {
@@ -563,13 +518,13 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 } else {
                     f1 = omega_rhs<true>(sh, w, d1, wg, rot, lam);
                 }
-                // largest rotation parameter among this lane's step ends (the padding steps of the last tile repeat the
-                // last grid point once the first sweep has run; before that nothing is decided on them: `settled` is false)
 #pragma unroll
                 for (int s = 0; s < kSPL; ++s) {
-                    Ef[3 + s] = f1[s];
-                    Ew[3 + s] = wg[s];
+                    Ef[4 + s] = f1[s];
+                    Ew[4 + s] = wg[s];
                 }
+                // largest rotation parameter among this lane's step ends (the padding steps of a short tile repeat its
+                // last point once the first sweep has run; before that nothing is decided on them: `settled` is false)
                 const double rot_max = lane_max(rot.v);
                 const bool flg = rot_max > 0.27;
                 const bool near_limit = rot_max > 0.26;   // close to the break-up switch of the torque: no linearisation
@@ -577,32 +532,34 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 flagged |= __ballot(settled && flg);
                 const unsigned long long over_now = __ballot(flg);
                 over_sweeps += over_now != 0ull;
-                double h1 = cf1, h2 = cf2, u1 = cw1, u2 = cw2;
-                if (tile == 0) {   // start-up: the two points before the grid continue points 0 and 1 linearly in the index
-                    const double fp1 = lane_bcast(Ef[3], 0), wp1 = lane_bcast(Ew[3], 0);
+                double h1 = cf1, h2 = cf2, h3 = cf3, u1 = cw1, u2 = cw2, u3 = cw3;
+                if (startup) {   // the three points before the grid continue points 0 and 1 linearly in the index
+                    const double fp1 = lane_bcast(Ef[4], 0), wp1 = lane_bcast(Ew[4], 0);
                     h1 = 2.0 * cf0 - fp1; u1 = 2.0 * om_s - wp1;
                     h2 = 3.0 * cf0 - 2.0 * fp1; u2 = 3.0 * om_s - 2.0 * wp1;
+                    h3 = 4.0 * cf0 - 3.0 * fp1; u3 = 4.0 * om_s - 3.0 * wp1;
                 }
-                Ef[2] = lane_prev(Ef[kSPL + 2], cf0);  Ew[2] = lane_prev(Ew[kSPL + 2], om_s);
-                Ef[1] = lane_prev(Ef[kSPL + 1], h1);   Ew[1] = lane_prev(Ew[kSPL + 1], u1);
-                Ef[0] = lane_prev(Ef[kSPL + 0], h2);   Ew[0] = lane_prev(Ew[kSPL + 0], u2);
-                Vd<kSPL> n0, n1, n2, n3;
+                Ef[3] = lane_prev(Ef[kSPL + 3], cf0);  Ew[3] = lane_prev(Ew[kSPL + 3], om_s);
+                Ef[2] = lane_prev(Ef[kSPL + 2], h1);   Ew[2] = lane_prev(Ew[kSPL + 2], u1);
+                Ef[1] = lane_prev(Ef[kSPL + 1], h2);   Ew[1] = lane_prev(Ew[kSPL + 1], u2);
+                Ef[0] = lane_prev(Ef[kSPL + 0], h3);   Ew[0] = lane_prev(Ew[kSPL + 0], u3);
 #pragma unroll
                 for (int s = 0; s < kSPL; ++s) {
-                    n0[s] = fma(-lam[s], Ew[3 + s], Ef[3 + s]);
-                    n1[s] = fma(-lam[s], Ew[2 + s], Ef[2 + s]);
-                    n2[s] = fma(-lam[s], Ew[1 + s], Ef[1 + s]);
-                    n3[s] = fma(-lam[s], Ew[s], Ef[s]);
+                    n0[s] = fma(-lam[s], Ew[4 + s], Ef[4 + s]);
+                    n1[s] = fma(-lam[s], Ew[3 + s], Ef[3 + s]);
+                    n2[s] = fma(-lam[s], Ew[2 + s], Ef[2 + s]);
+                    n3[s] = fma(-lam[s], Ew[1 + s], Ef[1 + s]);
+                    n4[s] = fma(-lam[s], Ew[s], Ef[s]);
                 }
                 if (!light) {
                     Vd<kSPL> zw;
 #pragma unroll
                     for (int s = 0; s < kSPL; ++s) zw[s] = h[s] * lam[s];
-                    const Phi<kSPL> pw_ = phi1234(zw);
+                    const Phi5<kSPL> pw_ = phi12345(zw);
                     ez = pw_.e;
-                    cw = eam4_node_weights(sh, pw_);
+                    cw = eam5_node_weights(wbase, pw_);
                 }
-                const Vd<kSPL> inc = eam4_increment_nodes(cw, h, n0, n1, n2, n3);
+                const Vd<kSPL> inc = eam5_increment_nodes(cw, h, n0, n1, n2, n3, n4);
                 Vd<kSPL> aw, bw;
                 double A = 1.0, B = 0.0;
 #pragma unroll
@@ -626,7 +583,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                     wg[s] = wc;
                 }
                 const double mag = (double)kSPL * fabs(wc);
-                const bool all_settled = dsum <= 1.0e-3 * mag;                       // false for NaN
+                const bool all_settled = dsum <= 1.0e-6 * mag;                       // false for NaN
                 const bool all_small = dsum <= 1.0e-4 * mag;
                 const bool all_tiny = dsum <= sh.ultra_tol * mag;
                 const bool all_ok = dsum <= sh.sweep_tol * mag;
@@ -637,13 +594,15 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 ultra = full && __all(all_tiny && !near_limit);
                 pending = __ballot(!all_ok);
                 if (pending == 0ull || flagged != 0ull || sweep >= kMaxSweeps) break;
+                if (kind >= 2 && sweep >= kCoarseMaxSweeps) break;   // not worth it at this stride (the tile is redone finer)
                 if (over_sweeps >= kChatterSweeps) { flagged |= over_now ? over_now : pending; break; }
             }
             sweeps_total += sweep;
 
             // ---------------- failure detection in time order (oracle/mp_oracle.c).  Per lane: a NaN or an
             // infinity anywhere shows in the sum, a non-positive value in the minimum, the break-up limit in the largest
-            // omega (the padding steps of the last tile repeat the last grid point).
+            // omega (the padding steps of a short tile repeat its last point).
+            unsigned long long mb, mf;
             {
                 double vsum = M1[0] + wg[0];
 #pragma unroll
@@ -651,56 +610,115 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 const double vmin = min_raw(lane_min(M1.v), lane_min(wg.v)), wmax = lane_max(wg.v);
                 const bool bad = !isfinite(vsum) || !(vmin > 0.0);
                 const bool over = sh.crot * wmax * wmax > 0.27;
-                const unsigned long long mb = __ballot(bad);
+                mb = __ballot(bad);
                 // a step whose sweeps never settle is chattering on the Nacc discontinuity: same verdict as a flag
-                const unsigned long long mf = flagged | __ballot(over) | (flagged ? 0ull : pending);
-                if (mb | mf) {
-                    const int first = __ffsll((unsigned long long)(mb | mf)) - 1;
-                    status = ((mf >> first) & 1ull) ? MP_STATUS_FLAG : MP_STATUS_NONFINITE;
-                    break;
-                }
+                mf = flagged | __ballot(over) | (flagged ? 0ull : pending);
+            }
+            if (mb | mf) {
+                if (kind >= 2) { kind = 1; continue; }   // not a verdict at a coarse stride: redo over single intervals
+                const int first = __ffsll((unsigned long long)(mb | mf)) - 1;
+                status = ((mf >> first) & 1ull) ? MP_STATUS_FLAG : MP_STATUS_NONFINITE;
+                break;
             }
 
-            // ---------------- luminosity and chi^2
-            const bool mine = ob_tile == tile;
+            // ---------------- what is kept, and the stride of the next tile (oracle/mp_oracle.c mpo_trajectory_mode).
+            // Per lane: does the solution leave the smooth branch of the right-hand side the tile started on; and the
+            // smoothness indicator h |4th difference of (f - lambda omega)| / omega against stride_tol, and against
+            // stride_tol / 64 and / 2048 (what it would be at twice / four times the step: 5th-order scaling, margin 2).
+            int keep_lanes = 64, next_kind = kind;
+            {
+                bool brk = false, ind1 = false, ind64 = false, ind2048 = false;
+#pragma unroll
+                for (int s = 0; s < kSPL; ++s) {
+                    const bool valid = lane * kSPL + s < nc;
+                    brk = brk || (valid && branch_flags(w, d1.rmu[s], wg[s]) != flags_s);
+                    const double d4 = h[s] * fabs((n0[s] + n4[s]) - 4.0 * (n1[s] + n3[s]) + 6.0 * n2[s]);
+                    const double lim = sh.stride_tol * wg[s];
+                    ind1 = ind1 || d4 > lim;
+                    ind64 = ind64 || 64.0 * d4 > lim;
+                    ind2048 = ind2048 || 2048.0 * d4 > lim;
+                }
+                const unsigned long long B = __ballot(brk), I1 = __ballot(ind1), I64 = __ballot(ind64), I2048 = __ballot(ind2048);
+                const int full_lanes = (nc + kSPL - 1) / kSPL;                 // lanes that hold steps of this tile
+                if (kind >= 2) {
+                    const unsigned long long bad = B | I1;
+                    const int first = bad ? __ffsll(bad) - 1 : 64;
+                    if (first < full_lanes) {
+                        if (first < kMinKeepLanes) { kind = 1; continue; }     // nothing worth keeping: redo at stride 1
+                        keep_lanes = first;
+                        next_kind = 1;                                         // the offending region gets single intervals
+                    } else if (kind == 2 && nc == kTile) {
+                        next_kind = I64 == 0ull ? 3 : 2;
+                    }
+                } else if (kind == 1 && nc == kTile) {
+                    if (B == 0ull) next_kind = I2048 == 0ull ? 3 : (I64 == 0ull ? 2 : 1);
+                    else {
+                        // a kink inside this tile: the history of a coarse successor must lie behind it
+                        const int first_clean = __ffsll(B) - 1 + 2;            // lanes from here on are past the kink
+                        const int tail = kTile - first_clean * kSPL;           // steps in them
+                        const unsigned long long post = first_clean < 64 ? ~0ull << first_clean : 0ull;
+                        if (tail >= 12 + kSPL && (I2048 & post) == 0ull) next_kind = 3;
+                        else if (tail >= 6 + kSPL && (I64 & post) == 0ull) next_kind = 2;
+                    }
+                }
+                if (kind == 0) next_kind = 1;                                   // after the sub-stepped tiles: single intervals
+                next_kind = min(next_kind, max_kind);
+            }
+            const int keep = min(keep_lanes * kSPL, nc);                       // steps kept
+            const int end_kept8 = pos8 + keep * d8;
+
+            // ---------------- commit: the tile's image goes to LDS (record for the next tile's history, source of the
+            // observations' states)
+            __syncthreads();                                                    // earlier readers of the image are done
+#pragma unroll
+            for (int s = 0; s < kSPL; ++s) {
+                const int e = lane * kSPL + s + 1;
+                im.W[e] = wg[s]; im.F[e] = Ef[4 + s]; im.M[e] = M1[s]; im.D[e] = fma(-M1[s], w.inv_tau, S1[s]);
+            }
+            if (lane == 0) { im.W[0] = om_s; im.F[0] = cf0; im.M[0] = M_s; im.D[0] = fma(-M_s, w.inv_tau, cS0); }
+            __syncthreads();
+
+            // ---------------- observations
             if constexpr (!CURVES) {
                 // The model is only needed at the two grid points bracketing each observation.  The lane holding an
-                // observation picks (Mdisc, omega) at those two points out of the tile's LDS image as the tile goes by
+                // observation picks (Mdisc, omega) at those two points out of the tile's image as the tile goes by
                 // (observations beyond the 64 register-resident ones: into the walker's scratch rows); the luminosity
                 // stage runs after the last tile on those captured states, once per 64 observations (the 10 001-point
                 // light curve is never formed).
-                int j0 = 0, j1 = 0;
-                if (long_lc) { j0 = max(tptr[tile * kSPL], 64); j1 = tptr[min((tile + 1) * kSPL, sh.n_tiles)]; }   // 64-step buckets
-                if (deferred && (__any(mine) || j1 > j0)) {
-                    double *Mbuf = Lbuf, *Wbuf = Lbuf + kTile + 1;
-#pragma unroll
-                    for (int s = 0; s < kSPL; ++s) { Mbuf[lane * kSPL + s + 1] = M1[s]; Wbuf[lane * kSPL + s + 1] = wg[s]; }
-                    if (lane == 0) { Mbuf[0] = M_s; Wbuf[0] = om_s; }
-                    if constexpr (ROLE == 1) wave_lds_fence(); else __syncthreads();
-                    if (mine) {
-                        const int g = ob_g - tile * kTile;
-                        obM[0] = Mbuf[g]; obM[1] = Mbuf[g + 1];
-                        obW[0] = Wbuf[g]; obW[1] = Wbuf[g + 1];
+                if (deferred) {
+                    const int p8 = 8 * ob_g;
+                    if (ob_g >= 0 && p8 >= pos8 && p8 < end_kept8) {
+                        image_state(sh, im, kind, pos8, d8, t_s, p8, obM[0], obW[0]);
+                        image_state(sh, im, kind, pos8, d8, t_s, p8 + 8, obM[1], obW[1]);
                     }
-                    for (int j = j0 + lane; j < j1; j += 64) {
-                        const int g = sh.obs_g[dsd.obs_off + j] - tile * kTile;
-                        double *p = sc + (j - 64);
-                        p[0] = Mbuf[g]; p[sc_stride] = Mbuf[g + 1];
-                        p[2 * sc_stride] = Wbuf[g]; p[3 * sc_stride] = Wbuf[g + 1];
+                    if (long_lc) {
+                        // observations 64.. whose interval starts inside the kept range (64-interval buckets of the dataset)
+                        const int g_lo = pos8 >> 3, g_hi = end_kept8 >> 3;                 // grid intervals [g_lo, g_hi)
+                        const int b_lo = g_lo / kTile64, b_hi = min((g_hi + kTile64 - 1) / kTile64, sh.n_tiles);
+                        const int j0 = max(tptr[b_lo], 64), j1 = tptr[b_hi];
+                        for (int j = j0 + lane; j < j1; j += 64) {
+                            const int g = sh.obs_g[dsd.obs_off + j];
+                            if (g < g_lo || g >= g_hi) continue;
+                            double Ma, Wa, Mb, Wb;
+                            image_state(sh, im, kind, pos8, d8, t_s, 8 * g, Ma, Wa);
+                            image_state(sh, im, kind, pos8, d8, t_s, 8 * g + 8, Mb, Wb);
+                            double *p = sc + (j - 64);
+                            p[0] = Ma; p[sc_stride] = Mb;
+                            p[2 * sc_stride] = Wa; p[3 * sc_stride] = Wb;
+                        }
                     }
-                    if constexpr (ROLE == 1) wave_lds_fence(); else __syncthreads();
                 }
-            } else {   // curve outputs requested: the whole light curve is formed anyway
-                int j0 = 0, j1 = 0;
-                if (long_lc) { j0 = max(tptr[tile * kSPL], 64); j1 = tptr[min((tile + 1) * kSPL, sh.n_tiles)]; }   // 64-step buckets
-                const bool tile_has_obs = __any(mine) || j1 > j0;
+            } else {   // curve outputs requested: every grid point is a step end (kinds 0 and 1 only)
                 Vd<kSPL> Lt, Lp, Ld;
                 luminosity(sh, w, d1, wg, Lt, Lp, Ld);
                 // The tile of the light curve is staged in LDS ([e + 1] = step end e, [0] = the tile's start point) for
                 // the interpolation and leaves for HBM from there with lane-contiguous addresses: every store
-                // instruction of the wavefront writes 512 consecutive bytes of the walker's row.
-                const int n_here = min(kTile, nsteps - tile * kTile);          // step ends of this tile that exist
-                const size_t o0 = row + (size_t)tile * kTile + 1;
+                // instruction of the wavefront writes 512 consecutive bytes of the walker's row.  In the sub-stepped
+                // tiles every 8th step end is a grid point.
+                const int sub = pre ? 8 : 1;                                    // step ends per grid interval
+                const int g0 = pos8 >> 3;                                       // grid index of the tile's start
+                const int n_here = keep / sub;                                  // grid points this tile adds
+                const size_t o0 = row + (size_t)g0 + 1;
                 double *S2 = Lbuf + kTile + 1;                                  // second staging area
 #pragma unroll
                 for (int s = 0; s < kSPL; ++s) Lbuf[lane * kSPL + s + 1] = Lt[s];
@@ -710,7 +728,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
 #pragma unroll
                     for (int c = 0; c < kSPL; ++c) {
                         const int e = c * 64 + lane;
-                        if (e < n_here) a.ltot[o0 + e] = Lbuf[e + 1] / 1.0e50;
+                        if (e < n_here) a.ltot[o0 + e] = Lbuf[(e + 1) * sub] / 1.0e50;
                     }
                 }
                 // the other curves (mp_model_lc only) go through the second staging area, one at a time
@@ -722,7 +740,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
 #pragma unroll
                     for (int c = 0; c < kSPL; ++c) {
                         const int e = c * 64 + lane;
-                        if (e < n_here) dst[o0 + e] = S2[e] / div;
+                        if (e < n_here) dst[o0 + e] = S2[(e + 1) * sub - 1] / div;
                     }
                     __syncthreads();
                 };
@@ -730,43 +748,52 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 put(a.ldip, Ld, 1.0e50);
                 put(a.mdisc, M1, 1.0);
                 put(a.omega, wg, 1.0);
-                if (tile_has_obs) {
-                    if (mine) {
-                        const int g = ob_g - tile * kTile;
-                        const double La = Lbuf[g], Lb = Lbuf[g + 1];
+                if (a.want_chi2) {
+                    const int g_hi = end_kept8 >> 3;
+                    if (ob_g >= g0 && ob_g < g_hi) {
+                        const int e = (ob_g - g0) * sub;
+                        const double La = Lbuf[e], Lb = Lbuf[e + sub];
                         const double mod = fma((Lb - La) * ob_idt, ob_dx, La) / 1.0e50;   // np.interp, then /1e50
                         const double res = (ob_y - mod) / ob_ye;
                         chi = fma(res, res, chi);
                     }
-                    for (int j = j0 + lane; j < j1; j += 64) {
-                        const int jj = dsd.obs_off + j;
-                        const int g = sh.obs_g[jj] - tile * kTile;
-                        const double La = Lbuf[g], Lb = Lbuf[g + 1];
-                        const double mod = fma((Lb - La) * sh.obs_idt[jj], sh.obs_dx[jj], La) / 1.0e50;
-                        const double res = (sh.obs_y[jj] - mod) / sh.obs_yerr[jj];
-                        chi = fma(res, res, chi);
+                    if (long_lc) {
+                        const int b_lo = g0 / kTile64, b_hi = min((g_hi + kTile64 - 1) / kTile64, sh.n_tiles);
+                        const int j0 = max(tptr[b_lo], 64), j1 = tptr[b_hi];
+                        for (int j = j0 + lane; j < j1; j += 64) {
+                            const int jj = dsd.obs_off + j;
+                            const int g = sh.obs_g[jj];
+                            if (g < g0 || g >= g_hi) continue;
+                            const int e = (g - g0) * sub;
+                            const double La = Lbuf[e], Lb = Lbuf[e + sub];
+                            const double mod = fma((Lb - La) * sh.obs_idt[jj], sh.obs_dx[jj], La) / 1.0e50;
+                            const double res = (sh.obs_y[jj] - mod) / sh.obs_yerr[jj];
+                            chi = fma(res, res, chi);
+                        }
                     }
                 }
+                L_s = Lbuf[keep];
                 __syncthreads();                                                // the next tile overwrites the staging area
-                L_s = lane_bcast(Lt[kSPL - 1], 63);
             }
 
-            // ---------------- carry the tile end (and the history behind it) to the next tile: only full tiles
-            // have a successor, so the sources are the last three step ends of lane 63
-            if (tile + 1 < n_tiles) {
-                // step end number e of the tile (0-based) lives in lane e / kSPL, slot e % kSPL
-                constexpr int e1 = kTile - 2, e2 = kTile - 3, e3 = kTile - 4, e4 = kTile - 5;
-                cS0 = lane_bcast(ES[3 + kSPL - 1], 63);            cf0 = lane_bcast(Ef[3 + kSPL - 1], 63);
-                cS1 = lane_bcast(ES[3 + e1 % kSPL], e1 / kSPL);    cf1 = lane_bcast(Ef[3 + e1 % kSPL], e1 / kSPL);
-                cS2 = lane_bcast(ES[3 + e2 % kSPL], e2 / kSPL);    cf2 = lane_bcast(Ef[3 + e2 % kSPL], e2 / kSPL);
-                cw1 = lane_bcast(wg[e1 % kSPL], e1 / kSPL);
-                cw2 = lane_bcast(wg[e2 % kSPL], e2 / kSPL);
-                cw3 = lane_bcast(wg[e3 % kSPL], e3 / kSPL);
-                cw4 = lane_bcast(wg[e4 % kSPL], e4 / kSPL);
-                t_s = lane_bcast(tb[kSPL - 1], 63);
-                M_s = lane_bcast(M1[kSPL - 1], 63);
-                om_s = lane_bcast(wg[kSPL - 1], 63);
+            // ---------------- carry the end of the kept steps to the next tile
+            {
+                const Vd<1> ee{{(double)keep * K.lnQ}};
+                t_s = t_s * exp_fast(ee)[0];
+                M_s = im.M[keep];
+                om_s = im.W[keep];
+                cf0 = im.F[keep];
+                Vd<1> md;
+                md[0] = M_s * w.inv_tau;
+                const double t17 = pow_m1_7_fast(md)[0];
+                flags_s = branch_flags(w, w.Crm * (t17 * t17), om_s);
             }
+            rec_valid = true;
+            rec_kind = kind;
+            rec_d8 = d8;
+            rec_J = keep;
+            pos8 = end_kept8;
+            kind = next_kind;
         }
         if (deferred && status == MP_STATUS_OK) {   // the luminosity evaluations of this walker: one per 64 observations
             const Vd<2> Mv{{obM[0], obM[1]}}, Wv{{obW[0], obW[1]}};
@@ -779,7 +806,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 chi = res * res;
             }
             if (long_lc) {
-                if constexpr (ROLE == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else __syncthreads();   // scratch rows written by other lanes
+                __syncthreads();   // scratch rows written by other lanes
                 for (int jb = 64; jb < dsd.n_obs; jb += 64) {
                     const bool valid = jb + lane < dsd.n_obs;
                     const int j = valid ? jb + lane : dsd.n_obs - 1;
@@ -796,8 +823,6 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
             }
         }
     }
-
-    if constexpr (ROLE == 1) ring_store(&ring->abort, 1);   // done (or failed): release the producer
 
     if constexpr (CURVES) {
         // A walker that did not finish (prior, flag, non-finite) leaves NaN in every requested curve: the rows of a
@@ -823,6 +848,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
     lnp_out = lnp;
     status_out = status;
     sweeps_out = sweeps_total;
+    tiles_out = tiles_total;
 }
 
 }  // namespace mp

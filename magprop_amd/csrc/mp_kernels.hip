@@ -24,9 +24,8 @@
 //      tile's light curve is staged in LDS for the interpolation and written to HBM with coalesced stores.
 //   4. A wavefront reduction of the per-lane chi^2 terms gives -0.5*chi^2 (code/synthetic_datasets/mcmc_eqns.py:25).
 //
-// Kernels: lnprob_kernel<CURVES, SPL, LONG> (one wavefront per walker), lnprob_pc_kernel<SPL, LONG> (a producer and a
-// consumer wavefront per walker for batches that cannot fill the SIMDs), stretch_kernel<SPL, LONG, PC> (emcee's stretch
-// move fused around either) and stretch_apply_kernel (the state update of a half-step whose proposals were evaluated
+// Kernels: lnprob_kernel<CURVES, SPL, LONG> (one wavefront per walker), stretch_kernel<SPL, LONG> (emcee's stretch
+// move fused around it) and stretch_apply_kernel (the state update of a half-step whose proposals were evaluated
 // on several GPUs); LONG = built with the scratch-row path for light curves of more than 64 points.
 // No MFMA (no dense contraction anywhere on this path), fp64 throughout; bound by the VALU issue rate of one wave per
 // SIMD (profiles/, tools/ubench).  The arithmetic is algebraically simplified with respect to the reference formulas
@@ -43,53 +42,23 @@ namespace mp {
 // ---------------------------------------------------------------- batched log-posterior kernel
 template <bool CURVES, int SPL, bool LONG>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, SPL >= 4 ? 1 : 2))) void lnprob_kernel(const DevShared sh, const LaunchArgs a) {
-    __shared__ double Lbuf[2 * (64 * SPL + 1)];
+    __shared__ TileImage<SPL> im;
+    __shared__ double Lbuf[CURVES ? 2 * (64 * SPL + 1) : 1];
     ktab_init();
+    wtab_init(sh.wtab);
     const int walker = blockIdx.x;
     double par[MP_MAX_NDIM];
     const double *pw = a.pars + (size_t)walker * a.ndim;
 #pragma unroll
     for (int i = 0; i < MP_MAX_NDIM; ++i) par[i] = i < a.ndim ? pw[i] : 0.0;
     double lnp;
-    int status, sweeps;
-    walker_eval<CURVES, SPL, LONG>(sh, a, walker, par, Lbuf, lnp, status, sweeps);
+    int status, sweeps, tiles;
+    walker_eval<CURVES, SPL, LONG>(sh, a, walker, par, im, Lbuf, lnp, status, sweeps, tiles);
     if (threadIdx.x == 0) {
         a.lnprob[walker] = lnp;
         if (a.status) a.status[walker] = status;
         if (a.sweeps) a.sweeps[walker] = sweeps;
-    }
-}
-
-// Two wavefronts per walker, producer (Mdisc phase) and consumer (omega, observations): mp_eval.hpp, PcRing.
-// The consumer is the critical path: it runs at raised issue priority, so that where both wavefronts of a pair (or of two
-// pairs) share a SIMD the producer only takes the issue slots the consumer leaves free.
-constexpr int kPcPrio = 3;
-MP_DEV bool pc_is_producer() { return threadIdx.x >= 64; }
-
-template <int SPL, bool LONG>
-__global__ __launch_bounds__(128) void lnprob_pc_kernel(const DevShared sh, const LaunchArgs a) {
-    __shared__ double Lbuf[2 * (64 * SPL + 1)];
-    __shared__ PcRing<SPL> ring;
-    ktab_init();
-    const int walker = blockIdx.x;
-    double par[MP_MAX_NDIM];
-    const double *pw = a.pars + (size_t)walker * a.ndim;
-#pragma unroll
-    for (int i = 0; i < MP_MAX_NDIM; ++i) par[i] = i < a.ndim ? pw[i] : 0.0;
-    if (threadIdx.x == 0) { ring.produced = 0; ring.consumed = 0; ring.abort = 0; }
-    __syncthreads();
-    if (pc_is_producer()) {
-        walker_produce<SPL>(sh, a, par, ring);
-        return;
-    }
-    __builtin_amdgcn_s_setprio(kPcPrio);
-    double lnp;
-    int status, sweeps;
-    walker_eval<false, SPL, LONG, 1>(sh, a, walker, par, Lbuf, lnp, status, sweeps, &ring);
-    if ((threadIdx.x & 63) == 0) {
-        a.lnprob[walker] = lnp;
-        if (a.status) a.status[walker] = status;
-        if (a.sweeps) a.sweeps[walker] = sweeps;
+        if (a.tiles) a.tiles[walker] = tiles;
     }
 }
 
@@ -131,18 +100,17 @@ MP_DEV double u01(uint32_t hi, uint32_t lo) {   // 53-bit uniform in [0, 1)
 // proposal (emcee's StretchMove.get_proposal), evaluate its log-posterior with walker_eval, accept or
 // reject against the walker's current value, update position / lnprob / counters in place and write the
 // step's row of the chain.  Walkers of the complementary half are only read, so the update is race-free.
-// PC: producer/consumer pair of wavefronts (128 threads), see lnprob_pc_kernel.
 // A launch covers the slots [slot_lo, slot_lo + gridDim.x) of the active half (all ensembles flattened).  With g.upd set
 // (walker-sharded ensembles, one process per GPU) nothing is updated in place: the outcome of slot s goes to row
 // s - slot_lo of g.upd as (proposal[ndim], its lnprob, accepted 0/1) and stretch_apply_kernel commits the rows of all
 // ranks after the all-gather.  The random numbers are keyed by (seed; step, half, walker), so every rank draws what the
 // single-GPU launch would have drawn for the same walker.
-struct NoRing {};
-template <int SPL, bool LONG, bool PC = false>
-__global__ __launch_bounds__(PC ? 128 : 64) void stretch_kernel(const DevShared sh, const StretchArgs g) {
-    __shared__ double lds[2 * (64 * SPL + 1)];
-    __shared__ typename std::conditional<PC, PcRing<SPL>, NoRing>::type ring;
+template <int SPL, bool LONG>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, SPL >= 4 ? 1 : 2))) void stretch_kernel(const DevShared sh, const StretchArgs g) {
+    __shared__ TileImage<SPL> im;
+    __shared__ double lds[1];
     ktab_init();
+    wtab_init(sh.wtab);
     const int gs = g.slot_lo + (int)blockIdx.x;                    // slot of the active half, all ensembles flattened
     const int w_ens = gs / g.n_half;                               // which ensemble
     const int slot = gs - w_ens * g.n_half;                        // which walker of the active half
@@ -173,26 +141,14 @@ __global__ __launch_bounds__(PC ? 128 : 64) void stretch_kernel(const DevShared 
     a.ndim = g.ndim;
     a.physical = 0;
     a.want_chi2 = 1;
-    if constexpr (PC) {
-        // both wavefronts hold the same proposal; the barrier also keeps the producer's reads of pos[] ahead of the
-        // consumer's update of it at the very end
-        if (threadIdx.x == 0) { ring.produced = 0; ring.consumed = 0; ring.abort = 0; }
-        __syncthreads();
-        if (pc_is_producer()) {
-            if (g.target != 1) walker_produce<SPL>(sh, a, par, ring);
-            return;
-        }
-        __builtin_amdgcn_s_setprio(kPcPrio);
-    }
     double lnp;
-    int status = MP_STATUS_OK, sweeps;
+    int status = MP_STATUS_OK, sweeps, tiles;
     if (g.target == 1) {   // isotropic unit Gaussian: exercises the move itself (tests)
         lnp = 0.0;
 #pragma unroll
         for (int i = 0; i < MP_MAX_NDIM; ++i) lnp = i < g.ndim ? sub_rn(lnp, mul_rn(mul_rn(0.5, prop[i]), prop[i])) : lnp;
     } else {
-        if constexpr (PC) walker_eval<false, SPL, LONG, 1>(sh, a, k, par, lds, lnp, status, sweeps, &ring);
-        else walker_eval<false, SPL, LONG>(sh, a, k, par, lds, lnp, status, sweeps);
+        walker_eval<false, SPL, LONG>(sh, a, k, par, im, lds, lnp, status, sweeps, tiles);
     }
     if ((threadIdx.x & 63) == 0) {   // lane 0 of the evaluating wavefront
         const double lnp_old = g.lnprob[k];
@@ -292,20 +248,14 @@ int launch_lnprob(const DevShared &sh, const LaunchArgs &a, void *stream) {
     const bool curves = a.ltot || a.lprop || a.ldip || a.mdisc || a.omega;
     dim3 grid((unsigned)a.n), block(64);
     // Variants (results agree to rounding); sh.n_simd = SIMDs of the device:
-    //  - up to n_simd/2 walkers (SIMDs to spare): a producer/consumer pair of wavefronts per walker (the omega-independent
-    //    Mdisc phase runs ahead on the second wavefront; bit-identical to the one-wavefront kernel, 17-20 % sooner);
-    //  - up to n_simd walkers (one wave per SIMD): one wavefront per walker, four steps per lane (256-step tiles
-    //    amortise the wavefront scans best; needs the whole register file of a SIMD);
-    //  - beyond: two steps per lane, which keeps two waves resident per SIMD (they fill each other's issue gaps).
+    //  - up to n_simd walkers (one wave per SIMD): four steps per lane (256-step tiles amortise the wavefront scans best;
+    //    needs the whole register file of a SIMD);
+    //  - beyond: two steps per lane, which keeps two waves resident per SIMD (they fill each other's issue gaps);
     //  - a handle that holds a light curve of more than 64 points runs the LONG builds of the same kernels.
     const bool wide = (sh.force_spl ? sh.force_spl : kernel_spl(sh, a.n)) == 4;
     const bool lng = sh.scratch_stride > 0;
     hipStream_t st = (hipStream_t)stream;
-    const bool pc = !curves && sh.force_pc >= 0 && !sh.force_spl && (sh.force_pc == 1 || two_wave_pair(sh, a.n));
-    if (pc) {
-        if (lng) hipLaunchKernelGGL((lnprob_pc_kernel<4, true>), grid, dim3(128), 0, st, sh, a);
-        else hipLaunchKernelGGL((lnprob_pc_kernel<4, false>), grid, dim3(128), 0, st, sh, a);
-    } else if (curves) {
+    if (curves) {
         if (wide) hipLaunchKernelGGL((lnprob_kernel<true, 4, false>), grid, block, 0, st, sh, a);
         else hipLaunchKernelGGL((lnprob_kernel<true, 2, false>), grid, block, 0, st, sh, a);
     } else if (wide) {
@@ -324,11 +274,7 @@ int launch_stretch(const DevShared &sh, const StretchArgs &g, int n_blocks, void
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)n_blocks);
     const bool lng = sh.scratch_stride > 0;
-    const bool pc = g.target != 1 && sh.force_pc >= 0 && !sh.force_spl && (sh.force_pc == 1 || two_wave_pair(sh, n_blocks));
-    if (pc) {
-        if (lng) hipLaunchKernelGGL((stretch_kernel<4, true, true>), grid, dim3(128), 0, st, sh, g);
-        else hipLaunchKernelGGL((stretch_kernel<4, false, true>), grid, dim3(128), 0, st, sh, g);
-    } else if ((sh.force_spl ? sh.force_spl : kernel_spl(sh, n_blocks)) == 4) {
+    if ((sh.force_spl ? sh.force_spl : kernel_spl(sh, n_blocks)) == 4) {
         if (lng) hipLaunchKernelGGL((stretch_kernel<4, true>), grid, dim3(64), 0, st, sh, g);
         else hipLaunchKernelGGL((stretch_kernel<4, false>), grid, dim3(64), 0, st, sh, g);
     } else {

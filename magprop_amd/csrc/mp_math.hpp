@@ -176,17 +176,18 @@ MP_DEV void horner(Vd<N> &p, const Vd<N> &x, double c) {
 // two v_mov_b32 per use site (14 % of the Newton-sweep loop).  Measured (tools/ab_run.sh): the table wins 2.6 % where
 // two waves share a SIMD (the 2-steps-per-lane kernels: the other wave covers the LDS latency) and loses 1.5 % with one
 // wave per SIMD (4 steps per lane, and the 4-wavefront kernel with 1 step per lane: +2.4 %), so it is used for N == 2 only.  Layout: [k] = 1/(16-k)! for k = 0..13 (1/16! .. 1/3!), then
-// log2(e), -ln2_hi, -ln2_lo, pad.  Filled by ktab_init() at kernel entry.
+// log2(e), -ln2_hi, -ln2_lo, pad, 1/17!, pad.  Filled by ktab_init() at kernel entry.
 typedef double d2v __attribute__((ext_vector_type(2)));
 template <int N>
 constexpr bool kUseKtab = N == 2;
-constexpr int kKtabN = 18;
+constexpr int kKtabN = 20;
 __shared__ __attribute__((aligned(16))) double g_ktab[kKtabN];
 
 __constant__ double kKtabInit[kKtabN] = {
     1.0 / 20922789888000.0, 1.0 / 1307674368000.0, 1.0 / 87178291200.0, 1.0 / 6227020800.0, 1.0 / 479001600.0,
     1.0 / 39916800.0, 1.0 / 3628800.0, 1.0 / 362880.0, 1.0 / 40320.0, 1.0 / 5040.0, 1.0 / 720.0, 1.0 / 120.0,
-    1.0 / 24.0, 1.0 / 6.0, 1.4426950408889634074, -6.93147180369123816490e-01, -1.90821492927058770002e-10, 0.0};
+    1.0 / 24.0, 1.0 / 6.0, 1.4426950408889634074, -6.93147180369123816490e-01, -1.90821492927058770002e-10, 0.0,
+    1.0 / 355687428096000.0, 0.0};   // [18] = 1/17! (phi_5 series)
 
 MP_DEV void ktab_init() {   // every thread of the workgroup calls this once, before any table read
     if (threadIdx.x < kKtabN) g_ktab[threadIdx.x] = kKtabInit[threadIdx.x];
@@ -195,6 +196,19 @@ MP_DEV void ktab_init() {   // every thread of the workgroup calls this once, be
 
 MP_DEV d2v ktab2(int k) {   // entries k, k+1 (k even); volatile: stays where it is written, inside the loops
     return *(volatile const __attribute__((address_space(3))) d2v *)&g_ktab[k];   // LDS pointer type: ds_read_b128, not flat
+}
+
+// The quadrature matrices of the four tile kinds (mp_device.h: kWtabStride doubles per kind), copied from the device table
+// at kernel entry and read with broadcast ds_read_b128 where they are used.
+__shared__ __attribute__((aligned(16))) double g_wtab[4 * kWtabStride];
+
+MP_DEV void wtab_init(const double *src) {   // every thread of the workgroup calls this once, before any table read
+    for (int i = threadIdx.x; i < 4 * kWtabStride; i += blockDim.x) g_wtab[i] = src[i];
+    __syncthreads();
+}
+
+MP_DEV d2v wtab2(int k) {   // entries k, k+1 (k even)
+    return *(volatile const __attribute__((address_space(3))) d2v *)&g_wtab[k];
 }
 
 // p <- (p*x + c[k])*x + c[k+1] on all N chains
@@ -414,51 +428,150 @@ MP_DEV Phi<N> phi1234(const Vd<N> &z) {
 }
 
 // h * int_0^1 e^{z(1-theta)} P(theta) dtheta for the cubic P through the node values v0..v3 at
-// t_{j+1}, t_j, t_{j-1}, t_{j-2} (quadrature matrix W of the geometric grid, DevShared::eamW)
+// t_{j+1}, t_j, t_{j-1}, t_{j-2} (quadrature matrix W4 of the tile's kind, LDS table at wbase)
 template <int N>
-MP_DEV Vd<N> eam4_increment(const DevShared &sh, const Phi<N> &p, const Vd<N> &h, const Vd<N> &v0, const Vd<N> &v1,
+MP_DEV Vd<N> eam4_increment(int wbase, const Phi<N> &p, const Vd<N> &h, const Vd<N> &v0, const Vd<N> &v1,
                             const Vd<N> &v2, const Vd<N> &v3) {
     Vd<N> acc, g;
     FORN acc[i] = 0.0;
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         const Vd<N> &ph = m == 0 ? p.p1 : m == 1 ? p.p2 : m == 2 ? p.p3 : p.p4;
-        FORN g[i] = sh.eamW[3][m] * v3[i];
-        FORN g[i] = fma(sh.eamW[2][m], v2[i], g[i]);
-        FORN g[i] = fma(sh.eamW[1][m], v1[i], g[i]);
-        FORN g[i] = fma(sh.eamW[0][m], v0[i], g[i]);
+        const d2v a = wtab2(wbase + kWtabW4 + 4 * m), b = wtab2(wbase + kWtabW4 + 4 * m + 2);   // W4[0..3][m]
+        FORN g[i] = b.y * v3[i];
+        FORN g[i] = fma(b.x, v2[i], g[i]);
+        FORN g[i] = fma(a.y, v1[i], g[i]);
+        FORN g[i] = fma(a.x, v0[i], g[i]);
         FORN acc[i] = fma(ph[i], g[i], acc[i]);
     }
     FORN acc[i] = h[i] * acc[i];
     return acc;
 }
 
-// The same quadrature in node form: c_k = sum_m W[k][m] phi_{m+1}(z), increment = h * sum_k c_k v_k.  The Newton sweeps
-// use this form because the weights depend on z = h*lambda only: a sweep that keeps lambda keeps them too.
+// ---------------------------------------------------------------- order 5 (the omega equation)
+// phi_1..phi_5 of z = h*lambda.  Taylor series of phi_5: 7 terms when every |z| of the wavefront is below 1/32 (< 1e-17
+// relative), 13 terms for |z| < 1/2, closed forms elsewhere.
 template <int N>
-struct EamW {
-    Vd<N> c0, c1, c2, c3;
+struct Phi5 {
+    Vd<N> e, p1, p2, p3, p4, p5;
 };
 
 template <int N>
-MP_DEV EamW<N> eam4_node_weights(const DevShared &sh, const Phi<N> &p) {
-    EamW<N> w;
+MP_DEV Phi5<N> phi12345(const Vd<N> &z) {
+    Vd<N> s;
+    const double zmax = lane_maxabs(z.v);          // the lane's largest |z|: one comparison per range instead of one per step
+    const bool all_tiny = zmax < 0.03125;
+    double inv6 = 1.0 / 6.0, inv24 = 1.0 / 24.0;
+    if constexpr (kUseKtab<N>) {
+        if (__all(all_tiny)) {
+            const d2v c4 = ktab2(4), c6 = ktab2(6), c8 = ktab2(8), c10 = ktab2(10), c12 = ktab2(12);
+            FORN s[i] = fma3(z[i], c4.y, c6.x);       // z/11! + 1/10!
+            FORN s[i] = fma3(s[i], z[i], c6.y);       // 1/9!
+            FORN s[i] = fma3(s[i], z[i], c8.x);       // 1/8!
+            FORN s[i] = fma3(s[i], z[i], c8.y);       // 1/7!
+            FORN s[i] = fma3(s[i], z[i], c10.x);      // 1/6!
+            FORN s[i] = fma3(s[i], z[i], c10.y);      // 1/5!
+            inv24 = c12.x; inv6 = c12.y;
+        } else {
+            {
+                const d2v a = ktab2(18), b = ktab2(0);
+                FORN s[i] = fma3(z[i], a.x, b.x);     // z/17! + 1/16!
+                FORN s[i] = fma3(s[i], z[i], b.y);    // 1/15!
+            }
+            horner2(s, z, 2);                         // 1/14!, 1/13!
+            horner2(s, z, 4);                         // 1/12!, 1/11!
+            horner2(s, z, 6);                         // 1/10!, 1/9!
+            horner2(s, z, 8);                         // 1/8!, 1/7!
+            horner2(s, z, 10);                        // 1/6!, 1/5!
+            const d2v c = ktab2(12);
+            inv24 = c.x; inv6 = c.y;
+        }
+    } else if (__all(all_tiny)) {
+        FORN s[i] = 1.0 / 39916800.0;             // 1/11!
+        horner(s, z, 1.0 / 3628800.0);            // 1/10!
+        horner(s, z, 1.0 / 362880.0);             // 1/9!
+        horner(s, z, 1.0 / 40320.0);              // 1/8!
+        horner(s, z, 1.0 / 5040.0);               // 1/7!
+        horner(s, z, 1.0 / 720.0);                // 1/6!
+        horner(s, z, 1.0 / 120.0);                // 1/5!
+    } else {
+        FORN s[i] = 1.0 / 355687428096000.0;      // 1/17!
+        horner(s, z, 1.0 / 20922789888000.0);     // 1/16!
+        horner(s, z, 1.0 / 1307674368000.0);      // 1/15!
+        horner(s, z, 1.0 / 87178291200.0);        // 1/14!
+        horner(s, z, 1.0 / 6227020800.0);         // 1/13!
+        horner(s, z, 1.0 / 479001600.0);          // 1/12!
+        horner(s, z, 1.0 / 39916800.0);           // 1/11!
+        horner(s, z, 1.0 / 3628800.0);            // 1/10!
+        horner(s, z, 1.0 / 362880.0);             // 1/9!
+        horner(s, z, 1.0 / 40320.0);              // 1/8!
+        horner(s, z, 1.0 / 5040.0);               // 1/7!
+        horner(s, z, 1.0 / 720.0);                // 1/6!
+        horner(s, z, 1.0 / 120.0);                // 1/5!
+    }
+    Phi5<N> r;
+    r.p5 = s;
+    FORN r.p4[i] = fma(z[i], s[i], inv24);
+    FORN r.p3[i] = fma(z[i], r.p4[i], inv6);
+    FORN r.p2[i] = fma(z[i], r.p3[i], 0.5);
+    FORN r.p1[i] = fma(z[i], r.p2[i], 1.0);
+    FORN r.e[i] = fma(z[i], r.p1[i], 1.0);
+    const bool any_big = !(zmax < 0.5);           // (a NaN among the z is not seen by fmax: it stays a NaN in the series below)
+    if (__any(any_big)) {                          // wave-uniform: only stiff / late-time tiles pay for this
+        Vb<N> big;
+        FORN big[i] = !(fabs(z[i]) < 0.5);
+        Vd<N> zc, zs;
+        FORN zc[i] = fmax(z[i], -750.0);
+        FORN zs[i] = big[i] ? z[i] : 1.0;
+        const Vd<N> ce = exp_fast(zc);
+        const Vd<N> rz = rcp_fast(zs);
+        FORN {
+            const double c1 = (ce[i] - 1.0) * rz[i];
+            const double c2 = (c1 - 1.0) * rz[i];
+            const double c3 = (c2 - 0.5) * rz[i];
+            const double c4 = (c3 - inv6) * rz[i];
+            const double c5 = (c4 - inv24) * rz[i];
+            r.e[i] = big[i] ? ce[i] : r.e[i];
+            r.p1[i] = big[i] ? c1 : r.p1[i];
+            r.p2[i] = big[i] ? c2 : r.p2[i];
+            r.p3[i] = big[i] ? c3 : r.p3[i];
+            r.p4[i] = big[i] ? c4 : r.p4[i];
+            r.p5[i] = big[i] ? c5 : r.p5[i];
+        }
+    }
+    return r;
+}
+
+// The quadrature in node form: c_k = sum_m W[k][m] phi_{m+1}(z), increment = h * sum_k c_k v_k for the quartic through
+// the node values v0..v4 at t_{j+1}, t_j, ..., t_{j-3}.  The Newton sweeps use this form because the weights depend on
+// z = h*lambda only: a sweep that keeps lambda keeps them too.
+template <int N>
+struct EamW5 {
+    Vd<N> c0, c1, c2, c3, c4;
+};
+
+template <int N>
+MP_DEV EamW5<N> eam5_node_weights(int wbase, const Phi5<N> &p) {
+    EamW5<N> w;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        Vd<N> &c = k == 0 ? w.c0 : k == 1 ? w.c1 : k == 2 ? w.c2 : w.c3;
-        FORN c[i] = sh.eamW[k][3] * p.p4[i];
-        FORN c[i] = fma(sh.eamW[k][2], p.p3[i], c[i]);
-        FORN c[i] = fma(sh.eamW[k][1], p.p2[i], c[i]);
-        FORN c[i] = fma(sh.eamW[k][0], p.p1[i], c[i]);
+    for (int k = 0; k < 5; ++k) {
+        Vd<N> &c = k == 0 ? w.c0 : k == 1 ? w.c1 : k == 2 ? w.c2 : k == 3 ? w.c3 : w.c4;
+        const d2v a = wtab2(wbase + 6 * k), b = wtab2(wbase + 6 * k + 2), e = wtab2(wbase + 6 * k + 4);   // W5[k][0..4]
+        FORN c[i] = e.x * p.p5[i];
+        FORN c[i] = fma(b.y, p.p4[i], c[i]);
+        FORN c[i] = fma(b.x, p.p3[i], c[i]);
+        FORN c[i] = fma(a.y, p.p2[i], c[i]);
+        FORN c[i] = fma(a.x, p.p1[i], c[i]);
     }
     return w;
 }
 
 template <int N>
-MP_DEV Vd<N> eam4_increment_nodes(const EamW<N> &w, const Vd<N> &h, const Vd<N> &v0, const Vd<N> &v1, const Vd<N> &v2,
-                                  const Vd<N> &v3) {
+MP_DEV Vd<N> eam5_increment_nodes(const EamW5<N> &w, const Vd<N> &h, const Vd<N> &v0, const Vd<N> &v1, const Vd<N> &v2,
+                                  const Vd<N> &v3, const Vd<N> &v4) {
     Vd<N> acc;
-    FORN acc[i] = w.c3[i] * v3[i];
+    FORN acc[i] = w.c4[i] * v4[i];
+    FORN acc[i] = fma(w.c3[i], v3[i], acc[i]);
     FORN acc[i] = fma(w.c2[i], v2[i], acc[i]);
     FORN acc[i] = fma(w.c1[i], v1[i], acc[i]);
     FORN acc[i] = fma(w.c0[i], v0[i], acc[i]);

@@ -21,7 +21,7 @@ from . import _capi, engine, synth
 class EnsembleSampler:
     def __init__(self, nwalkers, ndim=6, x=None, y=None, yerr=None, variant="synth", GRBtype=None, seed=0, a=2.0,
                  datasets=None, lower="default", upper="default", log_mask=None, device=-1, target="posterior",
-                 fbad=None, sweep_tol=None):
+                 fbad=None, sweep_tol=None, max_stride=None):
         """One ensemble on dataset (x, y, yerr), or one ensemble per entry of `datasets` = [(x, y, yerr), ...].
         fbad: file that receives the proposals whose model failed, like the reference's lnprob(…, fbad)
         (code/synthetic_datasets/mcmc_eqns.py:72-79); written after every run_mcmc call."""
@@ -30,6 +30,8 @@ class EnsembleSampler:
         self.nwalkers, self.ndim = int(nwalkers), int(ndim)
         self._L = _capi.lib()
         tol_kw = {} if sweep_tol is None else {"sweep_tol": float(sweep_tol)}   # None: _capi.DEFAULT_SWEEP_TOL
+        if max_stride is not None:                                              # None: _capi.DEFAULT_MAX_STRIDE
+            tol_kw["max_stride"] = int(max_stride)
         if variant == "synth":
             cfg, lo, hi, mask = _capi.cfg_synth(**tol_kw), synth.PRIOR_LOWER, synth.PRIOR_UPPER, synth.LOG_MASK
         elif variant == "lib":

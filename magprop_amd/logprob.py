@@ -13,10 +13,13 @@ from . import _capi, engine, synth
 
 class LogProb:
     def __init__(self, x, y, yerr, variant="synth", GRBtype=None, lower="default", upper="default", log_mask=None,
-                 device=-1, fbad=None, sweep_tol=None):
+                 device=-1, fbad=None, sweep_tol=None, max_stride=None):
         """sweep_tol: Newton-sweep tolerance of the time-parallel solver (0 = the library default,
-        include/magprop_amd.h MP_SWEEP_TOL_DEFAULT)."""
+        include/magprop_amd.h MP_SWEEP_TOL_DEFAULT).  max_stride: grid intervals one step of the solver may span (1, 2, 4;
+        0 = the library default 4; 1 = every grid interval is a step)."""
         tol_kw = {} if sweep_tol is None else {"sweep_tol": float(sweep_tol)}   # None: _capi.DEFAULT_SWEEP_TOL
+        if max_stride is not None:                                              # None: _capi.DEFAULT_MAX_STRIDE
+            tol_kw["max_stride"] = int(max_stride)
         if variant == "synth":
             cfg = _capi.cfg_synth(**tol_kw)
             lo, hi, mask = synth.PRIOR_LOWER, synth.PRIOR_UPPER, synth.LOG_MASK

@@ -96,15 +96,16 @@ def pytest_collection_modifyitems(config, items):
 
 @pytest.fixture
 def strict():
-    """Newton-sweep tolerance 1e-9 (MP_SWEEP_TOL_STRICT) for every handle created inside the test: used where the HIP
-    kernels are compared with the serial C restatement of the scheme or with each other (1e-10).  Everything that is
-    compared with the reference's golden values runs at the product's default tolerance."""
+    """Newton-sweep tolerance 1e-9 (MP_SWEEP_TOL_STRICT) and max_stride 1 (every grid interval a step) for every handle
+    created inside the test: used where the HIP kernels are compared with the serial C restatement of the fixed-step scheme
+    or with each other (1e-10).  Everything that is compared with the reference's golden values runs at the product's
+    defaults (adaptive stride, sweep tolerance 1e-7)."""
     from magprop_amd import _capi, engine
     engine.clear()
-    old = _capi.DEFAULT_SWEEP_TOL
-    _capi.DEFAULT_SWEEP_TOL = _capi.SWEEP_TOL_STRICT
+    old = _capi.DEFAULT_SWEEP_TOL, _capi.DEFAULT_MAX_STRIDE
+    _capi.DEFAULT_SWEEP_TOL, _capi.DEFAULT_MAX_STRIDE = _capi.SWEEP_TOL_STRICT, 1
     yield
-    _capi.DEFAULT_SWEEP_TOL = old
+    _capi.DEFAULT_SWEEP_TOL, _capi.DEFAULT_MAX_STRIDE = old
     engine.clear()
 
 

@@ -56,9 +56,10 @@ def synth_handle(mpa, tarr, gsynth):
 
 @pytest.fixture(scope="module")
 def synth_handle_strict(mpa, tarr, gsynth):
-    """MP_SWEEP_TOL_STRICT: what is compared with the serial C restatement of the scheme (1e-10)."""
+    """MP_SWEEP_TOL_STRICT and every grid interval a step: what is compared with the serial C restatement of the fixed-step
+    scheme (1e-10)."""
     from magprop_amd import _capi
-    h = _synth_handle(tarr, gsynth, sweep_tol=_capi.SWEEP_TOL_STRICT)
+    h = _synth_handle(tarr, gsynth, sweep_tol=_capi.SWEEP_TOL_STRICT, max_stride=1)
     yield h
     h.close()
 
