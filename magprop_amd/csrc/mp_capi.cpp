@@ -264,14 +264,14 @@ mp_handle *mp_create(const mp_model_cfg *cfg, const double *tgrid, int n_grid, i
         }
     // The integrator is built on a geometric grid (np.logspace), the only kind the reference uses
     // (magnetar/funcs.py:132-137, code/synthetic_datasets/funcs.py:19).
-    const double q = std::exp(std::log(tgrid[n_grid - 1] / tgrid[0]) / (double)(n_grid - 1));
     if (!(tgrid[0] > 0.0)) {
         fail(MP_EINVAL, "mp_create: tgrid must be positive");
         return nullptr;
     }
     // the kernels generate the step end times themselves, t_i = t_0 q^i: the grid has to be geometric to rounding
+    const double lnq_check = std::log(tgrid[n_grid - 1] / tgrid[0]) / (double)(n_grid - 1);
     for (int i = 1; i < n_grid; ++i)
-        if (std::fabs(tgrid[i] / (tgrid[0] * std::exp((double)i * std::log(q))) - 1.0) > 1.0e-12) {
+        if (std::fabs(tgrid[i] / (tgrid[0] * std::exp((double)i * lnq_check)) - 1.0) > 1.0e-12) {
             fail(MP_EINVAL, "mp_create: tgrid must be log-spaced (np.logspace); it leaves t0*q^i at index %d", i);
             return nullptr;
         }
@@ -402,15 +402,22 @@ mp_handle *mp_create(const mp_model_cfg *cfg, const double *tgrid, int n_grid, i
         K.inv_Q = std::exp(-lnQ);
         K.one_m_invQ = -std::expm1(-lnQ);
         const int ns = kind == 0 ? 1 : (1 << (kind - 1));
-        for (int i = 0; i < 4; ++i) K.theta[i] = (i < ns && ns > 1) ? std::expm1(lnq * (double)i) / std::expm1(lnQ) : 0.0;
-        double W4[16], W5[25];
-        quad_weights(std::exp(lnQ), 4, W4);
+        for (int i = 0; i < 4; ++i) {
+            const double th = (i < ns && ns > 1) ? std::expm1(lnq * (double)i) / std::expm1(lnQ) : 0.0;
+            const double t2 = th * th, t3 = t2 * th, t4 = t3 * th, t5 = t4 * th;
+            K.theta[i] = th;
+            K.hq[i][0] = 1.0 - 10.0 * t3 + 15.0 * t4 - 6.0 * t5;
+            K.hq[i][1] = th - 6.0 * t3 + 8.0 * t4 - 3.0 * t5;
+            K.hq[i][2] = 0.5 * t2 - 1.5 * t3 + 1.5 * t4 - 0.5 * t5;
+            K.hq[i][3] = 10.0 * t3 - 15.0 * t4 + 6.0 * t5;
+            K.hq[i][4] = -4.0 * t3 + 7.0 * t4 - 3.0 * t5;
+            K.hq[i][5] = 0.5 * t3 - t4 + 0.5 * t5;
+        }
+        double W5[25];
         quad_weights(std::exp(lnQ), 5, W5);
         double *T = wtab.data() + (size_t)kind * mp::kWtabStride;
         for (int k = 0; k < 5; ++k)
             for (int m = 0; m < 5; ++m) T[6 * k + m] = W5[k * 5 + m];
-        for (int k = 0; k < 4; ++k)
-            for (int m = 0; m < 4; ++m) T[mp::kWtabW4 + 4 * m + k] = W4[k * 4 + m];
     }
     if (h->d_wtab.ensure(wtab.size()) != MP_OK ||
         hipMemcpy(h->d_wtab.p, wtab.data(), wtab.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {

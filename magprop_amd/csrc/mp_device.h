@@ -33,16 +33,15 @@ struct StrideK {
     double inv_Q;        // 1/Q
     double one_m_invQ;   // 1 - 1/Q: step length = (step end time) * this
     double theta[4];     // time fraction of grid point i (i = 1..3) inside a step of kinds 2 and 3: (q^i - 1)/(Q - 1)
+    double hq[4][6];     // quintic Hermite basis at theta[i]: weights of y0, h y0', h^2 y0'', y1, h y1', h^2 y1'' (Mdisc)
 };
 
 // The quadrature matrices of the four kinds live in a device table (DevShared::wtab) that every workgroup copies into LDS
 // once: per kind kWtabStride doubles,
-//   [6 k + m]      W5[k][m], k, m = 0..4: order-5 quadrature on nodes t_{j+1} .. t_{j-3} (omega); rows padded to 6
-//   [30 + 4 m + k] W4[k][m], k, m = 0..3: order-4 quadrature on nodes t_{j+1} .. t_{j-2} (Mdisc: the source is analytic)
-// (25 + 16 wave-uniform doubles per kind do not fit the scalar registers next to the walker constants; from LDS they are
-// read where they are used, two per broadcast ds_read_b128).
-constexpr int kWtabStride = 48;
-constexpr int kWtabW4 = 30;
+//   [6 k + m]      W5[k][m], k, m = 0..4: order-5 quadrature on nodes t_{j+1} .. t_{j-3}; rows padded to 6
+// (25 wave-uniform doubles per kind do not fit the scalar registers next to the walker constants; from LDS they are read
+// where they are used, two per broadcast ds_read_b128).
+constexpr int kWtabStride = 32;
 
 // Everything the kernel reads that is shared by all walkers (resident in HBM, L2-hot).
 struct DevShared {

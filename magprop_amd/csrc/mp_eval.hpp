@@ -59,6 +59,21 @@ MP_DEV Vd<N> mdot_fb(const Walker &w, const Vd<N> &t) {
     return out;
 }
 
+// the same with its time derivative dMdotfb/dt = -(5/3) Mdotfb / (t + tfb)
+template <int N>
+MP_DEV Vd<N> mdot_fb_d(const Walker &w, const Vd<N> &t, Vd<N> &dS) {
+    Vd<N> u;
+    FORN u[i] = fma(t[i], w.inv_tfb, 1.0);
+    const Vd<N> r = rcbrt_fast(u);
+    Vd<N> out;
+    FORN {
+        const double r2 = r[i] * r[i], r3 = r2 * r[i];
+        out[i] = w.S_amp * (r2 * r3);
+        dS[i] = (-5.0 / 3.0) * w.inv_tfb * out[i] * r3;             // 1/u = r^3
+    }
+    return out;
+}
+
 // Radii / fastness / switch shared by the ODE right-hand side and the luminosity stage
 // (code/synthetic_datasets/funcs.py:105-123 / magnetar/funcs.py:64-84 in simplified algebra):
 //   Rm = min(rmu, k c/omega);  fastness = (Rm/Rc)^1.5 = omega Rm^1.5/sqrt(GM);  tanh(n (fastness-1)).
@@ -232,6 +247,20 @@ MP_DEV double hermite_d(double th, double h, double y0, double d0, double y1, do
     const double D = y1 - y0;
     return (h * d0 + th * (2.0 * (3.0 * D - h * (2.0 * d0 + d1)) + th * 3.0 * (h * (d0 + d1) - 2.0 * D))) / h;
 }
+// quintic Hermite (values, first and second derivatives at both ends) with the basis values b[6] of its theta: Mdisc, whose
+// derivatives are analytic (dM/dt = Mdotfb - M/tvisc), passes through a transition a few tvisc after the start where the
+// cubic is 1e-9 off at a stride of four grid intervals
+MP_DEV double hermite5(const double (&b)[6], double h, double y0, double d0, double e0, double y1, double d1, double e1) {
+    const double h2 = h * h;
+    return fma(b[0], y0, fma(b[3], y1, h * fma(b[1], d0, b[4] * d1) + h2 * fma(b[2], e0, b[5] * e1)));
+}
+// Mdisc inside a step: the quintic while the step resolves the viscous time (z = h/tvisc < 1); beyond, Mdisc follows the
+// fallback rate quasi-steadily, a power law the cubic represents to 2e-10, and its derivatives, formed as differences of
+// nearly equal terms, carry the rounding of Mdisc amplified by z (z^2 for the second): the cubic then
+MP_DEV double hermite_mdisc(const StrideK &K, int i, double h, double z, double y0, double d0, double e0, double y1, double d1,
+                            double e1) {
+    return z < 1.0 ? hermite5(K.hq[i], h, y0, d0, e0, y1, d1, e1) : hermite(K.theta[i], h, y0, d0, y1, d1);
+}
 
 // The image of the last kept tile in LDS: node 0 = the tile's start point, node e + 1 = step end e.  It serves the
 // observations (mode A picks the states bracketing each observed time out of it) and, as the record of the most recent
@@ -243,23 +272,25 @@ struct TileImage {
     double F[kN];   // omega_dot
     double M[kN];   // Mdisc
     double D[kN];   // dMdisc/dt
+    double D2[kN];  // d2Mdisc/dt2
 };
 
 // (Mdisc, omega) at position p8 (in eighths of a grid interval) inside the kept part of the image of a tile of kind
 // `kind` that started at pos8 / time t_s with steps of d8 eighths: the node itself when p8 is one, else the Hermite
 // interpolant over its step (strides 2 and 4 only; the remainder is then a whole number of grid intervals).
 template <int SPL>
-MP_DEV void image_state(const DevShared &sh, const TileImage<SPL> &im, int kind, int pos8, int d8, double t_s, int p8,
-                        double &Mv, double &Wv) {
+MP_DEV void image_state(const DevShared &sh, const TileImage<SPL> &im, int kind, int pos8, int d8, double t_s, double inv_tau,
+                        int p8, double &Mv, double &Wv) {
     const int rel = p8 - pos8, J = rel / d8, rem = rel - J * d8;
     Mv = im.M[J];
     Wv = im.W[J];
     if (rem != 0) {
         const StrideK &K = sh.sk[kind];
         const Vd<1> e{{(double)(J + 1) * K.lnQ}};
-        const double h = t_s * exp_fast(e)[0] * K.one_m_invQ, th = K.theta[(rem >> 3) & 3];
-        Mv = hermite(th, h, im.M[J], im.D[J], im.M[J + 1], im.D[J + 1]);
-        Wv = hermite(th, h, im.W[J], im.F[J], im.W[J + 1], im.F[J + 1]);
+        const int i = (rem >> 3) & 3;
+        const double h = t_s * exp_fast(e)[0] * K.one_m_invQ;
+        Mv = hermite_mdisc(K, i, h, h * inv_tau, im.M[J], im.D[J], im.D2[J], im.M[J + 1], im.D[J + 1], im.D2[J + 1]);
+        Wv = hermite(K.theta[i], h, im.W[J], im.F[J], im.W[J + 1], im.F[J + 1]);
     }
 }
 
@@ -267,7 +298,7 @@ MP_DEV void image_state(const DevShared &sh, const TileImage<SPL> &im, int kind,
 // Evaluate ONE walker on the calling wavefront (all 64 lanes enter with identical arguments).
 // SPL = consecutive steps owned by one lane; a tile is 64*SPL steps.  par[] holds the sampler coordinates
 // (prior checked and log-masked coordinates un-logged here unless a.physical); walker indexes ds_id and the
-// optional curve outputs; im / Lbuf are the wave's LDS areas (Lbuf: [2*(64*SPL + 1)], staging of the curve outputs).
+// optional curve outputs; im / Lbuf are the wave's LDS areas (Lbuf: [2*(4*64*SPL + 1)], staging of the curve outputs).
 template <bool CURVES, int SPL, bool LONG>
 MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, double (&par)[MP_MAX_NDIM],
                         TileImage<SPL> &im, double *Lbuf, double &lnp_out, int &status_out, int &sweeps_out,
@@ -347,7 +378,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
         // ---- tile control (wave-uniform).  Positions in eighths of a grid interval: the first pre_fine intervals are
         // covered with 1/8-interval sub-steps (kind 0), the rest with steps of 1, 2 or 4 intervals (kinds 1, 2, 3).
         const int end8 = 8 * nsteps, pre_end8 = 8 * sh.pre_fine;
-        const int max_kind = CURVES ? 1 : sh.max_kind;         // curve outputs: every grid point is a step end
+        const int max_kind = sh.max_kind;
         int pos8 = 0, kind = 1;
         bool rec_valid = false;                  // the image holds a kept tile (the history of the next one)
         int rec_kind = 0, rec_d8 = 1, rec_J = 0; // its kind, its step in eighths and the number of steps kept
@@ -364,7 +395,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
             ++tiles_total;
 
             // ---------------- step end times (the grid is geometric: t_k = t_s Q^k) and step lengths
-            Vd<kSPL> h, S1;
+            Vd<kSPL> h, S1, dS1;
             {
                 Vd<kSPL> ek, tb;
 #pragma unroll
@@ -375,16 +406,18 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                     tb[s] = t_s * E[s];
                     h[s] = (lane * kSPL + s < nc) ? tb[s] * K.one_m_invQ : 0.0;   // 0 for the padding steps of a short tile
                 }
-                S1 = mdot_fb(w, tb);
+                S1 = mdot_fb_d(w, tb, dS1);
             }
 
             // ---------------- history at this tile's spacing: the source of Mdisc is analytic; (omega_dot, omega) at the
             // three (predictor: four) previous points come from the record of the last kept tile
-            double cS0, cS1, cS2;
+            double cS0, cS1, cS2, cS3, cdS0;
             {
-                const Vd<3> tg{{t_s, t_s * K.inv_Q, t_s * K.inv_Q * K.inv_Q}};
-                const Vd<3> Sg = mdot_fb(w, tg);
-                cS0 = Sg[0]; cS1 = Sg[1]; cS2 = Sg[2];
+                const double q2 = K.inv_Q * K.inv_Q;
+                const Vd<4> tg{{t_s, t_s * K.inv_Q, t_s * q2, t_s * q2 * K.inv_Q}};
+                Vd<4> dSg;
+                const Vd<4> Sg = mdot_fb_d(w, tg, dSg);
+                cS0 = Sg[0]; cS1 = Sg[1]; cS2 = Sg[2]; cS3 = Sg[3]; cdS0 = dSg[0];
             }
             double cf1 = cf0, cf2 = cf0, cf3 = cf0, cw1 = om_s, cw2 = om_s, cw3 = om_s, cw4 = om_s;
             bool have4 = false, interp_hist = false;
@@ -418,25 +451,26 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 cw4 = have4 ? lane_bcast(wv, 3) : cw3;
             }
 
-            // ---------------- Mdisc: exponential Adams-Moulton step (explicit: the source is known) + affine scan.
-            // ES[k]: source at the three points before this lane's first step (k = 0,1,2) and at its step ends (k = 3+s).
+            // ---------------- Mdisc: exponential Adams-Moulton step of order 5 (explicit: the source is known) + affine scan.
+            // ES[k]: source at the four points before this lane's first step (k = 0..3) and at its step ends (k = 4+s).
             Vd<kSPL> M1;
             DiscPt<kSPL> d1;
             {
-                double ES[kSPL + 3];
+                double ES[kSPL + 4];
 #pragma unroll
-                for (int s = 0; s < kSPL; ++s) ES[3 + s] = S1[s];
-                ES[2] = lane_prev(ES[kSPL + 2], cS0);
-                ES[1] = lane_prev(ES[kSPL + 1], cS1);
-                ES[0] = lane_prev(ES[kSPL + 0], cS2);
-                Vd<kSPL> zm, v0, v1, v2, v3;
+                for (int s = 0; s < kSPL; ++s) ES[4 + s] = S1[s];
+                ES[3] = lane_prev(ES[kSPL + 3], cS0);
+                ES[2] = lane_prev(ES[kSPL + 2], cS1);
+                ES[1] = lane_prev(ES[kSPL + 1], cS2);
+                ES[0] = lane_prev(ES[kSPL + 0], cS3);
+                Vd<kSPL> zm, v0, v1, v2, v3, v4;
 #pragma unroll
                 for (int s = 0; s < kSPL; ++s) {
                     zm[s] = -h[s] * w.inv_tau;
-                    v0[s] = ES[3 + s]; v1[s] = ES[2 + s]; v2[s] = ES[1 + s]; v3[s] = ES[s];
+                    v0[s] = ES[4 + s]; v1[s] = ES[3 + s]; v2[s] = ES[2 + s]; v3[s] = ES[1 + s]; v4[s] = ES[s];
                 }
-                const Phi<kSPL> pm = phi1234(zm);
-                const Vd<kSPL> inc = eam4_increment(wbase, pm, h, v0, v1, v2, v3);
+                const Phi5<kSPL> pm = phi12345(zm);
+                const Vd<kSPL> inc = eam5_increment_nodes(eam5_node_weights(wbase, pm), h, v0, v1, v2, v3, v4);
                 Vd<kSPL> am, bm;
                 double A = 1.0, B = 0.0;                  // composition of this lane's step maps
 #pragma unroll
@@ -673,9 +707,13 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
 #pragma unroll
             for (int s = 0; s < kSPL; ++s) {
                 const int e = lane * kSPL + s + 1;
-                im.W[e] = wg[s]; im.F[e] = Ef[4 + s]; im.M[e] = M1[s]; im.D[e] = fma(-M1[s], w.inv_tau, S1[s]);
+                const double dM = fma(-M1[s], w.inv_tau, S1[s]);               // dM/dt = Mdotfb - M/tvisc, and its derivative
+                im.W[e] = wg[s]; im.F[e] = Ef[4 + s]; im.M[e] = M1[s]; im.D[e] = dM; im.D2[e] = fma(-dM, w.inv_tau, dS1[s]);
             }
-            if (lane == 0) { im.W[0] = om_s; im.F[0] = cf0; im.M[0] = M_s; im.D[0] = fma(-M_s, w.inv_tau, cS0); }
+            if (lane == 0) {
+                const double dM = fma(-M_s, w.inv_tau, cS0);
+                im.W[0] = om_s; im.F[0] = cf0; im.M[0] = M_s; im.D[0] = dM; im.D2[0] = fma(-dM, w.inv_tau, cdS0);
+            }
             __syncthreads();
 
             // ---------------- observations
@@ -688,8 +726,8 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 if (deferred) {
                     const int p8 = 8 * ob_g;
                     if (ob_g >= 0 && p8 >= pos8 && p8 < end_kept8) {
-                        image_state(sh, im, kind, pos8, d8, t_s, p8, obM[0], obW[0]);
-                        image_state(sh, im, kind, pos8, d8, t_s, p8 + 8, obM[1], obW[1]);
+                        image_state(sh, im, kind, pos8, d8, t_s, w.inv_tau, p8, obM[0], obW[0]);
+                        image_state(sh, im, kind, pos8, d8, t_s, w.inv_tau, p8 + 8, obM[1], obW[1]);
                     }
                     if (long_lc) {
                         // observations 64.. whose interval starts inside the kept range (64-interval buckets of the dataset)
@@ -700,59 +738,84 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                             const int g = sh.obs_g[dsd.obs_off + j];
                             if (g < g_lo || g >= g_hi) continue;
                             double Ma, Wa, Mb, Wb;
-                            image_state(sh, im, kind, pos8, d8, t_s, 8 * g, Ma, Wa);
-                            image_state(sh, im, kind, pos8, d8, t_s, 8 * g + 8, Mb, Wb);
+                            image_state(sh, im, kind, pos8, d8, t_s, w.inv_tau, 8 * g, Ma, Wa);
+                            image_state(sh, im, kind, pos8, d8, t_s, w.inv_tau, 8 * g + 8, Mb, Wb);
                             double *p = sc + (j - 64);
                             p[0] = Ma; p[sc_stride] = Mb;
                             p[2 * sc_stride] = Wa; p[3 * sc_stride] = Wb;
                         }
                     }
                 }
-            } else {   // curve outputs requested: every grid point is a step end (kinds 0 and 1 only)
-                Vd<kSPL> Lt, Lp, Ld;
-                luminosity(sh, w, d1, wg, Lt, Lp, Ld);
-                // The tile of the light curve is staged in LDS ([e + 1] = step end e, [0] = the tile's start point) for
-                // the interpolation and leaves for HBM from there with lane-contiguous addresses: every store
-                // instruction of the wavefront writes 512 consecutive bytes of the walker's row.  In the sub-stepped
-                // tiles every 8th step end is a grid point.
-                const int sub = pre ? 8 : 1;                                    // step ends per grid interval
+            } else {
+                // Curve outputs requested: the luminosity at every grid point of the kept steps.  A step over ns grid
+                // intervals holds ns of them: the states at the skipped ones come from the step's Hermite interpolant
+                // (the same states mode A would pick for an observation there); in the sub-stepped tiles every 8th step
+                // end is a grid point.  The tile of the light curve is staged in LDS ([m] = the m-th grid point after the
+                // tile's start point, [0] = the start point itself) for the interpolation at the observed times and leaves
+                // for HBM from there with lane-contiguous addresses: every store instruction of the wavefront writes 512
+                // consecutive bytes of the walker's row.
+                const int ns = pre ? 1 : (d8 >> 3);                             // grid points per step (kinds 1, 2, 3)
                 const int g0 = pos8 >> 3;                                       // grid index of the tile's start
-                const int n_here = keep / sub;                                  // grid points this tile adds
+                const int n_here = pre ? keep / 8 : keep * ns;                  // grid points this tile adds
                 const size_t o0 = row + (size_t)g0 + 1;
-                double *S2 = Lbuf + kTile + 1;                                  // second staging area
+                double *S2 = Lbuf + 4 * kTile + 1;                              // second staging area
+                // which: 0 Ltot, 1 Lprop, 2 Ldip, 3 Mdisc, 4 omega -> stage[m], m = 1..n_here
+                auto stage_curve = [&](int which, double *stage) {
+                    for (int i = 1; i <= ns; ++i) {
+                        Vd<kSPL> Mv = M1, Wv = wg;                              // i == ns: the step ends themselves
+                        if (i < ns) {
+                            const double th = K.theta[i];
 #pragma unroll
-                for (int s = 0; s < kSPL; ++s) Lbuf[lane * kSPL + s + 1] = Lt[s];
+                            for (int s = 0; s < kSPL; ++s) {
+                                const int J = lane * kSPL + s;                 // nodes J (step start) and J + 1 of the image
+                                Mv[s] = hermite_mdisc(K, i, h[s], h[s] * w.inv_tau, im.M[J], im.D[J], im.D2[J], im.M[J + 1], im.D[J + 1], im.D2[J + 1]);
+                                Wv[s] = hermite(th, h[s], im.W[J], im.F[J], wg[s], Ef[4 + s]);
+                            }
+                        }
+                        Vd<kSPL> val;
+                        if (which <= 2) {
+                            const DiscPt<kSPL> dv = i < ns ? disc_point(sh, w, Mv) : d1;
+                            Vd<kSPL> Lt, Lp, Ld;
+                            luminosity(sh, w, dv, Wv, Lt, Lp, Ld);
+                            val = which == 0 ? Lt : (which == 1 ? Lp : Ld);
+                        } else {
+                            val = which == 3 ? Mv : Wv;
+                        }
+#pragma unroll
+                        for (int s = 0; s < kSPL; ++s) {
+                            const int e = lane * kSPL + s;                     // step index in the tile
+                            if (pre) { if ((e & 7) == 7) stage[(e >> 3) + 1] = val[s]; }
+                            else stage[e * ns + i] = val[s];
+                        }
+                    }
+                };
+                auto store_curve = [&](double *dst, const double *stage, double div) {
+                    for (int c = 0; c * 64 < n_here; ++c) {
+                        const int m = c * 64 + lane;
+                        if (m < n_here) dst[o0 + m] = stage[m + 1] / div;
+                    }
+                };
+                stage_curve(0, Lbuf);
                 if (lane == 0) Lbuf[0] = L_s;
                 __syncthreads();
-                if (a.ltot) {
-#pragma unroll
-                    for (int c = 0; c < kSPL; ++c) {
-                        const int e = c * 64 + lane;
-                        if (e < n_here) a.ltot[o0 + e] = Lbuf[(e + 1) * sub] / 1.0e50;
-                    }
-                }
+                if (a.ltot) store_curve(a.ltot, Lbuf, 1.0e50);
                 // the other curves (mp_model_lc only) go through the second staging area, one at a time
-                auto put = [&](double *dst, const Vd<kSPL> &v, double div) {
+                auto put = [&](double *dst, int which, double div) {
                     if (!dst) return;                                           // wave-uniform
-#pragma unroll
-                    for (int s = 0; s < kSPL; ++s) S2[lane * kSPL + s] = v[s];
+                    stage_curve(which, S2);
                     __syncthreads();
-#pragma unroll
-                    for (int c = 0; c < kSPL; ++c) {
-                        const int e = c * 64 + lane;
-                        if (e < n_here) dst[o0 + e] = S2[(e + 1) * sub - 1] / div;
-                    }
+                    store_curve(dst, S2, div);
                     __syncthreads();
                 };
-                put(a.lprop, Lp, 1.0e50);
-                put(a.ldip, Ld, 1.0e50);
-                put(a.mdisc, M1, 1.0);
-                put(a.omega, wg, 1.0);
+                put(a.lprop, 1, 1.0e50);
+                put(a.ldip, 2, 1.0e50);
+                put(a.mdisc, 3, 1.0);
+                put(a.omega, 4, 1.0);
                 if (a.want_chi2) {
                     const int g_hi = end_kept8 >> 3;
                     if (ob_g >= g0 && ob_g < g_hi) {
-                        const int e = (ob_g - g0) * sub;
-                        const double La = Lbuf[e], Lb = Lbuf[e + sub];
+                        const int m = ob_g - g0;
+                        const double La = Lbuf[m], Lb = Lbuf[m + 1];
                         const double mod = fma((Lb - La) * ob_idt, ob_dx, La) / 1.0e50;   // np.interp, then /1e50
                         const double res = (ob_y - mod) / ob_ye;
                         chi = fma(res, res, chi);
@@ -764,15 +827,15 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                             const int jj = dsd.obs_off + j;
                             const int g = sh.obs_g[jj];
                             if (g < g0 || g >= g_hi) continue;
-                            const int e = (g - g0) * sub;
-                            const double La = Lbuf[e], Lb = Lbuf[e + sub];
+                            const int m = g - g0;
+                            const double La = Lbuf[m], Lb = Lbuf[m + 1];
                             const double mod = fma((Lb - La) * sh.obs_idt[jj], sh.obs_dx[jj], La) / 1.0e50;
                             const double res = (sh.obs_y[jj] - mod) / sh.obs_yerr[jj];
                             chi = fma(res, res, chi);
                         }
                     }
                 }
-                L_s = Lbuf[keep];
+                L_s = Lbuf[n_here];
                 __syncthreads();                                                // the next tile overwrites the staging area
             }
 

@@ -43,7 +43,7 @@ namespace mp {
 template <bool CURVES, int SPL, bool LONG>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, SPL >= 4 ? 1 : 2))) void lnprob_kernel(const DevShared sh, const LaunchArgs a) {
     __shared__ TileImage<SPL> im;
-    __shared__ double Lbuf[CURVES ? 2 * (64 * SPL + 1) : 1];
+    __shared__ double Lbuf[CURVES ? 2 * (4 * 64 * SPL + 1) : 1];   // up to 4 grid points per step
     ktab_init();
     wtab_init(sh.wtab);
     const int walker = blockIdx.x;

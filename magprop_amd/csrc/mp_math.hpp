@@ -334,121 +334,10 @@ MP_DEV Vd<N> pow_m1_7_fast(const Vd<N> &x) {
     return y;
 }
 
-// ---------------------------------------------------------------- phi functions
-// phi_j(z) = sum_k z^k/(k+j)!  : phi_1 = (e^z-1)/z, phi_{j+1} = (phi_j - 1/j!)/z
-template <int N>
-struct Phi {
-    Vd<N> e, p1, p2, p3, p4;
-};
-
-template <int N>
-MP_DEV Phi<N> phi1234(const Vd<N> &z) {
-    // Taylor series of phi_4: 7 terms when every |z| of the wavefront is below 1/32 (< 2e-17 relative), 13 terms
-    // for |z| < 1/2, closed forms elsewhere
-    Vd<N> s;
-    const double zmax = lane_maxabs(z.v);          // the lane's largest |z|: one comparison per range instead of one per step
-    const bool all_tiny = zmax < 0.03125;
-    double inv6 = 1.0 / 6.0;
-    if constexpr (kUseKtab<N>) {
-        if (__all(all_tiny)) {
-            // all four table reads first (they return in order, so each use waits only for its own pair)
-            const d2v c6 = ktab2(6), c8 = ktab2(8), c10 = ktab2(10), c12 = ktab2(12);
-            FORN s[i] = fma3(z[i], c6.x, c6.y);       // z/10! + 1/9!
-            FORN s[i] = fma3(s[i], z[i], c8.x);       // 1/8!
-            FORN s[i] = fma3(s[i], z[i], c8.y);       // 1/7!
-            FORN s[i] = fma3(s[i], z[i], c10.x);      // 1/6!
-            FORN s[i] = fma3(s[i], z[i], c10.y);      // 1/5!
-            FORN s[i] = fma3(s[i], z[i], c12.x);      // 1/4!
-            inv6 = c12.y;
-        } else {
-            {
-                const d2v c = ktab2(0);
-                FORN s[i] = fma3(z[i], c.x, c.y);     // z/16! + 1/15!
-            }
-            horner2(s, z, 2);
-            horner2(s, z, 4);
-            horner2(s, z, 6);
-            horner2(s, z, 8);
-            horner2(s, z, 10);
-            const d2v c = ktab2(12);
-            FORN s[i] = fma3(s[i], z[i], c.x);        // 1/4!
-            inv6 = c.y;
-        }
-    } else if (__all(all_tiny)) {
-        FORN s[i] = 1.0 / 3628800.0;              // 1/10!
-        horner(s, z, 1.0 / 362880.0);             // 1/9!
-        horner(s, z, 1.0 / 40320.0);              // 1/8!
-        horner(s, z, 1.0 / 5040.0);               // 1/7!
-        horner(s, z, 1.0 / 720.0);                // 1/6!
-        horner(s, z, 1.0 / 120.0);                // 1/5!
-        horner(s, z, 1.0 / 24.0);                 // 1/4!
-    } else {
-        FORN s[i] = 1.0 / 20922789888000.0;       // 1/16!
-        horner(s, z, 1.0 / 1307674368000.0);      // 1/15!
-        horner(s, z, 1.0 / 87178291200.0);        // 1/14!
-        horner(s, z, 1.0 / 6227020800.0);         // 1/13!
-        horner(s, z, 1.0 / 479001600.0);          // 1/12!
-        horner(s, z, 1.0 / 39916800.0);           // 1/11!
-        horner(s, z, 1.0 / 3628800.0);            // 1/10!
-        horner(s, z, 1.0 / 362880.0);             // 1/9!
-        horner(s, z, 1.0 / 40320.0);              // 1/8!
-        horner(s, z, 1.0 / 5040.0);               // 1/7!
-        horner(s, z, 1.0 / 720.0);                // 1/6!
-        horner(s, z, 1.0 / 120.0);                // 1/5!
-        horner(s, z, 1.0 / 24.0);                 // 1/4!
-    }
-    Phi<N> r;
-    r.p4 = s;
-    FORN r.p3[i] = fma(z[i], s[i], inv6);
-    FORN r.p2[i] = fma(z[i], r.p3[i], 0.5);
-    FORN r.p1[i] = fma(z[i], r.p2[i], 1.0);
-    FORN r.e[i] = fma(z[i], r.p1[i], 1.0);
-    const bool any_big = !(zmax < 0.5);           // (a NaN among the z is not seen by fmax: it stays a NaN in the series below)
-    if (__any(any_big)) {                          // wave-uniform: only stiff / late-time tiles pay for this
-        Vb<N> big;
-        FORN big[i] = !(fabs(z[i]) < 0.5);
-        Vd<N> zc, zs;
-        FORN zc[i] = fmax(z[i], -750.0);
-        FORN zs[i] = big[i] ? z[i] : 1.0;
-        const Vd<N> ce = exp_fast(zc);
-        const Vd<N> rz = rcp_fast(zs);
-        FORN {
-            const double c1 = (ce[i] - 1.0) * rz[i];
-            const double c2 = (c1 - 1.0) * rz[i];
-            const double c3 = (c2 - 0.5) * rz[i];
-            const double c4 = (c3 - inv6) * rz[i];
-            r.e[i] = big[i] ? ce[i] : r.e[i];
-            r.p1[i] = big[i] ? c1 : r.p1[i];
-            r.p2[i] = big[i] ? c2 : r.p2[i];
-            r.p3[i] = big[i] ? c3 : r.p3[i];
-            r.p4[i] = big[i] ? c4 : r.p4[i];
-        }
-    }
-    return r;
-}
-
-// h * int_0^1 e^{z(1-theta)} P(theta) dtheta for the cubic P through the node values v0..v3 at
-// t_{j+1}, t_j, t_{j-1}, t_{j-2} (quadrature matrix W4 of the tile's kind, LDS table at wbase)
-template <int N>
-MP_DEV Vd<N> eam4_increment(int wbase, const Phi<N> &p, const Vd<N> &h, const Vd<N> &v0, const Vd<N> &v1,
-                            const Vd<N> &v2, const Vd<N> &v3) {
-    Vd<N> acc, g;
-    FORN acc[i] = 0.0;
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        const Vd<N> &ph = m == 0 ? p.p1 : m == 1 ? p.p2 : m == 2 ? p.p3 : p.p4;
-        const d2v a = wtab2(wbase + kWtabW4 + 4 * m), b = wtab2(wbase + kWtabW4 + 4 * m + 2);   // W4[0..3][m]
-        FORN g[i] = b.y * v3[i];
-        FORN g[i] = fma(b.x, v2[i], g[i]);
-        FORN g[i] = fma(a.y, v1[i], g[i]);
-        FORN g[i] = fma(a.x, v0[i], g[i]);
-        FORN acc[i] = fma(ph[i], g[i], acc[i]);
-    }
-    FORN acc[i] = h[i] * acc[i];
-    return acc;
-}
-
-// ---------------------------------------------------------------- order 5 (the omega equation)
+// ---------------------------------------------------------------- phi functions, order-5 quadrature
+// phi_j(z) = sum_k z^k/(k+j)!  : phi_1 = (e^z-1)/z, phi_{j+1} = (phi_j - 1/j!)/z.  Both equations are advanced with the
+// order-5 exponential Adams-Moulton formula: h * int_0^1 e^{z(1-theta)} P(theta) dtheta for the quartic P through the node
+// values at t_{j+1}, t_j, ..., t_{j-3} (quadrature matrix W5 of the tile's kind, LDS table).
 // phi_1..phi_5 of z = h*lambda.  Taylor series of phi_5: 7 terms when every |z| of the wavefront is below 1/32 (< 1e-17
 // relative), 13 terms for |z| < 1/2, closed forms elsewhere.
 template <int N>

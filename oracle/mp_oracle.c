@@ -346,6 +346,17 @@ static double hermite_d(double th, double h, double y0, double d0, double y1, do
     return (h * d0 + th * (2.0 * (3.0 * D - h * (2.0 * d0 + d1)) + th * 3.0 * (h * (d0 + d1) - 2.0 * D))) / h;
 }
 
+/* quintic Hermite: values, first and second derivatives at both ends (Mdisc: its derivatives are analytic) */
+static double hermite5(double th, double h, double y0, double d0, double e0, double y1, double d1, double e1) {
+    const double t2 = th * th, t3 = t2 * th, t4 = t3 * th, t5 = t4 * th;
+    return (1.0 - 10.0 * t3 + 15.0 * t4 - 6.0 * t5) * y0 + (10.0 * t3 - 15.0 * t4 + 6.0 * t5) * y1 +
+           h * ((th - 6.0 * t3 + 8.0 * t4 - 3.0 * t5) * d0 + (-4.0 * t3 + 7.0 * t4 - 3.0 * t5) * d1) +
+           h * h * ((0.5 * t2 - 1.5 * t3 + 1.5 * t4 - 0.5 * t5) * e0 + (0.5 * t3 - t4 + 0.5 * t5) * e1);
+}
+static double mdot_fb_dt(const wk *w, double t) {   /* d/dt of the fallback rate */
+    return (-5.0 / 3.0) * mdot_fb(w, t) / (t + w->tfb);
+}
+
 /* which smooth branch of the right-hand side a state is on: bit 0 = Alfven radius capped at k*Rlc
  * (code/synthetic_datasets/funcs.py:109-110), bit 1 = Rm >= R (the torque-arm branch, :133-138) */
 static int branch_flags(const mpo_cfg *c, const wk *w, double Mdisc, double omega) {
@@ -356,9 +367,9 @@ static int branch_flags(const mpo_cfg *c, const wk *w, double Mdisc, double omeg
 }
 
 /*
- * PRODUCTION SCHEME (what the HIP kernels implement): exponential Adams-Moulton of order 5 for omega
- * (order 4 for the linear Mdisc equation, whose source is analytic) on geometric grids:
- *   Mdisc_{j+1} = e^{-z} Mdisc_j + h sum_m phi_{m+1}(-z) sum_k W4[k][m] Mdotfb(t_{j+1-k}),          z = h/tvisc
+ * PRODUCTION SCHEME (what the HIP kernels implement): exponential Adams-Moulton of order 5 for both
+ * equations (the source of the linear Mdisc equation is analytic) on geometric grids:
+ *   Mdisc_{j+1} = e^{-z} Mdisc_j + h sum_m phi_{m+1}(-z) sum_k W5[k][m] Mdotfb(t_{j+1-k}),          z = h/tvisc
  *   omega_{j+1} = e^{h lam} omega_j + h sum_m phi_{m+1}(h lam) sum_k W5[k][m] (f_{j+1-k} - lam omega_{j+1-k})
  * with f_p = omega_dot(Mdisc_p, omega_p) and lam = d(omega_dot)/d(omega) frozen at the NEW point (implicit in omega_{j+1},
  * solved by fixed-point iteration).  The integration proceeds in TILES of 64*spl steps (one wavefront, spl steps per lane
@@ -370,13 +381,13 @@ static int branch_flags(const mpo_cfg *c, const wk *w, double Mdisc, double omeg
  *     to the first lane in which (a) the solution changes the smooth branch of the right-hand side (Alfven-radius cap, torque
  *     arm: a kink no multistep formula can cross at a coarse step) or (b) the smoothness indicator h |4th difference of
  *     (f - lam omega)| / omega exceeds stride_tol; what follows is redone at stride 1.  Values at skipped grid points come
- *     from the cubic Hermite interpolant of (omega, f) / (Mdisc, dMdisc/dt) over the step (error ~ (h/t)^4 / 384).
+ *     from Hermite interpolants over the step: cubic in (omega, f), quintic in (Mdisc, dMdisc/dt, d2Mdisc/dt2).
  * History for a tile whose step differs from its predecessor's: the same Hermite interpolant on the predecessor's steps
  * (exact where the points coincide).  Start-up: Mdotfb is analytic (grid continued backwards); the missing (f, omega)
  * points continue points 0 and 1 linearly.  Failure ('flag'): the rotation parameter of an iterate at a step end exceeds
  * 0.27 in a tile at stride <= 1; at a coarser stride the tile is redone finer first.
  */
-typedef struct { double t, M, dM, w, f; } mpo_node;
+typedef struct { double t, M, dM, ddM, w, f; } mpo_node;
 typedef struct {
     int tiles, tiles_pre, tiles_s1, tiles_s2, tiles_s4, tiles_cut;   /* tile solves by kind; tiles not (fully) kept */
     int steps_kept;
@@ -421,7 +432,10 @@ int mpo_trajectory_mode(const mpo_cfg *c, const double *pars, int ndim, const do
     double rot, fcur = omega_dot(c, &w, M, om, &rot, NULL);
     if (!(isfinite(M) && isfinite(om)) || M <= 0.0 || om <= 0.0) status = MPO_NONFINITE;
     else if (rot > 0.27) status = MPO_FLAG;
-    nd[nn++] = (mpo_node){tgrid[0], M, mdot_fb(&w, tgrid[0]) - M / w.tvisc, om, fcur};
+    {
+        const double dM0 = mdot_fb(&w, tgrid[0]) - M / w.tvisc;
+        nd[nn++] = (mpo_node){tgrid[0], M, dM0, mdot_fb_dt(&w, tgrid[0]) - dM0 / w.tvisc, om, fcur};
+    }
     if (Mout) Mout[0] = M;
     if (Wout) Wout[0] = om;
     const int pre_fine = nsteps < MPO_PRE_FINE ? nsteps : MPO_PRE_FINE;
@@ -443,11 +457,10 @@ int mpo_trajectory_mode(const mpo_cfg *c, const double *pars, int ndim, const do
             nc = ((nsteps - i0) / s < TILE) ? (nsteps - i0) / s : TILE;
             Q = pow(q, (double)s);
         }
-        double W5[25], W4[4][4];
+        double W5[25];
         mpo_eam_weights(Q, P, W5);
-        mpo_eam4_weights(Q, W4);
         const double t0 = nd[nn - 1].t;
-        double Sh[3] = {mdot_fb(&w, t0), mdot_fb(&w, t0 / Q), mdot_fb(&w, t0 / (Q * Q))};
+        double Sh[4] = {mdot_fb(&w, t0), mdot_fb(&w, t0 / Q), mdot_fb(&w, t0 / (Q * Q)), mdot_fb(&w, t0 / (Q * Q * Q))};
         double fh[P], wh[P];
         fh[0] = fcur; wh[0] = om;
         int startup = (nn == 1);
@@ -465,8 +478,10 @@ int mpo_trajectory_mode(const mpo_cfg *c, const double *pars, int ndim, const do
             /* ---- Mdisc */
             const double S1 = mdot_fb(&w, tJ1);
             double ez, ph[8], acc = 0.0;
-            phi_upto(-h / w.tvisc, &ez, ph, 4);
-            for (int m = 0; m < 4; ++m) acc += ph[m] * (W4[0][m] * S1 + W4[1][m] * Sh[0] + W4[2][m] * Sh[1] + W4[3][m] * Sh[2]);
+            phi_upto(-h / w.tvisc, &ez, ph, P);
+            for (int m = 0; m < P; ++m)
+                acc += ph[m] * (W5[0 * P + m] * S1 + W5[1 * P + m] * Sh[0] + W5[2 * P + m] * Sh[1] + W5[3 * P + m] * Sh[2] +
+                                W5[4 * P + m] * Sh[3]);
             const double M1 = ez * Mt + h * acc;
             /* ---- omega: fixed-point iteration on the implicit step */
             double wn = ot + h * fh[0], fnew = 0.0, lam = 0.0, Nv[P];
@@ -498,9 +513,9 @@ int mpo_trajectory_mode(const mpo_cfg *c, const double *pars, int ndim, const do
             if ((0.5 * w.I * wn * wn) / w.modW > 0.27) { tstatus = MPO_FLAG; break; }
             brk[J] = branch_flags(c, &w, M1, wn) != flags0;
             ind[J] = (startup && J < P - 2) ? 0.0 : h * fabs(Nv[0] - 4.0 * Nv[1] + 6.0 * Nv[2] - 4.0 * Nv[3] + Nv[4]) / fabs(wn);
-            tn[J] = (mpo_node){tJ1, M1, S1 - M1 / w.tvisc, wn, fnew};
+            tn[J] = (mpo_node){tJ1, M1, S1 - M1 / w.tvisc, mdot_fb_dt(&w, tJ1) - (S1 - M1 / w.tvisc) / w.tvisc, wn, fnew};
             if (startup && J == 0) { f1 = fnew; w1 = wn; }
-            Sh[2] = Sh[1]; Sh[1] = Sh[0]; Sh[0] = S1;
+            Sh[3] = Sh[2]; Sh[2] = Sh[1]; Sh[1] = Sh[0]; Sh[0] = S1;
             for (int k = P - 2; k >= 1; --k) { fh[k] = fh[k - 1]; wh[k] = wh[k - 1]; }
             fh[0] = fnew; wh[0] = wn;
             Mt = M1; ot = wn;
@@ -555,7 +570,10 @@ int mpo_trajectory_mode(const mpo_cfg *c, const double *pars, int ndim, const do
                 const double h = tn[J].t - prev.t;
                 for (int i = 1; i < s; ++i) {
                     const double th = (tgrid[ib + i] - prev.t) / h;
-                    if (Mout) Mout[ib + i] = hermite(th, h, prev.M, prev.dM, tn[J].M, tn[J].dM);
+                    /* quintic while the step resolves the viscous time; beyond, the derivatives of the quasi-steady Mdisc are
+                       differences of nearly equal terms (rounding amplified by h/tvisc): the cubic, good to 2e-10 on a power law */
+                    if (Mout) Mout[ib + i] = (h / w.tvisc < 1.0) ? hermite5(th, h, prev.M, prev.dM, prev.ddM, tn[J].M, tn[J].dM, tn[J].ddM)
+                                                                 : hermite(th, h, prev.M, prev.dM, tn[J].M, tn[J].dM);
                     if (Wout) Wout[ib + i] = hermite(th, h, prev.w, prev.f, tn[J].w, tn[J].f);
                 }
                 if (Mout) Mout[ib + s] = tn[J].M;

@@ -27,7 +27,9 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_cfg_struct_layout_and_presets():
-    assert ctypes.sizeof(_capi.ModelCfg) == 11 * 8 + 2 * 4 + 8 and _capi.cfg_synth().sweep_tol == 0.0   # 0 = MP_SWEEP_TOL_DEFAULT
+    assert ctypes.sizeof(_capi.ModelCfg) == 11 * 8 + 2 * 4 + 2 * 8
+    c0 = _capi.cfg_synth()
+    assert c0.sweep_tol == 0.0 and c0.stride_tol == 0.0 and c0.max_stride == 0   # 0 = the library defaults (MP_*_DEFAULT)
     s, l = _capi.cfg_synth(), _capi.cfg_lib()
     assert (s.inertia_factor, s.rm_massflow_factor, s.n_ode, s.n_lum, s.nacc_lum_threshold, s.lprop_gm_term) == \
         (0.35, 3.0, 10.0, 10.0, 0.27, 1)

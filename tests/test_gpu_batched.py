@@ -87,11 +87,12 @@ def test_mode_b_batched_light_curves(gsynth, gflag, tarr, n):
             if same_variant:
                 assert np.array_equal(lt[i], out_i[1]), i
             else:
-                # the other kernel variant (tiles of 128 instead of 256 steps) at the product's default sweep tolerance:
-                # the light curve of a prior-wide walker agrees to ~3e-7 where the propeller switches on or off (3e-8 at
-                # the strict tolerance; the reference's own LSODA noise on these curves is 1e-6 ... 5e-6)
+                # the other kernel variant (tiles of 128 instead of 256 steps: the adaptive tiles fall differently) at the
+                # product's defaults: the light curve of a prior-wide walker agrees to ~1.4e-6 where the propeller switches
+                # on or off (a 5e-8 difference in omega, amplified by the n = 10 switch; the reference's own LSODA noise on
+                # these curves is 1e-6 ... 5e-6)
                 worst = max(worst, float(np.max(np.abs(lt[i] - out_i[1]) / (np.abs(out_i[1]) + 1e-3 * out_i[1].max()))))
-    assert worst <= 1e-6, worst
+    assert worst <= 3e-6, worst
     # the canonical rows against the reference's model_lum (golden_synth.npz, decimated; LSODA noise ~1e-6)
     d = int(gsynth["decim"])
     for k, t in enumerate(TYPES):
@@ -169,7 +170,7 @@ def test_config5_four_types_mixed_lengths_one_launch(gsynth, glonglc, tarr, co):
     sets = _config5_sets(gsynth, glonglc, tarr)
     assert sorted(len(s[0]) for s in sets) == [8, 50, 50, 50, 50, 63, 64, 65, 112, 410, 1944]
     lp_ = LogProb(*sets[0])                                    # product default: against the reference's values
-    lps = LogProb(*sets[0], sweep_tol=1.0e-9)                  # strict: against the serial restatement of the scheme
+    lps = LogProb(*sets[0], sweep_tol=1.0e-9, max_stride=1)    # strict, every grid interval a step: against the serial restatement
     for s in sets[1:]:
         lp_.add_dataset(*s)
         lps.add_dataset(*s)
@@ -207,7 +208,7 @@ def test_config5_four_types_mixed_lengths_one_launch(gsynth, glonglc, tarr, co):
     out_s, st_s = lps.handle.lnprob_batch(P, ds_id=ids, want_status=True)
     assert np.array_equal(st_s, st)
     fin = st == 0
-    assert np.all(np.abs(out[fin] - out_s[fin]) <= 2e-8 * np.abs(out_s[fin]) + 1e-9)       # default vs strict sweep tolerance
+    assert np.all(np.abs(out[fin] - out_s[fin]) <= 1e-7 * np.abs(out_s[fin]) + 1e-9)       # product defaults (adaptive stride) vs strict fixed steps
     for i in sample:
         x, y, yerr = sets[ids[i]]
         ref, rs = co.lnprob_batch(co.cfg_synth(), P[i], tarr, x, y, yerr, gsynth["prior_lower"], gsynth["prior_upper"], LOG_MASK)

@@ -13,14 +13,14 @@ from conftest import (CANON, LC_REF_RTOL, LC_TIGHT_RTOL, REF_ATOL, REF_RTOL, TIG
 pytestmark = pytest.mark.gpu
 
 GPU_VS_C_RTOL = 1e-10   # HIP kernel (strict sweep tolerance) vs serial C oracle: same scheme, different evaluation order / algebra
-DEFAULT_VS_STRICT_RTOL = 2e-8   # lnprob at the default sweep tolerance (1e-7) vs strict (1e-9); observed <= 4.5e-9
-CROSS_VARIANT_RTOL = 1e-8       # kernel variants (tile lengths) against each other at the default tolerance
+DEFAULT_VS_STRICT_RTOL = 1e-7   # lnprob at the product defaults (sweep tolerance 1e-7, steps over 1/2/4 grid intervals) vs strict
+                                # (1e-9, every grid interval a step); observed <= 5e-8 (soak: tests/test_gpu_soak.py)
+CROSS_VARIANT_RTOL = 1e-7       # kernel variants (tile lengths: the adaptive tiles fall differently) against each other
 
 
 def kernel_variant(n):
     """(wavefronts per walker, steps per lane) the library picks for a batch of n (mp_device.h): batches of different
-    variants agree to rounding, batches of the same variant bit for bit.  Up to 512 walkers run the producer/consumer
-    pair of wavefronts, which executes the statements of the (1, 4) kernel and is bit-identical to it."""
+    variants agree to CROSS_VARIANT_RTOL, batches of the same variant bit for bit."""
     return (1, 4) if n <= 1024 else (1, 2)
 LOG_MASK = 0b111100
 
@@ -166,9 +166,11 @@ def test_model_lum_curves(mpa, co, gsynth, tarr, name, tol, request):
     from magprop_amd import _capi, engine
     st, _, traj = engine.engine(_capi.cfg_synth()).handle.model_lc(CANON[name], want_traj=True)
     tt = gsynth[name + "_traj_tight"]
-    assert np.max(np.abs(traj[0, ::d] / tt[0] - 1.0)) < 5e-11
+    # (product defaults: the states at grid points a step skips come from the step's Hermite interpolant, 2.5e-10 in Mdisc)
+    assert np.max(np.abs(traj[0, ::d] / tt[0] - 1.0)) < (5e-11 if tol == "strict" else 5e-10)
     assert np.max(np.abs(traj[1, ::d] / tt[1] - 1.0)) < 2e-9
-    assert np.max(np.abs(traj[0] / traj_c[0] - 1.0)) < 1e-12 and np.max(np.abs(traj[1] / traj_c[1] - 1.0)) < 1e-10 * loose
+    assert np.max(np.abs(traj[0] / traj_c[0] - 1.0)) < (1e-12 if tol == "strict" else 5e-10)
+    assert np.max(np.abs(traj[1] / traj_c[1] - 1.0)) < 1e-10 * loose
 
 
 def test_model_lum_xdata_and_flag(mpa, gsynth):
@@ -488,10 +490,9 @@ def test_library_first_then_torch_in_one_process(gsynth):
     assert r.returncode == 0 and "one-runtime-ok" in r.stdout, r.stderr[-2000:]
 
 
-def test_producer_consumer_pair_is_bit_identical(synth_handle, gsynth):
-    """257..512 walkers run on a producer/consumer pair of wavefronts (lnprob_pc_kernel): the statements of the
-    one-wavefront kernel split over two wavefronts, so the same walkers in a batch of 1 024 give the same bits -
-    values, statuses (prior / flag / non-finite walkers make the consumer stop early and release the producer)."""
+def test_batch_size_does_not_change_a_walker(synth_handle, gsynth):
+    """A walker's result does not depend on what else is in the launch: any sub-batch of a batch that runs the same
+    kernel variant gives the same bits - values and statuses (prior / flag / non-finite walkers among them)."""
     rng = np.random.default_rng(5)
     P = np.array(TRUTHS["Stuttering"]) + 1.0e-3 * rng.standard_normal((1024, 6))
     P[::7] = synth_handle_prior_sample(rng, len(P[::7]))           # prior-wide walkers, some of them flag

@@ -318,3 +318,32 @@ def test_lsoda_port_reference_cost_mode_gives_the_same_numbers(gsynth, tarr):
         b = lp.lnprob(p, tarr, x, y, yerr, reference_cost=True)
         assert a == b
     assert lp._pool_eval.__doc__ and "cost structure" in lp._pool_eval.__doc__
+
+
+@pytest.mark.parametrize("spl", [4, 2])
+def test_adaptive_stride_restatement(gsynth, gflag, gflag2, tarr, cfg, spl):
+    """The product's default mode restated serially (mpo_trajectory_mode, mode 1: tiles of 64*spl steps over 1, 2 or 4 grid
+    intervals, cut at kinks and fast features): same verdicts as the reference on every prior-wide golden point, values
+    inside the same bounds as the fixed-step scheme, and a third of the tiles."""
+    x, y, yerr = gsynth["Humped_x"], gsynth["Humped_y"], gsynth["Humped_yerr"]
+    out, st, tiles = co.lnprob_batch(cfg, gflag["pars"], tarr, x, y, yerr, gsynth["prior_lower"], gsynth["prior_upper"],
+                                     LOG_MASK, mode="adaptive", spl=spl, want_tiles=True)
+    rst = gflag["status"]
+    assert np.array_equal(st, rst)
+    assert_vs_reference(out, gflag["lnprob"], rst == 0, gflag["lnprob_tight"], noise_mask(gflag, len(out)))
+    fixed, _ = co.lnprob_batch(cfg, gflag["pars"], tarr, x, y, yerr, gsynth["prior_lower"], gsynth["prior_upper"], LOG_MASK)
+    ok = rst == 0
+    rel = np.abs(out[ok] - fixed[ok]) / np.maximum(np.abs(fixed[ok]), 1.0)
+    assert rel.max() <= 1e-7 and np.quantile(rel, 0.999) <= 3e-8, (rel.max(), np.quantile(rel, 0.999))
+    per_walker = tiles[ok, 0].mean()
+    fixed_tiles = 1 + -(-(10000 - 32) // (64 * spl)) if spl == 4 else 2 + -(-(10000 - 32) // (64 * spl))
+    assert per_walker < 0.4 * fixed_tiles, (per_walker, fixed_tiles)
+    # the other three datasets, every 5th point
+    for d, name in enumerate(gflag2["ds_names"]):
+        sel = np.nonzero(gflag2["ds"] == d)[0][::5]
+        xs, ys, es = gsynth[str(name) + "_x"], gsynth[str(name) + "_y"], gsynth[str(name) + "_yerr"]
+        o2, s2 = co.lnprob_batch(cfg, gflag2["pars"][sel], tarr, xs, ys, es, gsynth["prior_lower"], gsynth["prior_upper"],
+                                 LOG_MASK, mode="adaptive", spl=spl)
+        assert np.array_equal(s2, gflag2["status"][sel])
+        assert_vs_reference(o2, gflag2["lnprob"][sel], gflag2["status"][sel] == 0, gflag2["lnprob_tight"][sel],
+                            noise_mask(gflag2, len(gflag2["ds"]))[sel])
