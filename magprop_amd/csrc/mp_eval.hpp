@@ -234,9 +234,10 @@ constexpr int kMaxSweepsMargin = 16;  // sweeps allowed beyond the tile length (
 constexpr int kChatterSweeps = 24;
 // A tile at a coarse stride is kept if at least this many lanes precede the first offending one (oracle: MPO_MIN_KEEP).
 constexpr int kMinKeepLanes = 8;
-// Sweeps a tile at a coarse stride may take: one that has not converged by then (a poor extrapolated guess across a fast
-// feature) is cheaper redone over single intervals.
-constexpr int kCoarseMaxSweeps = 6;
+// Sweeps a tile at a coarse stride may take: of one that has not converged by then (a poor extrapolated guess across a fast
+// feature) the converged leading lanes are kept and the rest is redone at the next finer stride.
+constexpr int kCoarseMaxSweeps = 5;
+constexpr int kFineMaxSweeps = 8;     // the same for tiles over single intervals or sub-steps, if enough lanes have converged
 
 // cubic Hermite on a step of length h (theta in [0, 1]): value, and its time derivative
 MP_DEV double hermite(double th, double h, double y0, double d0, double y1, double d1) {
@@ -525,7 +526,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
             // first guess was good.
             Vd<kSPL> lam, ez, n0, n1, n2, n3, n4;
             EamW5<kSPL> cw;
-            bool light = false, ultra = false;
+            bool light = false, ultra = false, early_stop = false;
             while (true) {
                 ++sweep;
                 if (!light) {   // (after a sweep that moved every lane by < 1e-4 the guesses are positive and finite)
@@ -628,7 +629,14 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 ultra = full && __all(all_tiny && !near_limit);
                 pending = __ballot(!all_ok);
                 if (pending == 0ull || flagged != 0ull || sweep >= kMaxSweeps) break;
-                if (kind >= 2 && sweep >= kCoarseMaxSweeps) break;   // not worth it at this stride (the tile is redone finer)
+                if (kind >= 2 && sweep >= kCoarseMaxSweeps) break;   // not worth it at this stride (the rest is redone finer)
+                // Slow sweeps on single intervals (a poor extrapolated guess through a fast spin-up, far from the break-up
+                // limit): the lanes that have converged are final (a step depends on earlier ones only); they are kept
+                // and a new tile starts behind them with a fresh extrapolation, instead of sweeping on over all 64 lanes.
+                if (kind <= 1 && sweep >= kFineMaxSweeps && over_sweeps == 0 && __ffsll(pending) - 1 >= 2 * kMinKeepLanes) {
+                    early_stop = true;
+                    break;
+                }
                 if (over_sweeps >= kChatterSweeps) { flagged |= over_now ? over_now : pending; break; }
             }
             sweeps_total += sweep;
@@ -646,10 +654,14 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 const bool over = sh.crot * wmax * wmax > 0.27;
                 mb = __ballot(bad);
                 // a step whose sweeps never settle is chattering on the Nacc discontinuity: same verdict as a flag
-                mf = flagged | __ballot(over) | (flagged ? 0ull : pending);
+                mf = flagged | __ballot(over) | ((flagged || early_stop) ? 0ull : pending);
+                if (early_stop) { mb &= ~pending; mf &= ~pending; }   // nothing is decided on lanes that are not kept
             }
-            if (mb | mf) {
-                if (kind >= 2) { kind = 1; continue; }   // not a verdict at a coarse stride: redo over single intervals
+            // At a coarse stride nothing of this is a verdict: the lanes before the first one that failed, or whose sweeps
+            // had not converged when they were stopped, hold converged steps (a step depends on earlier ones only) and
+            // are kept like the steps before a kink; the rest is redone finer.
+            const unsigned long long unconv = kind >= 2 ? (mb | mf | pending) : (early_stop ? pending : 0ull);
+            if (kind <= 1 && (mb | mf)) {
                 const int first = __ffsll((unsigned long long)(mb | mf)) - 1;
                 status = ((mf >> first) & 1ull) ? MP_STATUS_FLAG : MP_STATUS_NONFINITE;
                 break;
@@ -675,15 +687,19 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 const unsigned long long B = __ballot(brk), I1 = __ballot(ind1), I64 = __ballot(ind64), I2048 = __ballot(ind2048);
                 const int full_lanes = (nc + kSPL - 1) / kSPL;                 // lanes that hold steps of this tile
                 if (kind >= 2) {
-                    const unsigned long long bad = B | I1;
+                    const unsigned long long bad = B | I1 | unconv;
                     const int first = bad ? __ffsll(bad) - 1 : 64;
                     if (first < full_lanes) {
                         if (first < kMinKeepLanes) { kind = 1; continue; }     // nothing worth keeping: redo at stride 1
                         keep_lanes = first;
-                        next_kind = 1;                                         // the offending region gets single intervals
+                        // a kink or a fast feature gets single intervals; slow sweeps alone, the next finer stride
+                        next_kind = (((B | I1) >> first) & 1ull) ? 1 : kind - 1;
                     } else if (kind == 2 && nc == kTile) {
                         next_kind = I64 == 0ull ? 3 : 2;
                     }
+                } else if (unconv != 0ull) {                                    // kinds 0, 1 stopped early: the converged lanes
+                    keep_lanes = __ffsll(unconv) - 1;
+                    if (pre) keep_lanes &= ~(8 / kSPL - 1);                    // (whole grid intervals of sub-steps)
                 } else if (kind == 1 && nc == kTile) {
                     if (B == 0ull) next_kind = I2048 == 0ull ? 3 : (I64 == 0ull ? 2 : 1);
                     else {

@@ -41,7 +41,7 @@ namespace mp {
 
 // ---------------------------------------------------------------- batched log-posterior kernel
 template <bool CURVES, int SPL, bool LONG>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, SPL >= 4 ? 1 : 2))) void lnprob_kernel(const DevShared sh, const LaunchArgs a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPL >= 4 ? 1 : 2, SPL >= 4 ? 1 : 2))) void lnprob_kernel(const DevShared sh, const LaunchArgs a) {
     __shared__ TileImage<SPL> im;
     __shared__ double Lbuf[CURVES ? 2 * (4 * 64 * SPL + 1) : 1];   // up to 4 grid points per step
     ktab_init();
@@ -106,7 +106,7 @@ MP_DEV double u01(uint32_t hi, uint32_t lo) {   // 53-bit uniform in [0, 1)
 // ranks after the all-gather.  The random numbers are keyed by (seed; step, half, walker), so every rank draws what the
 // single-GPU launch would have drawn for the same walker.
 template <int SPL, bool LONG>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, SPL >= 4 ? 1 : 2))) void stretch_kernel(const DevShared sh, const StretchArgs g) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPL >= 4 ? 1 : 2, SPL >= 4 ? 1 : 2))) void stretch_kernel(const DevShared sh, const StretchArgs g) {
     __shared__ TileImage<SPL> im;
     __shared__ double lds[1];
     ktab_init();
