@@ -150,6 +150,11 @@ def glonglc():
 
 
 @pytest.fixture(scope="session")
+def gswift():
+    return np.load(os.path.join(GOLDEN, "golden_swift.npz"))
+
+
+@pytest.fixture(scope="session")
 def gcorners():
     return np.load(os.path.join(GOLDEN, "golden_corners.npz"))
 

@@ -20,7 +20,7 @@ What is called (paths relative to /root/reference):
 `*_tight` arrays: the same reference code with its odeint call given rtol=atol=1e-12 (integrator noise
 removed; see tight_lsoda).
 Outputs: golden_synth.npz, golden_lib.npz, golden_flagscan.npz, golden_corners.npz, golden_libscan.npz, golden_longlc.npz,
-golden_flagscan2.npz, golden_libscan2.npz, golden_rhs.npz, golden_libkw.npz, MANIFEST.json.
+golden_flagscan2.npz, golden_libscan2.npz, golden_rhs.npz, golden_libkw.npz, golden_swift.npz, MANIFEST.json.
 `--only tight` (make_tight) adds to the scan fixtures the tight-integrator value of EVERY successful point and the
 enumerated LSODA-noise points (`*lsoda_noise_idx`): where the reference's default run is itself off by more than the
 SURVEY.md 8(c) contract 1e-5 + 2e-6 |ref|.
@@ -597,10 +597,76 @@ def make_longlc():
     print("longlc synth1944:", g["synth1944_lnprob"][:3], g["synth1944_lnprob_tight"][:3])
 
 
+def _swift_times(name):
+    """Time stamps (s since trigger) of a real Swift light curve, data/SGRBS/<name>_raw.txt (data only: the first
+    column of the numeric rows; the files mix BAT / XRT blocks with text markers)."""
+    t = []
+    for line in open(os.path.join(REF, "data", "SGRBS", name + "_raw.txt")):
+        parts = line.split()
+        if len(parts) == 6:
+            try:
+                t.append(float(parts[0]))
+            except ValueError:
+                pass
+    return np.sort(np.array(t))
+
+
+def make_swift():
+    """Light curves whose observation TIMES are those of real Swift bursts (densely clustered early, sparse late;
+    SURVEY.md section 2 marks data/SGRBS/*_raw.txt as the realistic shapes): GRB 060614 (1 944 rows) and GRB 051016B
+    (80 rows).  Fluxes are synthetic (the model of a canonical parameter set + noise, generate_data.py:61-67 style), the
+    values are the reference's: synth variant on the times inside its grid [1, 1e6] s, library variant on the short-GRB
+    grid [1e-3, 1e6] s with every time stamp."""
+    import pandas as pd
+    os.chdir(REF)
+    rng = np.random.default_rng(SEED0 + 606)
+    g = {}
+    for name, grb in (("060614", "Humped"), ("051016B", "Classic")):
+        t_all = _swift_times(name)
+        g[f"swift_{name}_n_rows"] = np.array(len(t_all))
+        # ---- synth variant, "L" grid
+        x = t_all[(t_all >= sf.tarr[0]) & (t_all <= sf.tarr[-1])]
+        model = sf.model_lum(np.array(GRB_PARS[grb]))
+        y0 = np.interp(x, model[0], model[1])
+        yerr = 0.25 * y0
+        y = y0 + rng.normal(0.0, yerr)
+        truth = np.array(TRUTHS[grb])
+        P = [truth.copy()] + [truth + 1.0e-4 * rng.standard_normal(6) for _ in range(5)]
+        P += [truth + 0.05 * np.maximum(np.abs(truth), 0.5) * rng.standard_normal(6) for _ in range(3)]
+        P += [LOWER + (UPPER - LOWER) * rng.random(6) for _ in range(3)]
+        P = np.array(P)
+        res = [synth_lnprob(p, x, y, yerr) for p in P]
+        with tight_lsoda():
+            tight = np.array([synth_lnprob(p, x, y, yerr)[0] for p in P])
+        g[f"swift_{name}_ds"] = np.array([x, y, yerr])
+        g[f"swift_{name}_pars"] = P
+        g[f"swift_{name}_lnprob"] = np.array([r[0] for r in res])
+        g[f"swift_{name}_status"] = np.array([r[1] for r in res], dtype=np.int32)
+        g[f"swift_{name}_lnprob_tight"] = np.where(np.isfinite(tight), tight, np.nan)
+        g[f"swift_{name}_lsoda_noise_idx"] = noise_idx(g[f"swift_{name}_lnprob"], tight)
+        # ---- library variant, "S" grid: all time stamps from 1e-3 s on
+        pars = np.array(GRB_PARS[grb])
+        lc = lib.model_lc(pars, GRBtype="S")
+        xs = t_all[(t_all >= lc[0, 0]) & (t_all <= lc[0, -1])]
+        y0 = np.interp(xs, lc[0], lc[1])
+        yerr = 0.2 * y0
+        y = y0 + rng.normal(0.0, yerr)
+        data = pd.DataFrame({"t": xs, "Lum50": y, "Lum50err": yerr})
+        Pl = np.array([np.abs(pars * (1.0 + 0.1 * rng.standard_normal(6))) for _ in range(6)])
+        g[f"swift_{name}_libS_ds"] = np.array([xs, y, yerr])
+        g[f"swift_{name}_libS_pars"] = Pl
+        g[f"swift_{name}_libS_lnlike"] = np.array([lib.lnlike(p, data, "S") for p in Pl])
+        with tight_lsoda_lib():
+            g[f"swift_{name}_libS_lnlike_tight"] = np.array([lib.lnlike(p, data, "S") for p in Pl])
+        g[f"swift_{name}_libS_lsoda_noise_idx"] = noise_idx(g[f"swift_{name}_libS_lnlike"], g[f"swift_{name}_libS_lnlike_tight"])
+        print("swift", name, "rows", len(t_all), "on L grid", len(x), "on S grid", len(xs), "lnprob", g[f"swift_{name}_lnprob"][:2])
+    np.savez_compressed(os.path.join(HERE, "golden_swift.npz"), **g)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--flag-scan", type=int, default=1500)
-    ap.add_argument("--only", choices=["all", "lib", "libkw", "corners", "libscan", "longlc", "flagscan2", "libscan2", "rhs", "tight"], default="all", help="regenerate only one file")
+    ap.add_argument("--only", choices=["all", "lib", "libkw", "corners", "libscan", "longlc", "flagscan2", "libscan2", "rhs", "tight", "swift"], default="all", help="regenerate only one file")
     a = ap.parse_args()
     import scipy, pandas
     if a.only == "all":
@@ -623,6 +689,8 @@ def main():
     if a.only in ("all", "rhs"):
         make_rhs()
     noise_report = make_tight() if a.only in ("all", "tight") else None
+    if a.only in ("all", "swift"):
+        make_swift()
     manifest = {
         "generator": "tests/golden/make_golden.py",
         "reference": "sgibson91/magprop mounted at /root/reference (magnetar v%s)" % lib.__version__

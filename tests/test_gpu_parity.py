@@ -606,3 +606,29 @@ def test_fit_statistics_epilogue(mpa, gsynth):
     assert st["aicc"] == pytest.approx(mpa.aicc(y, ymod, yerr, 6), rel=1e-10)
     many = fit_statistics(np.tile(p, (3, 1)), x, y, yerr)
     assert many["chisq"].shape == (3,) and np.allclose(many["chisq"], st["chisq"], rtol=1e-12)
+
+
+@pytest.mark.parametrize("name", ["060614", "051016B"])
+def test_light_curves_with_real_swift_time_stamps(mpa, gswift, gsynth, name):
+    """Observation times of real Swift bursts (1 921 / 74 inside the synth grid, most of them in the first hundred seconds:
+    up to 40 per grid interval early, none for thousands of intervals late; every row from 1e-3 s on for the library
+    variant's short-GRB grid): the reference's values, default and tight integrator, through both front ends; the long one
+    also inside a 1 300-walker batch (the 2-steps-per-lane kernel with scratch rows)."""
+    import pandas as pd
+    from magprop_amd import LogProb
+    x, y, yerr = gswift[f"swift_{name}_ds"]
+    P, ref, rst = gswift[f"swift_{name}_pars"], gswift[f"swift_{name}_lnprob"], gswift[f"swift_{name}_status"]
+    tight, noise = gswift[f"swift_{name}_lnprob_tight"], noise_mask(gswift, len(P), f"swift_{name}_lsoda_noise_idx")
+    out = mpa.synth.lnprob(P, pd.Series(x), pd.Series(y), pd.Series(yerr), None)
+    assert np.array_equal(np.isfinite(out), rst == 0)
+    assert_vs_reference(out, ref, rst == 0, tight, noise)
+    lp_ = LogProb(x, y, yerr)
+    big = np.tile(P, (109, 1))[:1300]
+    out_big = lp_(big)
+    assert np.allclose(out_big[: len(P)][rst == 0], out[rst == 0], rtol=CROSS_VARIANT_RTOL, atol=1e-9)
+    assert_vs_reference(out_big[: len(P)], ref, rst == 0, tight, noise)
+    xs, ys, es = gswift[f"swift_{name}_libS_ds"]
+    data = pd.DataFrame({"t": xs, "Lum50": ys, "Lum50err": es})
+    ll = mpa.lnlike(gswift[f"swift_{name}_libS_pars"], data, "S")
+    r, t = gswift[f"swift_{name}_libS_lnlike"], gswift[f"swift_{name}_libS_lnlike_tight"]
+    assert_vs_reference(ll, r, np.isfinite(r), t, noise_mask(gswift, len(r), f"swift_{name}_libS_lsoda_noise_idx"))

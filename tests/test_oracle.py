@@ -347,3 +347,22 @@ def test_adaptive_stride_restatement(gsynth, gflag, gflag2, tarr, cfg, spl):
         assert np.array_equal(s2, gflag2["status"][sel])
         assert_vs_reference(o2, gflag2["lnprob"][sel], gflag2["status"][sel] == 0, gflag2["lnprob_tight"][sel],
                             noise_mask(gflag2, len(gflag2["ds"]))[sel])
+
+
+@pytest.mark.parametrize("name", ["060614", "051016B"])
+def test_light_curves_with_real_swift_time_stamps(gswift, gsynth, tarr, tarr_S, cfg, name):
+    """Observation times of real Swift bursts (1 921 / 74 of them inside the synth grid, densely clustered in the first
+    hundred seconds; every row from 1e-3 s on for the library variant's short-GRB grid): the reference's values."""
+    x, y, yerr = gswift[f"swift_{name}_ds"]
+    P, ref, rst = gswift[f"swift_{name}_pars"], gswift[f"swift_{name}_lnprob"], gswift[f"swift_{name}_status"]
+    assert np.diff(x).min() >= 0.0 and x.size in (1921, 74) and (x.size == 74 or np.median(x) < 1.0e3)   # 060614: half before 1 000 s
+    for mode in ("fixed", "adaptive"):
+        out, st = co.lnprob_batch(cfg, P, tarr, x, y, yerr, gsynth["prior_lower"], gsynth["prior_upper"], LOG_MASK, mode=mode)
+        assert np.array_equal(st, rst)
+        assert_vs_reference(out, ref, rst == 0, gswift[f"swift_{name}_lnprob_tight"],
+                            noise_mask(gswift, len(out), f"swift_{name}_lsoda_noise_idx"))
+    xs, ys, es = gswift[f"swift_{name}_libS_ds"]
+    assert xs[0] < 1.0                                          # rows before the first second exist only on the "S" grid
+    r, t = gswift[f"swift_{name}_libS_lnlike"], gswift[f"swift_{name}_libS_lnlike_tight"]
+    ll = np.array([co.lnlike(co.cfg_lib(), p, tarr_S, xs, ys, es)[0] for p in gswift[f"swift_{name}_libS_pars"]])
+    assert_vs_reference(ll, r, np.isfinite(r), t, noise_mask(gswift, len(r), f"swift_{name}_libS_lsoda_noise_idx"))
