@@ -25,10 +25,9 @@ def aicc(ydata, ymod, yerr, Npars):
     ydata, ymod, yerr = (np.asarray(v, dtype=float) for v in (ydata, ymod, yerr))
     if not (ydata.size == ymod.size == yerr.size):
         raise ValueError("ydata, ymod and yerr should all be the same length")
-    a = -1.0 * np.sum(((ydata - ymod) / yerr) ** 2.0)
-    b = 2.0 * Npars
-    c = ((2.0 * Npars) * (Npars + 1.0)) / (ydata.size - Npars - 1.0)
-    return a + b + c
+    k, n = float(Npars), float(ydata.size)
+    chisq = np.sum(np.square((ydata - ymod) / yerr))
+    return 2.0 * k * (1.0 + (k + 1.0) / (n - k - 1.0)) - chisq
 
 
 def fit_statistics(pars, x, y, yerr, variant="synth", GRBtype=None, device=-1):

@@ -33,20 +33,16 @@ def write_dataset(path, x, y, yerr):
 def write_chain_files(basename, chain, lnprob):
     """chain (nsteps, nwalkers, npars), lnprob (nsteps, nwalkers) -> the reference's <basename>_chain.csv,
     <basename>_<k>.csv, <basename>_lnp.csv (synth_mcmc.py:188-213)."""
+    chain, lnprob = np.asarray(chain, dtype=float), np.asarray(lnprob, dtype=float)
     nstep, nwalk, npars = chain.shape
+    # (np.savetxt formats row by row in C: an 8 192-walker x 3 000-step chain is 1.7e8 numbers, minutes of f-strings)
+    rows = np.concatenate([chain, lnprob[:, :, None]], axis=2).reshape(nstep * nwalk, npars + 1)
     with open(f"{basename}_chain.csv", "w") as f:
         f.write(f"{npars}, {nwalk}, {nstep}\n")
-        for j in range(nstep):
-            for i in range(nwalk):
-                f.write("".join(f"{chain[j, i, k]:.6f}, " for k in range(npars)))
-                f.write(f"{lnprob[j, i]:.6f}\n")
+        np.savetxt(f, rows, fmt="%.6f", delimiter=", ")
     for k in range(npars):
-        with open(f"{basename}_{k}.csv", "w") as f:
-            for j in range(nstep):
-                f.write(", ".join(f"{chain[j, i, k]:.6f}" for i in range(nwalk)) + "\n")
-    with open(f"{basename}_lnp.csv", "w") as f:
-        for j in range(nstep):
-            f.write(", ".join(f"{lnprob[j, i]:.6f}" for i in range(nwalk)) + "\n")
+        np.savetxt(f"{basename}_{k}.csv", chain[:, :, k], fmt="%.6f", delimiter=", ")
+    np.savetxt(f"{basename}_lnp.csv", lnprob, fmt="%.6f", delimiter=", ")
 
 
 def read_chain_file(path):
