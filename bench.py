@@ -353,9 +353,9 @@ def run_passes(c, config, scaling, steps, warmup, curve=False, nwalk=None, grb=N
     dt = float(tmax.item())
     kern_ms = np.array([ev0[i].elapsed_time(ev1[i]) for i in range(warmup, total) if i % EVENT_EVERY == 0 or i == warmup])
     n_simd = lp.handle.n_simd
-    pc = 2 * n_local <= n_simd and not curve
-    variant = ("curve kernel, " if curve else "") + ("producer/consumer pair of wavefronts" if pc
-                                                      else "4 steps per lane" if n_local <= n_simd else "2 steps per lane")
+    variant = ("curve kernel, " if curve else "") + ("4 steps per lane, one wavefront per SIMD" if n_local <= n_simd
+                                                      else "2 steps per lane, two wavefronts per SIMD")
+    variant += "; order-5 exponential Adams-Moulton, steps over 1/2/4 grid intervals (adaptive)"
     if config == 5:
         workload = (f"BASELINE config 5: four GRB types x {n_global // 4} walkers at truth+{a.spread:g}*randn, {len(n_obs_desc)} light "
                     f"curves of {n_obs_desc} points selected per walker, {n_global} walkers in one launch per pass")
@@ -374,7 +374,7 @@ def run_passes(c, config, scaling, steps, warmup, curve=False, nwalk=None, grb=N
         "n_obs": n_obs_desc, "kernel_variant": variant, "sweep_tol": lp.handle.sweep_tol,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "mp::lnprob_pc_kernel" if pc else "mp::lnprob_kernel",
+                     "kernel": "mp::lnprob_kernel",
                      "kernel_ms_avg": 1e3 * kavg, "kernel_ms_min": float(kern_ms.min()),
                      "algorithmic_bytes_per_eval": bytes_eval, "evals_per_launch": n_local,
                      "note": "latency-bound fp64 VALU recurrence: neither HBM nor MFMA binds; see valu"},
@@ -556,27 +556,31 @@ def main():
     # ---- N = 1 extras: harder inputs for the same kernel, the reference's golden walkers, sustained run, config 1
     extra = golden = sustained = None
     if world == 1 and not a.no_extra and a.config != 5 and not a.curve:
-        def time_kernel(P_np, reps=48):
+        def time_kernel(P_np, reps=48, lp_=None):
             """Same sampling as the timed loop: HIP events around every EVENT_EVERY-th of `reps` back-to-back launches."""
+            lp_ = lp_ or lp
             P = torch.from_numpy(np.ascontiguousarray(P_np)).to(dev)
             out = torch.empty(P.shape[0], dtype=torch.float64, device=dev)
             st = torch.empty(P.shape[0], dtype=torch.int32, device=dev)
+
+            def go():
+                lp_.handle.lnprob_batch_dev(P.data_ptr(), P.shape[0], 6, out.data_ptr(), d_status=st.data_ptr(), stream=stream.cuda_stream)
             idx = [r for r in range(reps) if r % EVENT_EVERY == 0]
             e0 = {r: torch.cuda.Event(enable_timing=True) for r in idx}
             e1 = {r: torch.cuda.Event(enable_timing=True) for r in idx}
             for _ in range(3):
-                launch(P, out, None, st)
+                go()
             for r in range(reps):
                 if r in e0:
                     e0[r].record(stream)
-                launch(P, out, None, st)
+                go()
                 if r in e0:
                     e1[r].record(stream)
             torch.cuda.synchronize(dev)
             ms = float(np.mean([e0[r].elapsed_time(e1[r]) for r in idx]))
-            lp.handle.lnprob_batch(P_np)                                        # host entry: records the sweeps per tile
-            return {"kernel_ms": ms, "evals_per_sec": P.shape[0] / ms * 1e3, "sweeps_per_tile": lp.handle.last_mean_sweeps,
-                    "not_ok": int((st != 0).sum().item())}
+            lp_.handle.lnprob_batch(P_np)                                       # host entry: records tiles and sweeps
+            return {"kernel_ms": ms, "evals_per_sec": P.shape[0] / ms * 1e3, "tiles_per_walker": lp_.handle.last_mean_tiles,
+                    "sweeps_per_tile": lp_.handle.last_mean_sweeps, "not_ok": int((st != 0).sum().item())}
         rngx = np.random.default_rng(a.seed + 1)
         wide = PRIOR_LOWER + (PRIOR_UPPER - PRIOR_LOWER) * rngx.random((n_global, 6))
         es = EnsembleSampler(n_global, 6, x, y, yerr, seed=a.seed + 2, device=c.dev_index)
@@ -585,6 +589,14 @@ def main():
         near = L["props"][a.warmup].cpu().numpy()
         extra = {"near_truth": time_kernel(near), "prior_wide": time_kernel(wide), "burnt_in_500_steps": time_kernel(burnt),
                  "note": "HIP events around every 4th of 48 back-to-back launches, as in the timed loop (roofline.kernel_ms_avg)"}
+        # the same walkers with every grid interval a step (cfg.max_stride = 1), also at the strict sweep tolerance: what the
+        # stride adaptivity and the default tolerance buy (rounds 1-2 ran an order-4 formula over every interval)
+        from magprop_amd import LogProb as _LP, _capi as _c
+        for key, kw in (("near_truth_fixed_steps", {"max_stride": 1}),
+                        ("near_truth_fixed_steps_strict_tol", {"max_stride": 1, "sweep_tol": _c.SWEEP_TOL_STRICT})):
+            lpx = _LP(x, y, yerr, device=c.dev_index, **kw)
+            extra[key] = time_kernel(near, lp_=lpx)
+            lpx.handle.close()
         Pg, tight, ref = g[grb + "_pars"], g[grb + "_lnprob_tight"], g[grb + "_lnprob"]
         noise = g[grb + "_lsoda_noise_idx"] if grb + "_lsoda_noise_idx" in g else np.zeros(0, dtype=int)
         og = lp(Pg)

@@ -366,6 +366,16 @@ mp_handle *mp_create(const mp_model_cfg *cfg, const double *tgrid, int n_grid, i
         const double v = std::atof(e);
         if (v > 0.0 && v < 1.0e-3) s.stride_tol = v;
     }
+    s.coarse_tol_factor = 0.1;
+    if (const char *e = std::getenv("MAGPROP_AMD_COARSE_TOL_FACTOR")) {   // experiments only
+        const double v = std::atof(e);
+        if (v > 0.0 && v <= 1.0) s.coarse_tol_factor = v;
+    }
+    s.coarse_ultra_factor = s.coarse_tol_factor;
+    if (const char *e = std::getenv("MAGPROP_AMD_COARSE_ULTRA_FACTOR")) {   // experiments only
+        const double v = std::atof(e);
+        if (v >= 0.0 && v <= 1.0) s.coarse_ultra_factor = v;
+    }
     s.ultra_tol = std::min(1.0e-5, 100.0 * s.sweep_tol);
     if (const char *e = std::getenv("MAGPROP_AMD_ULTRA_TOL")) {   // experiments only (0 disables); kept inside [0, 1e-4]
         const double v = std::atof(e);

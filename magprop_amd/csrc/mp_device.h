@@ -75,6 +75,8 @@ struct DevShared {
     double sweep_tol;     // relative change of the step-end values that ends the Newton sweeps of a tile
     double ultra_tol;     // corrections below this let the next sweep linearise omega_dot instead of evaluating it
     double stride_tol;    // smoothness indicator above which a tile at a coarse stride is cut (cfg.stride_tol)
+    double coarse_tol_factor;   // sweep tolerance of tiles over 2 or 4 grid intervals, relative to sweep_tol
+    double coarse_ultra_factor; // the same for ultra_tol
     int32_t n_simd;       // SIMDs of the device (multiProcessorCount x 4): batch sizes up to this get one wave per SIMD
     int32_t force_spl;    // experiments: 0 = automatic, else steps per lane (2, 4)
     int32_t max_kind;     // coarsest tile kind allowed: 1, 2, 3 for cfg.max_stride 1, 2, 4

@@ -263,6 +263,30 @@ MP_DEV double hermite_mdisc(const StrideK &K, int i, double h, double z, double 
     return z < 1.0 ? hermite5(K.hq[i], h, y0, d0, e0, y1, d1, e1) : hermite(K.theta[i], h, y0, d0, y1, d1);
 }
 
+// Q^k of the four tile kinds, k = 0 .. 64*SPL: the step end times of a tile are t_s Q^k (the grid is geometric).  Filled once
+// per kernel (every lane computes its own entries), read by every tile.
+template <int SPL>
+struct TimeTable {
+    static constexpr int kN = 64 * SPL + 1;
+    double E[4][kN];
+};
+
+template <int SPL>
+MP_DEV void time_table_init(const DevShared &sh, TimeTable<SPL> &tt) {   // every thread of the (one-wavefront) workgroup calls this
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int kind = 0; kind < 4; ++kind) {
+        Vd<SPL> ek;
+#pragma unroll
+        for (int s = 0; s < SPL; ++s) ek[s] = (double)(lane * SPL + s + 1) * sh.sk[kind].lnQ;
+        const Vd<SPL> E = exp_fast(ek);
+#pragma unroll
+        for (int s = 0; s < SPL; ++s) tt.E[kind][lane * SPL + s + 1] = E[s];
+        if (lane == 0) tt.E[kind][0] = 1.0;
+    }
+    __syncthreads();
+}
+
 // The image of the last kept tile in LDS: node 0 = the tile's start point, node e + 1 = step end e.  It serves the
 // observations (mode A picks the states bracketing each observed time out of it) and, as the record of the most recent
 // steps, the multistep history of a successor tile whose step differs.
@@ -274,22 +298,22 @@ struct TileImage {
     double M[kN];   // Mdisc
     double D[kN];   // dMdisc/dt
     double D2[kN];  // d2Mdisc/dt2
+    double R[kN];   // uncapped Alfven radius (the branch of the right-hand side at the start of the next tile)
 };
 
 // (Mdisc, omega) at position p8 (in eighths of a grid interval) inside the kept part of the image of a tile of kind
 // `kind` that started at pos8 / time t_s with steps of d8 eighths: the node itself when p8 is one, else the Hermite
 // interpolant over its step (strides 2 and 4 only; the remainder is then a whole number of grid intervals).
 template <int SPL>
-MP_DEV void image_state(const DevShared &sh, const TileImage<SPL> &im, int kind, int pos8, int d8, double t_s, double inv_tau,
-                        int p8, double &Mv, double &Wv) {
+MP_DEV void image_state(const DevShared &sh, const TileImage<SPL> &im, const TimeTable<SPL> &tt, int kind, int pos8, int d8,
+                        double t_s, double inv_tau, int p8, double &Mv, double &Wv) {
     const int rel = p8 - pos8, J = rel / d8, rem = rel - J * d8;
     Mv = im.M[J];
     Wv = im.W[J];
     if (rem != 0) {
         const StrideK &K = sh.sk[kind];
-        const Vd<1> e{{(double)(J + 1) * K.lnQ}};
         const int i = (rem >> 3) & 3;
-        const double h = t_s * exp_fast(e)[0] * K.one_m_invQ;
+        const double h = t_s * tt.E[kind][J + 1] * K.one_m_invQ;
         Mv = hermite_mdisc(K, i, h, h * inv_tau, im.M[J], im.D[J], im.D2[J], im.M[J + 1], im.D[J + 1], im.D2[J + 1]);
         Wv = hermite(K.theta[i], h, im.W[J], im.F[J], im.W[J + 1], im.F[J + 1]);
     }
@@ -302,8 +326,8 @@ MP_DEV void image_state(const DevShared &sh, const TileImage<SPL> &im, int kind,
 // optional curve outputs; im / Lbuf are the wave's LDS areas (Lbuf: [2*(4*64*SPL + 1)], staging of the curve outputs).
 template <bool CURVES, int SPL, bool LONG>
 MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, double (&par)[MP_MAX_NDIM],
-                        TileImage<SPL> &im, double *Lbuf, double &lnp_out, int &status_out, int &sweeps_out,
-                        int &tiles_out) {
+                        TileImage<SPL> &im, const TimeTable<SPL> &tt, double *Lbuf, double &lnp_out, int &status_out,
+                        int &sweeps_out, int &tiles_out) {
     constexpr int kSPL = SPL, kTile = 64 * SPL, kMaxSweeps = kTile + kMaxSweepsMargin;
     const int lane = threadIdx.x & 63;
 
@@ -398,13 +422,10 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
             // ---------------- step end times (the grid is geometric: t_k = t_s Q^k) and step lengths
             Vd<kSPL> h, S1, dS1;
             {
-                Vd<kSPL> ek, tb;
-#pragma unroll
-                for (int s = 0; s < kSPL; ++s) ek[s] = (double)min(lane * kSPL + s + 1, nc) * K.lnQ;
-                const Vd<kSPL> E = exp_fast(ek);
+                Vd<kSPL> tb;
 #pragma unroll
                 for (int s = 0; s < kSPL; ++s) {
-                    tb[s] = t_s * E[s];
+                    tb[s] = t_s * tt.E[kind][min(lane * kSPL + s + 1, nc)];
                     h[s] = (lane * kSPL + s < nc) ? tb[s] * K.one_m_invQ : 0.0;   // 0 for the padding steps of a short tile
                 }
                 S1 = mdot_fb_d(w, tb, dS1);
@@ -413,7 +434,14 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
             // ---------------- history at this tile's spacing: the source of Mdisc is analytic; (omega_dot, omega) at the
             // three (predictor: four) previous points come from the record of the last kept tile
             double cS0, cS1, cS2, cS3, cdS0;
-            {
+            if (rec_valid && rec_kind == kind && rec_J >= 3) {
+                // same spacing as the record: its last nodes are the points (dMdisc/dt = Mdotfb - Mdisc/tvisc)
+                cS0 = fma(im.M[rec_J], w.inv_tau, im.D[rec_J]);
+                cS1 = fma(im.M[rec_J - 1], w.inv_tau, im.D[rec_J - 1]);
+                cS2 = fma(im.M[rec_J - 2], w.inv_tau, im.D[rec_J - 2]);
+                cS3 = fma(im.M[rec_J - 3], w.inv_tau, im.D[rec_J - 3]);
+                cdS0 = fma(im.D[rec_J], w.inv_tau, im.D2[rec_J]);
+            } else {
                 const double q2 = K.inv_Q * K.inv_Q;
                 const Vd<4> tg{{t_s, t_s * K.inv_Q, t_s * q2, t_s * q2 * K.inv_Q}};
                 Vd<4> dSg;
@@ -512,7 +540,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
             // ... then Newton-type sweeps of the linearised step maps.
             // E*[k]: values at the four points before this lane's first step (k = 0..3) and at its step ends (k = 4+s).
             double Ef[kSPL + 4], Ew[kSPL + 4];
-            unsigned long long flagged = 0ull, pending = ~0ull;
+            unsigned long long flagged = 0ull, pending = ~0ull, pending_tight = ~0ull;
             bool settled = false;    // this lane's guesses moved by < 1e-6 in the previous sweep: close enough to its solution
                                      // for an excursion beyond the break-up limit to be the solution's, not the iteration's
             int sweep = 0, over_sweeps = 0;
@@ -527,6 +555,9 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
             Vd<kSPL> lam, ez, n0, n1, n2, n3, n4;
             EamW5<kSPL> cw;
             bool light = false, ultra = false, early_stop = false;
+            // (a step over 2 or 4 grid intervals weighs an error of omega_dot 2 or 4 times as much: tighter sweeps there)
+            const double tol_k = kind >= 2 ? sh.coarse_tol_factor * sh.sweep_tol : sh.sweep_tol;
+            const double ultra_k = kind >= 2 ? sh.coarse_ultra_factor * sh.ultra_tol : sh.ultra_tol;
             while (true) {
                 ++sweep;
                 if (!light) {   // (after a sweep that moved every lane by < 1e-4 the guesses are positive and finite)
@@ -620,20 +651,24 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 const double mag = (double)kSPL * fabs(wc);
                 const bool all_settled = dsum <= 1.0e-6 * mag;                       // false for NaN
                 const bool all_small = dsum <= 1.0e-4 * mag;
-                const bool all_tiny = dsum <= sh.ultra_tol * mag;
-                const bool all_ok = dsum <= sh.sweep_tol * mag;
+                const bool all_tiny = dsum <= ultra_k * mag;
+                const bool all_ok = dsum <= tol_k * mag;
                 settled = all_settled;
                 light = __all(all_small);
                 // (lambda is the derivative at the point this sweep evaluated; the linearisation cannot see the break-up
                 // discontinuity of the accretion torque, so tiles that come near it keep evaluating omega_dot)
                 ultra = full && __all(all_tiny && !near_limit);
                 pending = __ballot(!all_ok);
+                // (lanes of a tile that is stopped before all of it has converged are kept only if their own last
+                // correction was a hundred times below the tolerance: slow sweeps contract by 0.3-0.5 per pass, so a
+                // correction just below the tolerance leaves an error of the same size)
+                pending_tight = __ballot(!(dsum <= 0.01 * tol_k * mag));
                 if (pending == 0ull || flagged != 0ull || sweep >= kMaxSweeps) break;
                 if (kind >= 2 && sweep >= kCoarseMaxSweeps) break;   // not worth it at this stride (the rest is redone finer)
                 // Slow sweeps on single intervals (a poor extrapolated guess through a fast spin-up, far from the break-up
                 // limit): the lanes that have converged are final (a step depends on earlier ones only); they are kept
                 // and a new tile starts behind them with a fresh extrapolation, instead of sweeping on over all 64 lanes.
-                if (kind <= 1 && sweep >= kFineMaxSweeps && over_sweeps == 0 && __ffsll(pending) - 1 >= 2 * kMinKeepLanes) {
+                if (kind <= 1 && sweep >= kFineMaxSweeps && over_sweeps == 0 && __ffsll(pending_tight) - 1 >= 2 * kMinKeepLanes) {
                     early_stop = true;
                     break;
                 }
@@ -655,12 +690,12 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 mb = __ballot(bad);
                 // a step whose sweeps never settle is chattering on the Nacc discontinuity: same verdict as a flag
                 mf = flagged | __ballot(over) | ((flagged || early_stop) ? 0ull : pending);
-                if (early_stop) { mb &= ~pending; mf &= ~pending; }   // nothing is decided on lanes that are not kept
+                if (early_stop) { mb &= ~pending_tight; mf &= ~pending_tight; }   // nothing is decided on lanes that are not kept
             }
             // At a coarse stride nothing of this is a verdict: the lanes before the first one that failed, or whose sweeps
             // had not converged when they were stopped, hold converged steps (a step depends on earlier ones only) and
             // are kept like the steps before a kink; the rest is redone finer.
-            const unsigned long long unconv = kind >= 2 ? (mb | mf | pending) : (early_stop ? pending : 0ull);
+            const unsigned long long unconv = kind >= 2 ? (mb | mf | (pending ? pending_tight : 0ull)) : (early_stop ? pending_tight : 0ull);
             if (kind <= 1 && (mb | mf)) {
                 const int first = __ffsll((unsigned long long)(mb | mf)) - 1;
                 status = ((mf >> first) & 1ull) ? MP_STATUS_FLAG : MP_STATUS_NONFINITE;
@@ -711,7 +746,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                         else if (tail >= 6 + kSPL && (I64 & post) == 0ull) next_kind = 2;
                     }
                 }
-                if (kind == 0) next_kind = 1;                                   // after the sub-stepped tiles: single intervals
+                if (kind == 0) next_kind = 3;   // after the sub-stepped tiles: optimistic (a tile that meets a fast feature is cut)
                 next_kind = min(next_kind, max_kind);
             }
             const int keep = min(keep_lanes * kSPL, nc);                       // steps kept
@@ -725,6 +760,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 const int e = lane * kSPL + s + 1;
                 const double dM = fma(-M1[s], w.inv_tau, S1[s]);               // dM/dt = Mdotfb - M/tvisc, and its derivative
                 im.W[e] = wg[s]; im.F[e] = Ef[4 + s]; im.M[e] = M1[s]; im.D[e] = dM; im.D2[e] = fma(-dM, w.inv_tau, dS1[s]);
+                im.R[e] = d1.rmu[s];
             }
             if (lane == 0) {
                 const double dM = fma(-M_s, w.inv_tau, cS0);
@@ -742,8 +778,8 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 if (deferred) {
                     const int p8 = 8 * ob_g;
                     if (ob_g >= 0 && p8 >= pos8 && p8 < end_kept8) {
-                        image_state(sh, im, kind, pos8, d8, t_s, w.inv_tau, p8, obM[0], obW[0]);
-                        image_state(sh, im, kind, pos8, d8, t_s, w.inv_tau, p8 + 8, obM[1], obW[1]);
+                        image_state(sh, im, tt, kind, pos8, d8, t_s, w.inv_tau, p8, obM[0], obW[0]);
+                        image_state(sh, im, tt, kind, pos8, d8, t_s, w.inv_tau, p8 + 8, obM[1], obW[1]);
                     }
                     if (long_lc) {
                         // observations 64.. whose interval starts inside the kept range (64-interval buckets of the dataset)
@@ -754,8 +790,8 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                             const int g = sh.obs_g[dsd.obs_off + j];
                             if (g < g_lo || g >= g_hi) continue;
                             double Ma, Wa, Mb, Wb;
-                            image_state(sh, im, kind, pos8, d8, t_s, w.inv_tau, 8 * g, Ma, Wa);
-                            image_state(sh, im, kind, pos8, d8, t_s, w.inv_tau, 8 * g + 8, Mb, Wb);
+                            image_state(sh, im, tt, kind, pos8, d8, t_s, w.inv_tau, 8 * g, Ma, Wa);
+                            image_state(sh, im, tt, kind, pos8, d8, t_s, w.inv_tau, 8 * g + 8, Mb, Wb);
                             double *p = sc + (j - 64);
                             p[0] = Ma; p[sc_stride] = Mb;
                             p[2 * sc_stride] = Wa; p[3 * sc_stride] = Wb;
@@ -856,17 +892,11 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
             }
 
             // ---------------- carry the end of the kept steps to the next tile
-            {
-                const Vd<1> ee{{(double)keep * K.lnQ}};
-                t_s = t_s * exp_fast(ee)[0];
-                M_s = im.M[keep];
-                om_s = im.W[keep];
-                cf0 = im.F[keep];
-                Vd<1> md;
-                md[0] = M_s * w.inv_tau;
-                const double t17 = pow_m1_7_fast(md)[0];
-                flags_s = branch_flags(w, w.Crm * (t17 * t17), om_s);
-            }
+            t_s = t_s * tt.E[kind][keep];
+            M_s = im.M[keep];
+            om_s = im.W[keep];
+            cf0 = im.F[keep];
+            flags_s = branch_flags(w, im.R[keep], om_s);
             rec_valid = true;
             rec_kind = kind;
             rec_d8 = d8;

@@ -43,9 +43,11 @@ namespace mp {
 template <bool CURVES, int SPL, bool LONG>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPL >= 4 ? 1 : 2, SPL >= 4 ? 1 : 2))) void lnprob_kernel(const DevShared sh, const LaunchArgs a) {
     __shared__ TileImage<SPL> im;
+    __shared__ TimeTable<SPL> tt;
     __shared__ double Lbuf[CURVES ? 2 * (4 * 64 * SPL + 1) : 1];   // up to 4 grid points per step
     ktab_init();
     wtab_init(sh.wtab);
+    time_table_init(sh, tt);
     const int walker = blockIdx.x;
     double par[MP_MAX_NDIM];
     const double *pw = a.pars + (size_t)walker * a.ndim;
@@ -53,7 +55,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPL >= 4 ? 1
     for (int i = 0; i < MP_MAX_NDIM; ++i) par[i] = i < a.ndim ? pw[i] : 0.0;
     double lnp;
     int status, sweeps, tiles;
-    walker_eval<CURVES, SPL, LONG>(sh, a, walker, par, im, Lbuf, lnp, status, sweeps, tiles);
+    walker_eval<CURVES, SPL, LONG>(sh, a, walker, par, im, tt, Lbuf, lnp, status, sweeps, tiles);
     if (threadIdx.x == 0) {
         a.lnprob[walker] = lnp;
         if (a.status) a.status[walker] = status;
@@ -108,9 +110,11 @@ MP_DEV double u01(uint32_t hi, uint32_t lo) {   // 53-bit uniform in [0, 1)
 template <int SPL, bool LONG>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPL >= 4 ? 1 : 2, SPL >= 4 ? 1 : 2))) void stretch_kernel(const DevShared sh, const StretchArgs g) {
     __shared__ TileImage<SPL> im;
+    __shared__ TimeTable<SPL> tt;
     __shared__ double lds[1];
     ktab_init();
     wtab_init(sh.wtab);
+    time_table_init(sh, tt);
     const int gs = g.slot_lo + (int)blockIdx.x;                    // slot of the active half, all ensembles flattened
     const int w_ens = gs / g.n_half;                               // which ensemble
     const int slot = gs - w_ens * g.n_half;                        // which walker of the active half
@@ -148,7 +152,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPL >= 4 ? 1
 #pragma unroll
         for (int i = 0; i < MP_MAX_NDIM; ++i) lnp = i < g.ndim ? sub_rn(lnp, mul_rn(mul_rn(0.5, prop[i]), prop[i])) : lnp;
     } else {
-        walker_eval<false, SPL, LONG>(sh, a, k, par, im, lds, lnp, status, sweeps, tiles);
+        walker_eval<false, SPL, LONG>(sh, a, k, par, im, tt, lds, lnp, status, sweeps, tiles);
     }
     if ((threadIdx.x & 63) == 0) {   // lane 0 of the evaluating wavefront
         const double lnp_old = g.lnprob[k];

@@ -558,7 +558,7 @@ int mpo_trajectory_mode(const mpo_cfg *c, const double *pars, int ndim, const do
             } else if (s == 2) next_s = (imax * 64.0 < stride_tol) ? 4 : 2;
             if (next_s > max_stride) next_s = max_stride;
         }
-        if (pre) next_s = 1;
+        if (pre) next_s = (mode == 1 && sub_done + keep >= pre_fine * MPO_PRE_SUB) ? max_stride : 1;   /* optimistic after the sub-steps */
         /* ---- commit the kept steps: nodes, and the grid points they contain */
         mpo_node prev = nd[nn - 1];
         for (J = 0; J < keep; ++J) {

@@ -21,7 +21,7 @@ for spec in sys.argv[1:]:
     for ext in ("md", "json"):
         shutil.copy(os.path.join(src, "summary." + ext), os.path.join(ROOT, "profiles", f"{tag}_rocprof_summary.{ext}"))
     d = s.get("derived", {})
-    n = str(int(s["counters_per_launch"].get("SQ_WAVES", 0)) // (2 if "pc_kernel" in s.get("kernel", "") or mode == "stretch" else 1))
+    n = str(int(s["counters_per_launch"].get("SQ_WAVES", 0)))
     if mode not in ("stretch",) and "bench_under_profiler" in s:
         n = str(s["bench_under_profiler"]["evals_per_launch"])
     fig.setdefault(mode, {})[n] = {
