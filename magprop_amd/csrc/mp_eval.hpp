@@ -707,6 +707,8 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
             // smoothness indicator h |4th difference of (f - lambda omega)| / omega against stride_tol, and against
             // stride_tol / 64 and / 2048 (what it would be at twice / four times the step: 5th-order scaling, margin 2).
             int keep_lanes = 64, next_kind = kind;
+            // (the tile tried at a coarse stride right behind the sub-steps has no calm predecessor to vouch for it: a tenth)
+            const double tile_tol = (kind >= 2 && rec_kind == 0) ? 0.1 * sh.stride_tol : sh.stride_tol;
             {
                 bool brk = false, ind1 = false, ind64 = false, ind2048 = false;
 #pragma unroll
@@ -714,7 +716,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                     const bool valid = lane * kSPL + s < nc;
                     brk = brk || (valid && branch_flags(w, d1.rmu[s], wg[s]) != flags_s);
                     const double d4 = h[s] * fabs((n0[s] + n4[s]) - 4.0 * (n1[s] + n3[s]) + 6.0 * n2[s]);
-                    const double lim = sh.stride_tol * wg[s];
+                    const double lim = tile_tol * wg[s];
                     ind1 = ind1 || d4 > lim;
                     ind64 = ind64 || 64.0 * d4 > lim;
                     ind2048 = ind2048 || 2048.0 * d4 > lim;

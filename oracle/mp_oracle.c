@@ -442,8 +442,10 @@ int mpo_trajectory_mode(const mpo_cfg *c, const double *pars, int ndim, const do
     int i0 = 0;          /* grid index of the tile start */
     int sub_done = 0;    /* sub-steps of the pre-phase done */
     int s = 1;           /* stride of the next grid tile */
+    int last_was_pre = 0;
     while (status == MPO_OK && i0 < nsteps) {
         const int pre = i0 < pre_fine;
+        const int after_pre = !pre && last_was_pre;
         int nc;
         double Q;
         if (pre) {
@@ -528,10 +530,12 @@ int mpo_trajectory_mode(const mpo_cfg *c, const double *pars, int ndim, const do
         if (pre || s == 1) {
             if (tstatus != MPO_OK) { status = tstatus; break; }            /* a verdict only at stride <= 1 */
         } else {
+            /* the tile tried at a coarse stride right behind the sub-steps has no calm predecessor to vouch for it: a tenth */
+            const double tile_tol = after_pre ? 0.1 * stride_tol : stride_tol;
             int first = (nsolved < nc) ? nsolved / spl : 64;
             for (int l = 0; l < first && l * spl < nc; ++l)
                 for (int e = l * spl; e < (l + 1) * spl && e < nsolved; ++e)
-                    if (brk[e] || ind[e] > stride_tol) { if (l < first) first = l; }
+                    if (brk[e] || ind[e] > tile_tol) { if (l < first) first = l; }
             if (first * spl >= nc) first = 64;
             if (first < 64) {
                 ++st_.tiles_cut;
@@ -586,6 +590,7 @@ int mpo_trajectory_mode(const mpo_cfg *c, const double *pars, int ndim, const do
         if (pre) { sub_done += keep; i0 = sub_done / MPO_PRE_SUB; } else i0 += keep * s;
         M = tn[keep - 1].M; om = tn[keep - 1].w; fcur = tn[keep - 1].f;
         s = next_s;
+        last_was_pre = pre;
     }
     free(nd); free(tn); free(ind); free(brk);
     if (status != MPO_OK) for (int j = 0; j < n; ++j) { if (Mout) Mout[j] = NAN; if (Wout) Wout[j] = NAN; }
