@@ -266,6 +266,12 @@ double mp_last_mean_sweeps(const mp_handle *h);
 double mp_last_mean_tiles(const mp_handle *h);
 /* total Newton sweeps of every walker of that batch (all tiles; 0 for walkers that never started); returns the count copied */
 int mp_last_sweeps(const mp_handle *h, int32_t *out, int n);
+/* Diagnostics of the solver: with mp_tile_log(h, 1) every later host-buffer batch records, per walker, one word per tile it
+ * solved (the first MP_TILE_LOG of them): kind (0: 1/8-interval sub-steps, 1, 2, 3: steps over 1, 2, 4 grid intervals) |
+ * sweeps << 4 | lanes kept << 16.  mp_last_tile_log copies walker i's words of the most recent batch; returns how many. */
+#define MP_TILE_LOG 96
+int mp_tile_log(mp_handle *h, int enable);
+int mp_last_tile_log(const mp_handle *h, int walker, int32_t *out, int n);
 /* tiles solved (kept or redone) by every walker of that batch; returns the count copied */
 int mp_last_tiles(const mp_handle *h, int32_t *out, int n);
 double mp_sweep_tol(const mp_handle *h); /* the tolerance in force (cfg.sweep_tol or the default) */

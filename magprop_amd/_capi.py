@@ -25,7 +25,7 @@ EXPORTS = (
     "mp_synchronize", "mp_device", "mp_stream", "mp_n_grid", "mp_last_mean_sweeps", "mp_last_mean_tiles",
     "mp_sampler_create", "mp_sampler_destroy", "mp_sampler_set_positions", "mp_sampler_run", "mp_sampler_get_state",
     "mp_sampler_get_bad", "mp_sampler_n_slots", "mp_sampler_row_doubles", "mp_sampler_halfstep_shard",
-    "mp_sampler_halfstep_apply", "mp_sampler_state_ptrs", "mp_sweep_tol", "mp_n_simd", "mp_last_sweeps", "mp_last_tiles",
+    "mp_sampler_halfstep_apply", "mp_sampler_state_ptrs", "mp_sweep_tol", "mp_n_simd", "mp_last_sweeps", "mp_last_tiles", "mp_tile_log", "mp_last_tile_log",
 )
 ABI_VERSION = 3
 
@@ -143,6 +143,10 @@ def lib():
     L.mp_last_sweeps.restype = C.c_int
     L.mp_last_tiles.argtypes = [vp, ip, C.c_int]
     L.mp_last_tiles.restype = C.c_int
+    L.mp_tile_log.argtypes = [vp, C.c_int]
+    L.mp_tile_log.restype = C.c_int
+    L.mp_last_tile_log.argtypes = [vp, C.c_int, ip, C.c_int]
+    L.mp_last_tile_log.restype = C.c_int
     L.mp_sampler_get_bad.argtypes = [vp, C.c_int64, dp, C.c_int, i64p, i64p]
     L.mp_sampler_n_slots.argtypes = [vp]
     L.mp_sampler_row_doubles.argtypes = [vp]
@@ -332,6 +336,19 @@ class Handle:
         out = np.zeros(n, dtype=np.int32)
         m = self._L.mp_last_tiles(self._h, _iptr(out), int(n))
         return out[:max(m, 0)]
+
+    def tile_log(self, enable=True):
+        """Record, in every later host-buffer batch, what each walker's tiles were (diagnostics)."""
+        check(self._L.mp_tile_log(self._h, int(bool(enable))), "mp_tile_log")
+
+    def last_tile_log(self, walker):
+        """[(kind, sweeps, lanes kept, why), ...] of `walker` in the most recent host-buffer batch (tile_log() on): kind 0 =
+        1/8-interval sub-steps, 1 / 2 / 3 = steps over 1 / 2 / 4 grid intervals; 0 lanes kept = the tile was redone; why =
+        bits: 1 a branch of the right-hand side changed inside the tile, 2 / 4 / 8 the smoothness indicator exceeded
+        stride_tol / its 64th / its 2048th somewhere, 16 lanes had not converged when the sweeps were stopped."""
+        buf = np.zeros(96, dtype=np.int32)
+        m = self._L.mp_last_tile_log(self._h, int(walker), _iptr(buf), 96)
+        return [(int(w) & 15, (int(w) >> 4) & 0xFFF, (int(w) >> 16) & 0xFF, (int(w) >> 24) & 0x1F) for w in buf[:max(m, 0)]]
 
     @property
     def sweep_tol(self):

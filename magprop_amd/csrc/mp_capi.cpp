@@ -123,6 +123,9 @@ struct mp_handle {
     DevBuf<double> w_pars, w_lnprob, w_curves;
     DevBuf<int32_t> w_dsid, w_status, w_sweeps;
     double last_mean_tiles = 0.0;
+    bool tile_log_on = false;
+    DevBuf<int32_t> w_tile_log;
+    std::vector<int32_t> last_tile_log;
     DevBuf<unsigned char> w_io;   // mp_lnprob_batch: [pars | ds_id] in, [lnprob | status | sweeps] out, one copy each way
     PinnedBuf h_io;
     DevBuf<double> w_scratch;   // DevShared::obs_scratch (only allocated once a light curve longer than 64 points is set)
@@ -366,6 +369,10 @@ mp_handle *mp_create(const mp_model_cfg *cfg, const double *tgrid, int n_grid, i
         const double v = std::atof(e);
         if (v > 0.0 && v < 1.0e-3) s.stride_tol = v;
     }
+    s.coarse_max_sweeps = 5;
+    s.fine_max_sweeps = 8;
+    if (const char *e = std::getenv("MAGPROP_AMD_COARSE_MAX_SWEEPS")) { const int v = std::atoi(e); if (v >= 2 && v <= 64) s.coarse_max_sweeps = v; }   // experiments only
+    if (const char *e = std::getenv("MAGPROP_AMD_FINE_MAX_SWEEPS")) { const int v = std::atoi(e); if (v >= 2 && v <= 272) s.fine_max_sweeps = v; }
     s.coarse_tol_factor = 0.1;
     if (const char *e = std::getenv("MAGPROP_AMD_COARSE_TOL_FACTOR")) {   // experiments only
         const double v = std::atof(e);
@@ -451,7 +458,7 @@ int mp_destroy(mp_handle *h) {
     h->d_tgrid.release(); h->d_obs_dx.release(); h->d_obs_idt.release(); h->d_obs_y.release();
     h->d_obs_yerr.release(); h->d_obs_g.release(); h->d_tile_ptr.release(); h->d_ds.release();
     h->w_pars.release(); h->w_lnprob.release(); h->w_curves.release();
-    h->w_dsid.release(); h->w_status.release(); h->w_sweeps.release(); h->w_scratch.release();
+    h->w_dsid.release(); h->w_status.release(); h->w_sweeps.release(); h->w_scratch.release(); h->w_tile_log.release();
     h->w_io.release(); h->h_io.release();
     if (h->scratch_done) (void)hipEventDestroy(h->scratch_done);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -577,7 +584,16 @@ int mp_lnprob_batch(mp_handle *h, const double *pars, const int32_t *ds_id, int 
     a.sweeps = a.status + n;
     a.tiles = a.sweeps + n;
     a.ltot = ltot_out ? h->w_curves.p : nullptr;   // rows of walkers that fail are NaN-filled by the kernel
+    if (h->tile_log_on) {
+        if ((rc = h->w_tile_log.ensure((size_t)n * MP_TILE_LOG))) return rc;
+        HIP_TRY(hipMemsetAsync(h->w_tile_log.p, 0xFF, (size_t)n * MP_TILE_LOG * sizeof(int32_t), st));
+        a.tile_log = h->w_tile_log.p;
+    }
     if ((rc = launch_lnprob_ordered(h, a, st))) return rc;
+    if (h->tile_log_on) {
+        h->last_tile_log.resize((size_t)n * MP_TILE_LOG);
+        HIP_TRY(hipMemcpyAsync(h->last_tile_log.data(), h->w_tile_log.p, (size_t)n * MP_TILE_LOG * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    } else h->last_tile_log.clear();
     HIP_TRY(hipMemcpyAsync(h_out, d_out, out_bytes, hipMemcpyDeviceToHost, st));
     if (ltot_out)
         HIP_TRY(hipMemcpyAsync(ltot_out, h->w_curves.p, sizeof(double) * (size_t)n * ng, hipMemcpyDeviceToHost, st));
@@ -1044,6 +1060,20 @@ int mp_last_sweeps(const mp_handle *h, int32_t *out, int n) {
     if (!h || !out || n < 0) return fail(MP_EINVAL, "mp_last_sweeps: bad argument");
     const int m = std::min<int>(n, (int)h->last_sweeps.size());
     std::copy(h->last_sweeps.begin(), h->last_sweeps.begin() + m, out);
+    return m;
+}
+int mp_tile_log(mp_handle *h, int enable) {
+    if (!h) return fail(MP_EINVAL, "mp_tile_log: NULL handle");
+    Lock lock(h->mu);
+    h->tile_log_on = enable != 0;
+    return MP_OK;
+}
+int mp_last_tile_log(const mp_handle *h, int walker, int32_t *out, int n) {
+    if (!h || !out || n < 0 || walker < 0) return fail(MP_EINVAL, "mp_last_tile_log: bad argument");
+    const size_t off = (size_t)walker * MP_TILE_LOG;
+    if (off + MP_TILE_LOG > h->last_tile_log.size()) return 0;
+    int m = 0;
+    while (m < n && m < MP_TILE_LOG && h->last_tile_log[off + m] != -1) { out[m] = h->last_tile_log[off + m]; ++m; }
     return m;
 }
 int mp_last_tiles(const mp_handle *h, int32_t *out, int n) {

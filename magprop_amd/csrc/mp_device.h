@@ -80,7 +80,7 @@ struct DevShared {
     int32_t n_simd;       // SIMDs of the device (multiProcessorCount x 4): batch sizes up to this get one wave per SIMD
     int32_t force_spl;    // experiments: 0 = automatic, else steps per lane (2, 4)
     int32_t max_kind;     // coarsest tile kind allowed: 1, 2, 3 for cfg.max_stride 1, 2, 4
-    int32_t pad1;
+    int32_t coarse_max_sweeps, fine_max_sweeps, pad1;   // sweeps after which a slowly converging tile keeps its converged lanes
     StrideK sk[4];
     const double *wtab;   // [4][kWtabStride] quadrature matrices of the four tile kinds
     mp_model_cfg cfg;
@@ -98,6 +98,7 @@ struct LaunchArgs {
     int32_t *status;        // [n] or nullptr
     int32_t *sweeps;        // [n] or nullptr: total Newton sweeps over all tiles
     int32_t *tiles;         // [n] or nullptr: tiles solved (kept or not)
+    int32_t *tile_log;      // diagnostics, or nullptr: [n][MP_TILE_LOG] one word per tile solved: kind | sweeps << 4 | kept lanes << 16
     double *ltot;           // [n][n_grid] or nullptr   (1e50 erg/s)
     double *lprop;          // [n][n_grid] or nullptr
     double *ldip;           // [n][n_grid] or nullptr

@@ -407,6 +407,8 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
         int pos8 = 0, kind = 1;
         bool rec_valid = false;                  // the image holds a kept tile (the history of the next one)
         int rec_kind = 0, rec_d8 = 1, rec_J = 0; // its kind, its step in eighths and the number of steps kept
+        int cool = 0;                            // tiles over single intervals for which the scaled indicator decides about coarsening
+        int cool4 = 0;                           // tiles over 2 intervals that stay at 2 after the sweeps of a stride-4 tile were slow
         // Each lane owns kSPL consecutive steps of the tile: steps lane*kSPL + s, s = 0..kSPL-1.
         while (pos8 < end8) {
             const bool pre = pos8 < pre_end8;
@@ -552,7 +554,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
             // omega_dot at the new point is its linearisation about the previous one, f + lambda*(omega_new - omega_old),
             // exact to the second order in that correction.  Such a sweep is the cheap verification pass of a tile whose
             // first guess was good.
-            Vd<kSPL> lam, ez, n0, n1, n2, n3, n4;
+            Vd<kSPL> lam, ez, p5, n0, n1, n2, n3, n4;
             EamW5<kSPL> cw;
             bool light = false, ultra = false, early_stop = false;
             // (a step over 2 or 4 grid intervals weighs an error of omega_dot 2 or 4 times as much: tighter sweeps there)
@@ -623,6 +625,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                     for (int s = 0; s < kSPL; ++s) zw[s] = h[s] * lam[s];
                     const Phi5<kSPL> pw_ = phi12345(zw);
                     ez = pw_.e;
+                    p5 = pw_.p5;
                     cw = eam5_node_weights(wbase, pw_);
                 }
                 const Vd<kSPL> inc = eam5_increment_nodes(cw, h, n0, n1, n2, n3, n4);
@@ -664,11 +667,11 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 // correction just below the tolerance leaves an error of the same size)
                 pending_tight = __ballot(!(dsum <= 0.01 * tol_k * mag));
                 if (pending == 0ull || flagged != 0ull || sweep >= kMaxSweeps) break;
-                if (kind >= 2 && sweep >= kCoarseMaxSweeps) break;   // not worth it at this stride (the rest is redone finer)
+                if (kind >= 2 && sweep >= sh.coarse_max_sweeps) break;   // not worth it at this stride (the rest is redone finer)
                 // Slow sweeps on single intervals (a poor extrapolated guess through a fast spin-up, far from the break-up
                 // limit): the lanes that have converged are final (a step depends on earlier ones only); they are kept
                 // and a new tile starts behind them with a fresh extrapolation, instead of sweeping on over all 64 lanes.
-                if (kind <= 1 && sweep >= kFineMaxSweeps && over_sweeps == 0 && __ffsll(pending_tight) - 1 >= 2 * kMinKeepLanes) {
+                if (kind <= 1 && sweep >= sh.fine_max_sweeps && over_sweeps == 0 && __ffsll(pending_tight) - 1 >= 2 * kMinKeepLanes) {
                     early_stop = true;
                     break;
                 }
@@ -704,9 +707,9 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
 
             // ---------------- what is kept, and the stride of the next tile (oracle/mp_oracle.c mpo_trajectory_mode).
             // Per lane: does the solution leave the smooth branch of the right-hand side the tile started on; and the
-            // smoothness indicator h |4th difference of (f - lambda omega)| / omega against stride_tol, and against
+            // smoothness indicator 120 |phi_5(h lambda)| h |4th difference of (f - lambda omega)| / omega against stride_tol, and against
             // stride_tol / 64 and / 2048 (what it would be at twice / four times the step: 5th-order scaling, margin 2).
-            int keep_lanes = 64, next_kind = kind;
+            int keep_lanes = 64, next_kind = kind, why = 0;   // why: diagnostics (tile log)
             // (the tile tried at a coarse stride right behind the sub-steps has no calm predecessor to vouch for it: a tenth)
             const double tile_tol = (kind >= 2 && rec_kind == 0) ? 0.1 * sh.stride_tol : sh.stride_tol;
             {
@@ -715,7 +718,9 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 for (int s = 0; s < kSPL; ++s) {
                     const bool valid = lane * kSPL + s < nc;
                     brk = brk || (valid && branch_flags(w, d1.rmu[s], wg[s]) != flags_s);
-                    const double d4 = h[s] * fabs((n0[s] + n4[s]) - 4.0 * (n1[s] + n3[s]) + 6.0 * n2[s]);
+                    // (the formula's error term: h phi_5(h lambda) x the 4th difference; 120 phi_5 = 1 at 0, -> 5/|h lambda| where
+                    // the equation is stiff and the exponential integrator tracks the spin equilibrium)
+                    const double d4 = 120.0 * fabs(p5[s]) * h[s] * fabs((n0[s] + n4[s]) - 4.0 * (n1[s] + n3[s]) + 6.0 * n2[s]);
                     const double lim = tile_tol * wg[s];
                     ind1 = ind1 || d4 > lim;
                     ind64 = ind64 || 64.0 * d4 > lim;
@@ -723,22 +728,38 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 }
                 const unsigned long long B = __ballot(brk), I1 = __ballot(ind1), I64 = __ballot(ind64), I2048 = __ballot(ind2048);
                 const int full_lanes = (nc + kSPL - 1) / kSPL;                 // lanes that hold steps of this tile
+                why = (B != 0ull ? 1 : 0) | (I1 != 0ull ? 2 : 0) | (I64 != 0ull ? 4 : 0) | (I2048 != 0ull ? 8 : 0) | (unconv != 0ull ? 16 : 0);
                 if (kind >= 2) {
                     const unsigned long long bad = B | I1 | unconv;
                     const int first = bad ? __ffsll(bad) - 1 : 64;
                     if (first < full_lanes) {
-                        if (first < kMinKeepLanes) { kind = 1; continue; }     // nothing worth keeping: redo at stride 1
+                        if (first < 2 * kMinKeepLanes) cool = 3;                // a coarse attempt that failed early
+                        if (first < kMinKeepLanes) {                            // nothing worth keeping: redo at stride 1
+                            if (a.tile_log && lane == 0 && tiles_total <= MP_TILE_LOG)
+                                a.tile_log[(size_t)walker * MP_TILE_LOG + tiles_total - 1] = kind | (sweep << 4);
+                            kind = 1;
+                            continue;
+                        }
                         keep_lanes = first;
                         // a kink or a fast feature gets single intervals; slow sweeps alone, the next finer stride
                         next_kind = (((B | I1) >> first) & 1ull) ? 1 : kind - 1;
+                        if (next_kind == 2) cool4 = 3;                         // slow sweeps at stride 4: stay at 2 for a few tiles
                     } else if (kind == 2 && nc == kTile) {
-                        next_kind = I64 == 0ull ? 3 : 2;
+                        if (cool4 > 0) --cool4;
+                        else next_kind = I64 == 0ull ? 3 : 2;
                     }
                 } else if (unconv != 0ull) {                                    // kinds 0, 1 stopped early: the converged lanes
                     keep_lanes = __ffsll(unconv) - 1;
                     if (pre) keep_lanes &= ~(8 / kSPL - 1);                    // (whole grid intervals of sub-steps)
                 } else if (kind == 1 && nc == kTile) {
-                    if (B == 0ull) next_kind = I2048 == 0ull ? 3 : (I64 == 0ull ? 2 : 1);
+                    // No kink in this tile: the scaled indicator decides while a recent coarse attempt has failed early
+                    // (cool > 0); otherwise the coarse stride is simply tried (a tile is cut where it does not hold): the
+                    // indicator of a tile whose sweeps stopped at the tolerance carries their residual, amplified by the 4th
+                    // difference, and kept stiff late-time stretches at single intervals for a dozen tiles.
+                    if (B == 0ull) {
+                        if (cool > 0) { --cool; next_kind = I2048 == 0ull ? 3 : (I64 == 0ull ? 2 : 1); }
+                        else next_kind = I1 == 0ull ? 3 : 1;
+                    }
                     else {
                         // a kink inside this tile: the history of a coarse successor must lie behind it
                         const int first_clean = __ffsll(B) - 1 + 2;            // lanes from here on are past the kink
@@ -752,6 +773,8 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 next_kind = min(next_kind, max_kind);
             }
             const int keep = min(keep_lanes * kSPL, nc);                       // steps kept
+            if (a.tile_log && lane == 0 && tiles_total <= MP_TILE_LOG)
+                a.tile_log[(size_t)walker * MP_TILE_LOG + tiles_total - 1] = kind | (sweep << 4) | (keep_lanes << 16) | (why << 24);
             const int end_kept8 = pos8 + keep * d8;
 
             // ---------------- commit: the tile's image goes to LDS (record for the next tile's history, source of the

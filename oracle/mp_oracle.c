@@ -379,8 +379,8 @@ static int branch_flags(const mpo_cfg *c, const wk *w, double Mdisc, double omeg
  *   - mode 0 (FIXED): every later tile steps over single grid intervals;
  *   - mode 1 (ADAPTIVE, the product default): tiles step over 1, 2 or 4 grid intervals.  A tile at stride > 1 is kept only up
  *     to the first lane in which (a) the solution changes the smooth branch of the right-hand side (Alfven-radius cap, torque
- *     arm: a kink no multistep formula can cross at a coarse step) or (b) the smoothness indicator h |4th difference of
- *     (f - lam omega)| / omega exceeds stride_tol; what follows is redone at stride 1.  Values at skipped grid points come
+ *     arm: a kink no multistep formula can cross at a coarse step) or (b) the smoothness indicator
+ *     120 |phi_5(h lam)| h |4th difference of (f - lam omega)| / omega (the formula's own error term) exceeds stride_tol; what follows is redone at stride 1.  Values at skipped grid points come
  *     from Hermite interpolants over the step: cubic in (omega, f), quintic in (Mdisc, dMdisc/dt, d2Mdisc/dt2).
  * History for a tile whose step differs from its predecessor's: the same Hermite interpolant on the predecessor's steps
  * (exact where the points coincide).  Start-up: Mdotfb is analytic (grid continued backwards); the missing (f, omega)
@@ -443,6 +443,7 @@ int mpo_trajectory_mode(const mpo_cfg *c, const double *pars, int ndim, const do
     int sub_done = 0;    /* sub-steps of the pre-phase done */
     int s = 1;           /* stride of the next grid tile */
     int last_was_pre = 0;
+    int cool = 0;        /* tiles over single intervals for which the scaled indicator decides about coarsening */
     while (status == MPO_OK && i0 < nsteps) {
         const int pre = i0 < pre_fine;
         const int after_pre = !pre && last_was_pre;
@@ -514,7 +515,10 @@ int mpo_trajectory_mode(const mpo_cfg *c, const double *pars, int ndim, const do
             if (!(isfinite(M1) && isfinite(wn)) || M1 <= 0.0 || wn <= 0.0) { tstatus = MPO_NONFINITE; break; }
             if ((0.5 * w.I * wn * wn) / w.modW > 0.27) { tstatus = MPO_FLAG; break; }
             brk[J] = branch_flags(c, &w, M1, wn) != flags0;
-            ind[J] = (startup && J < P - 2) ? 0.0 : h * fabs(Nv[0] - 4.0 * Nv[1] + 6.0 * Nv[2] - 4.0 * Nv[3] + Nv[4]) / fabs(wn);
+            /* the formula's error term is h phi_5(h lam) x the 4th difference of the node values: phi_5(0) = 1/120, and
+               -> 1/(24 |h lam|) where the equation is stiff and the exponential integrator tracks the spin equilibrium */
+            ind[J] = (startup && J < P - 2) ? 0.0
+                                            : 120.0 * fabs(ph[4]) * h * fabs(Nv[0] - 4.0 * Nv[1] + 6.0 * Nv[2] - 4.0 * Nv[3] + Nv[4]) / fabs(wn);
             tn[J] = (mpo_node){tJ1, M1, S1 - M1 / w.tvisc, mdot_fb_dt(&w, tJ1) - (S1 - M1 / w.tvisc) / w.tvisc, wn, fnew};
             if (startup && J == 0) { f1 = fnew; w1 = wn; }
             Sh[3] = Sh[2]; Sh[2] = Sh[1]; Sh[1] = Sh[0]; Sh[0] = S1;
@@ -539,6 +543,7 @@ int mpo_trajectory_mode(const mpo_cfg *c, const double *pars, int ndim, const do
             if (first * spl >= nc) first = 64;
             if (first < 64) {
                 ++st_.tiles_cut;
+                if (first < 2 * MPO_MIN_KEEP) cool = 3;                      /* a coarse attempt that failed early */
                 if (first < MPO_MIN_KEEP) { s = 1; continue; }               /* nothing worth keeping: redo at stride 1 */
                 keep = first * spl;
                 next_s = 1;                                                  /* the offending region gets single intervals */
@@ -550,7 +555,13 @@ int mpo_trajectory_mode(const mpo_cfg *c, const double *pars, int ndim, const do
             int lastbrk = -1;
             for (int e = 0; e < keep; ++e) { if (ind[e] > imax) imax = ind[e]; if (brk[e] && lastbrk < 0) lastbrk = e / spl; }
             if (s == 1) {
-                if (lastbrk < 0) next_s = (imax * 2048.0 < stride_tol) ? 4 : (imax * 64.0 < stride_tol) ? 2 : 1;
+                /* no kink in this tile: the scaled indicator decides while a recent coarse attempt has failed (cool > 0);
+                   otherwise the coarse stride is simply tried (the tile is cut where it does not hold): the indicator of
+                   a tile whose sweeps stopped at the tolerance carries their residual, amplified by the 4th difference */
+                if (lastbrk < 0) {
+                    if (cool > 0) { --cool; next_s = (imax * 2048.0 < stride_tol) ? 4 : (imax * 64.0 < stride_tol) ? 2 : 1; }
+                    else next_s = (imax > stride_tol) ? 1 : 4;
+                }
                 else {
                     /* a kink inside this tile: the history of a coarse successor must lie behind it */
                     const int first_clean = (lastbrk + 2) * spl, tail = keep - first_clean;   /* steps after the kink lane + 1 */
