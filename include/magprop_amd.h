@@ -94,22 +94,22 @@ typedef struct mp_model_cfg {
     double f_beam;             /* default beaming fraction     (overridden per walker when ndim is 7 or 9)              */
     double nacc_lum_threshold; /* luminosity-stage break-up test: 0.27 (synth funcs.py:206) | 0.0 (magnetar/funcs.py:193) */
     int32_t lprop_gm_term;     /* 1: Lprop includes -(GM/Rm)*eta2*Mdisc/tvisc (synth funcs.py:222-223); 0: lib          */
-    int32_t max_stride;        /* grid intervals a step of the solver may span: 0 = MP_MAX_STRIDE_DEFAULT (4), or 1, 2, 4.   */
+    int32_t max_stride;        /* grid intervals a step of the solver may span: 0 = MP_MAX_STRIDE_DEFAULT (8), or 1, 2, 4, 8. */
                                /* 1 = every grid interval is a step (the serial restatement oracle/mp_oracle.c mode 0)       */
     double sweep_tol;          /* relative change of omega at the step ends that ends the Newton sweeps of a tile of the   */
                                /* time-parallel solver; 0 = MP_SWEEP_TOL_DEFAULT.  What it buys and costs: DESIGN.md 3     */
     double stride_tol;         /* smoothness indicator h |4th difference of (f - lambda omega)| / omega above which a tile   */
-                               /* stepping over 2 or 4 grid intervals is cut back to single intervals; 0 =                   */
+                               /* stepping over 2, 4 or 8 grid intervals is cut back to single intervals; 0 =                */
                                /* MP_STRIDE_TOL_DEFAULT                                                                      */
 } mp_model_cfg;
 
 /* Stride adaptivity of the solver: where the solution is smooth on the scale of the output grid the
- * order-5 formula steps over 2 or 4 grid intervals at once and the states at the skipped grid points come from the cubic
+ * order-5 formula steps over 2, 4 or 8 grid intervals at once and the states at the skipped grid points come from the cubic
  * Hermite interpolant of the step (<= 1e-11 relative); tiles that contain a kink of the right-hand side (Alfven-radius
  * cap, torque arm) or a fast transient are redone over single intervals.  Measured on the 6 256 golden prior-wide points:
  * same maximum deviation from the reference's tight-integrator values as with max_stride = 1 (5e-8), 13 instead of 40
  * tiles per walker. */
-#define MP_MAX_STRIDE_DEFAULT 4
+#define MP_MAX_STRIDE_DEFAULT 8
 #define MP_STRIDE_TOL_DEFAULT 1.0e-7
 
 /* The sweeps contract by 1e-2..1e-3 per pass, so a tile whose last correction was <= 1e-7 relative is converged to

@@ -181,7 +181,7 @@ def check(rc, what):
 SWEEP_TOL_DEFAULT, SWEEP_TOL_STRICT = 1.0e-7, 1.0e-9   # include/magprop_amd.h MP_SWEEP_TOL_*
 DEFAULT_SWEEP_TOL = 0.0   # what cfg_synth()/cfg_lib() put into mp_model_cfg.sweep_tol (0 = the library default); the test
                           # suite sets SWEEP_TOL_STRICT here for its kernel-vs-serial-restatement comparisons
-DEFAULT_MAX_STRIDE = 0    # likewise mp_model_cfg.max_stride (0 = the library default, adaptive up to 4 grid intervals per
+DEFAULT_MAX_STRIDE = 0    # likewise mp_model_cfg.max_stride (0 = the library default, adaptive up to 8 grid intervals per
                           # step); the strict test mode sets 1: every grid interval a step, the scheme of the serial restatement
 
 
@@ -343,12 +343,13 @@ class Handle:
 
     def last_tile_log(self, walker):
         """[(kind, sweeps, lanes kept, why), ...] of `walker` in the most recent host-buffer batch (tile_log() on): kind 0 =
-        1/8-interval sub-steps, 1 / 2 / 3 = steps over 1 / 2 / 4 grid intervals; 0 lanes kept = the tile was redone; why =
-        bits: 1 a branch of the right-hand side changed inside the tile, 2 / 4 / 8 the smoothness indicator exceeded
-        stride_tol / its 64th / its 2048th somewhere, 16 lanes had not converged when the sweeps were stopped."""
+        1/8-interval sub-steps, 1 .. 4 = steps over 1 / 2 / 4 / 8 grid intervals; 0 lanes kept = the tile was redone; why =
+        bits: 1 a branch of the right-hand side changed inside the tile, 2 / 4 / 8 / 32 the smoothness indicator exceeded
+        stride_tol / its 64th / its 2048th / its 65536th somewhere, 16 lanes had not converged when the sweeps were
+        stopped, 64 the tile was given up after its second sweep."""
         buf = np.zeros(96, dtype=np.int32)
         m = self._L.mp_last_tile_log(self._h, int(walker), _iptr(buf), 96)
-        return [(int(w) & 15, (int(w) >> 4) & 0xFFF, (int(w) >> 16) & 0xFF, (int(w) >> 24) & 0x1F) for w in buf[:max(m, 0)]]
+        return [(int(w) & 15, (int(w) >> 4) & 0xFFF, (int(w) >> 16) & 0xFF, (int(w) >> 24) & 0xFF) for w in buf[:max(m, 0)]]
 
     @property
     def sweep_tol(self):

@@ -288,8 +288,9 @@ mp_handle *mp_create(const mp_model_cfg *cfg, const double *tgrid, int n_grid, i
         return nullptr;
     }
     if (!(cfg->stride_tol >= 0.0) || cfg->stride_tol > 1.0e-3 ||
-        !(cfg->max_stride == 0 || cfg->max_stride == 1 || cfg->max_stride == 2 || cfg->max_stride == 4)) {
-        fail(MP_EINVAL, "mp_create: cfg.max_stride must be 0, 1, 2 or 4 and cfg.stride_tol 0 or in (0, 1e-3]");
+        !(cfg->max_stride == 0 || cfg->max_stride == 1 || cfg->max_stride == 2 || cfg->max_stride == 4 ||
+          cfg->max_stride == 8)) {
+        fail(MP_EINVAL, "mp_create: cfg.max_stride must be 0, 1, 2, 4 or 8 and cfg.stride_tol 0 or in (0, 1e-3]");
         return nullptr;
     }
     int count = 0;
@@ -351,9 +352,9 @@ mp_handle *mp_create(const mp_model_cfg *cfg, const double *tgrid, int n_grid, i
         int ms = cfg->max_stride > 0 ? cfg->max_stride : MP_MAX_STRIDE_DEFAULT;
         if (const char *e = std::getenv("MAGPROP_AMD_MAX_STRIDE")) {   // experiments only
             const int v = std::atoi(e);
-            if (v == 1 || v == 2 || v == 4) ms = v;
+            if (v == 1 || v == 2 || v == 4 || v == 8) ms = v;
         }
-        s.max_kind = ms == 1 ? 1 : (ms == 2 ? 2 : 3);
+        s.max_kind = ms == 1 ? 1 : (ms == 2 ? 2 : (ms == 4 ? 3 : 4));
     }
     s.n_simd = std::max(1, prop.multiProcessorCount) * 4;         // 4 SIMDs per CU (1 024 on MI355X)
     s.force_spl = 0;
@@ -370,6 +371,8 @@ mp_handle *mp_create(const mp_model_cfg *cfg, const double *tgrid, int n_grid, i
         if (v > 0.0 && v < 1.0e-3) s.stride_tol = v;
     }
     s.coarse_max_sweeps = 5;
+    s.trouble_limit = 2;
+    if (const char *e = std::getenv("MAGPROP_AMD_TROUBLE_LIMIT")) { const int v = std::atoi(e); if (v >= 0 && v <= 1000) s.trouble_limit = v; }   // experiments only
     s.fine_max_sweeps = 8;
     if (const char *e = std::getenv("MAGPROP_AMD_COARSE_MAX_SWEEPS")) { const int v = std::atoi(e); if (v >= 2 && v <= 64) s.coarse_max_sweeps = v; }   // experiments only
     if (const char *e = std::getenv("MAGPROP_AMD_FINE_MAX_SWEEPS")) { const int v = std::atoi(e); if (v >= 2 && v <= 272) s.fine_max_sweeps = v; }
@@ -383,12 +386,17 @@ mp_handle *mp_create(const mp_model_cfg *cfg, const double *tgrid, int n_grid, i
         const double v = std::atof(e);
         if (v >= 0.0 && v <= 1.0) s.coarse_ultra_factor = v;
     }
+    s.k4_tol_factor = 0.1;
+    if (const char *e = std::getenv("MAGPROP_AMD_K4_TOL_FACTOR")) {   // experiments only
+        const double v = std::atof(e);
+        if (v > 0.0 && v <= 1.0) s.k4_tol_factor = v;
+    }
     s.ultra_tol = std::min(1.0e-5, 100.0 * s.sweep_tol);
     if (const char *e = std::getenv("MAGPROP_AMD_ULTRA_TOL")) {   // experiments only (0 disables); kept inside [0, 1e-4]
         const double v = std::atof(e);
         if (v >= 0.0 && v <= 1.0e-4) s.ultra_tol = v;
     }
-    // Constants of the four tile kinds: steps over 1/8, 1, 2, 4 grid intervals (mp_device.h StrideK).
+    // Constants of the tile kinds: steps over 1/8, 1, 2, 4, 8 grid intervals (mp_device.h StrideK).
     // Quadrature matrices of the exponential Adams-Moulton formulas on nodes t_{j+1}, t_j, t_{j-1}, ... of a geometric
     // grid of ratio Q (in units of the step, origin t_j: 1, 0, -1/Q, -(1/Q + 1/Q^2), ...):
     // W[k][m] = m! * [theta^m] l_k(theta), l_k the Lagrange basis on the nodes.
@@ -411,30 +419,41 @@ mp_handle *mp_create(const mp_model_cfg *cfg, const double *tgrid, int n_grid, i
             for (int m = 0; m < K; ++m) { if (m > 1) fact *= (double)m; W[k * K + m] = fact * co[m] / denom; }
         }
     };
-    std::vector<double> wtab(4 * (size_t)mp::kWtabStride, 0.0);
-    for (int kind = 0; kind < 4; ++kind) {
+    std::vector<double> wtab((size_t)mp::kWtabSize, 0.0);
+    for (int kind = 0; kind < mp::kKinds; ++kind) {
         mp::StrideK &K = s.sk[kind];
         const double lnQ = kind == 0 ? lnq / 8.0 : lnq * (double)(1 << (kind - 1));
         K.lnQ = lnQ;
         K.inv_Q = std::exp(-lnQ);
         K.one_m_invQ = -std::expm1(-lnQ);
         const int ns = kind == 0 ? 1 : (1 << (kind - 1));
-        for (int i = 0; i < 4; ++i) {
-            const double th = (i < ns && ns > 1) ? std::expm1(lnq * (double)i) / std::expm1(lnQ) : 0.0;
-            const double t2 = th * th, t3 = t2 * th, t4 = t3 * th, t5 = t4 * th;
-            K.theta[i] = th;
-            K.hq[i][0] = 1.0 - 10.0 * t3 + 15.0 * t4 - 6.0 * t5;
-            K.hq[i][1] = th - 6.0 * t3 + 8.0 * t4 - 3.0 * t5;
-            K.hq[i][2] = 0.5 * t2 - 1.5 * t3 + 1.5 * t4 - 0.5 * t5;
-            K.hq[i][3] = 10.0 * t3 - 15.0 * t4 + 6.0 * t5;
-            K.hq[i][4] = -4.0 * t3 + 7.0 * t4 - 3.0 * t5;
-            K.hq[i][5] = 0.5 * t3 - t4 + 0.5 * t5;
-        }
+        double *T = wtab.data() + (size_t)kind * mp::kWtabStride;
+        for (int i = 0; i < 8; ++i)
+            T[mp::kWtabTheta + i] = (i < ns && ns > 1) ? std::expm1(lnq * (double)i) / std::expm1(lnQ) : 0.0;
         double W5[25];
         quad_weights(std::exp(lnQ), 5, W5);
-        double *T = wtab.data() + (size_t)kind * mp::kWtabStride;
         for (int k = 0; k < 5; ++k)
             for (int m = 0; m < 5; ++m) T[6 * k + m] = W5[k * 5 + m];
+        // dense output of Mdisc where the step is longer than tvisc (mp_device.h kWtabDense): cubic Lagrange weights at the
+        // skipped grid points, the step being the first / middle / last interval of its four nodes (times in units of the
+        // step, origin at its start; consecutive steps grow by Q)
+        if (kind >= 2) {
+            const double Q = std::exp(lnQ);
+            const double nodes[3][4] = {{0.0, 1.0, 1.0 + Q, 1.0 + Q + Q * Q},
+                                        {-1.0 / Q, 0.0, 1.0, 1.0 + Q},
+                                        {-1.0 / Q - 1.0 / (Q * Q), -1.0 / Q, 0.0, 1.0}};
+            for (int i = 1; i < ns; ++i) {
+                const double th = T[mp::kWtabTheta + i];
+                double *D = wtab.data() + mp::kWtabDense + ((kind - 2) * 7 + (i - 1)) * 12;
+                for (int v = 0; v < 3; ++v)
+                    for (int k = 0; k < 4; ++k) {
+                        double l = 1.0;
+                        for (int m = 0; m < 4; ++m)
+                            if (m != k) l *= (th - nodes[v][m]) / (nodes[v][k] - nodes[v][m]);
+                        D[v * 4 + k] = l;
+                    }
+            }
+        }
     }
     if (h->d_wtab.ensure(wtab.size()) != MP_OK ||
         hipMemcpy(h->d_wtab.p, wtab.data(), wtab.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {

@@ -25,23 +25,30 @@ struct DsDesc {
 };
 
 // What a tile of the time-parallel solver needs to know about its step: tiles step over 1/8 of a grid interval (kind 0,
-// the first intervals), 1, 2 or 4 intervals (kinds 1, 2, 3).  The grid is geometric, so the ratio Q of consecutive step
+// the first intervals), 1, 2, 4 or 8 intervals (kinds 1 .. 4).  The grid is geometric, so the ratio Q of consecutive step
 // end times, the quadrature matrices of the exponential Adams-Moulton formulas and the positions of the skipped grid
 // points inside a step are constants of the kind (host-computed, oracle/mp_oracle.c mpo_eam_weights).
+constexpr int kKinds = 5;
 struct StrideK {
     double lnQ;          // ln of the ratio of consecutive step end times
     double inv_Q;        // 1/Q
     double one_m_invQ;   // 1 - 1/Q: step length = (step end time) * this
-    double theta[4];     // time fraction of grid point i (i = 1..3) inside a step of kinds 2 and 3: (q^i - 1)/(Q - 1)
-    double hq[4][6];     // quintic Hermite basis at theta[i]: weights of y0, h y0', h^2 y0'', y1, h y1', h^2 y1'' (Mdisc)
 };
 
-// The quadrature matrices of the four kinds live in a device table (DevShared::wtab) that every workgroup copies into LDS
-// once: per kind kWtabStride doubles,
+// The other constants of the kinds live in a device table (DevShared::wtab) that every workgroup copies into LDS once:
+// per kind kWtabStride doubles,
 //   [6 k + m]      W5[k][m], k, m = 0..4: order-5 quadrature on nodes t_{j+1} .. t_{j-3}; rows padded to 6
+//   [32 + i]       theta_i, i = 1..7: time fraction of the i-th skipped grid point inside a step, (q^i - 1)/(Q - 1)
 // (25 wave-uniform doubles per kind do not fit the scalar registers next to the walker constants; from LDS they are read
 // where they are used, two per broadcast ds_read_b128).
-constexpr int kWtabStride = 32;
+constexpr int kWtabStride = 40;
+constexpr int kWtabTheta = 32;
+// behind the kinds' blocks: the dense-output weights of Mdisc where the step is longer than the viscous time (cubic Lagrange
+// interpolation of Mdisc / (tvisc Mdotfb) through four nodes), [((kind - 2) * 7 + (i - 1)) * 12 + variant * 4 + k]:
+// kinds 2 .. 4, skipped grid point i = 1 .. 7, variant = position of the step among the three intervals of its four nodes
+// (0: the first, the step is the first of the tile's kept part; 1: the middle; 2: the last), k = node
+constexpr int kWtabDense = kKinds * kWtabStride;
+constexpr int kWtabSize = kWtabDense + 3 * 7 * 12;
 
 // Everything the kernel reads that is shared by all walkers (resident in HBM, L2-hot).
 struct DevShared {
@@ -75,14 +82,15 @@ struct DevShared {
     double sweep_tol;     // relative change of the step-end values that ends the Newton sweeps of a tile
     double ultra_tol;     // corrections below this let the next sweep linearise omega_dot instead of evaluating it
     double stride_tol;    // smoothness indicator above which a tile at a coarse stride is cut (cfg.stride_tol)
-    double coarse_tol_factor;   // sweep tolerance of tiles over 2 or 4 grid intervals, relative to sweep_tol
+    double coarse_tol_factor;   // sweep tolerance of tiles over 2, 4 or 8 grid intervals, relative to sweep_tol
     double coarse_ultra_factor; // the same for ultra_tol
+    double k4_tol_factor;       // stride_tol of tiles over 8 grid intervals, relative to stride_tol (0.1; oracle/mp_oracle.c)
     int32_t n_simd;       // SIMDs of the device (multiProcessorCount x 4): batch sizes up to this get one wave per SIMD
     int32_t force_spl;    // experiments: 0 = automatic, else steps per lane (2, 4)
-    int32_t max_kind;     // coarsest tile kind allowed: 1, 2, 3 for cfg.max_stride 1, 2, 4
-    int32_t coarse_max_sweeps, fine_max_sweeps, pad1;   // sweeps after which a slowly converging tile keeps its converged lanes
-    StrideK sk[4];
-    const double *wtab;   // [4][kWtabStride] quadrature matrices of the four tile kinds
+    int32_t max_kind;     // coarsest tile kind allowed: 1, 2, 3, 4 for cfg.max_stride 1, 2, 4, 8
+    int32_t coarse_max_sweeps, fine_max_sweeps, trouble_limit;   // sweeps after which a slowly converging tile keeps its converged lanes
+    StrideK sk[kKinds];
+    const double *wtab;   // [kWtabSize] quadrature matrices, skipped-point positions and dense-output weights of the tile kinds
     mp_model_cfg cfg;
 };
 

@@ -59,9 +59,9 @@ MP_DEV Vd<N> mdot_fb(const Walker &w, const Vd<N> &t) {
     return out;
 }
 
-// the same with its time derivative dMdotfb/dt = -(5/3) Mdotfb / (t + tfb)
+// the same with its time derivative dMdotfb/dt = -(5/3) Mdotfb / (t + tfb) and iu = tfb / (t + tfb)
 template <int N>
-MP_DEV Vd<N> mdot_fb_d(const Walker &w, const Vd<N> &t, Vd<N> &dS) {
+MP_DEV Vd<N> mdot_fb_d(const Walker &w, const Vd<N> &t, Vd<N> &dS, Vd<N> &iu) {
     Vd<N> u;
     FORN u[i] = fma(t[i], w.inv_tfb, 1.0);
     const Vd<N> r = rcbrt_fast(u);
@@ -69,7 +69,8 @@ MP_DEV Vd<N> mdot_fb_d(const Walker &w, const Vd<N> &t, Vd<N> &dS) {
     FORN {
         const double r2 = r[i] * r[i], r3 = r2 * r[i];
         out[i] = w.S_amp * (r2 * r3);
-        dS[i] = (-5.0 / 3.0) * w.inv_tfb * out[i] * r3;             // 1/u = r^3
+        iu[i] = r3;                                                  // 1/u = r^3
+        dS[i] = (-5.0 / 3.0) * w.inv_tfb * out[i] * r3;
     }
     return out;
 }
@@ -248,43 +249,54 @@ MP_DEV double hermite_d(double th, double h, double y0, double d0, double y1, do
     const double D = y1 - y0;
     return (h * d0 + th * (2.0 * (3.0 * D - h * (2.0 * d0 + d1)) + th * 3.0 * (h * (d0 + d1) - 2.0 * D))) / h;
 }
-// quintic Hermite (values, first and second derivatives at both ends) with the basis values b[6] of its theta: Mdisc, whose
-// derivatives are analytic (dM/dt = Mdotfb - M/tvisc), passes through a transition a few tvisc after the start where the
-// cubic is 1e-9 off at a stride of four grid intervals
-MP_DEV double hermite5(const double (&b)[6], double h, double y0, double d0, double e0, double y1, double d1, double e1) {
-    const double h2 = h * h;
-    return fma(b[0], y0, fma(b[3], y1, h * fma(b[1], d0, b[4] * d1) + h2 * fma(b[2], e0, b[5] * e1)));
+// quintic Hermite (values, first and second derivatives at both ends): Mdisc, whose derivatives are analytic
+// (dM/dt = Mdotfb - M/tvisc), passes through a transition a few tvisc after the start where the cubic is 1e-9 off at a
+// stride of four grid intervals
+MP_DEV double hermite5(double th, double h, double y0, double d0, double e0, double y1, double d1, double e1) {
+    const double t2 = th * th, t3 = t2 * th;
+    const double s = t3 * fma(th, fma(th, 6.0, -15.0), 10.0);          // 10 t^3 - 15 t^4 + 6 t^5
+    const double b1 = fma(t3, fma(th, fma(th, -3.0, 8.0), -6.0), th);  // t - 6 t^3 + 8 t^4 - 3 t^5
+    const double b4 = t3 * fma(th, fma(th, -3.0, 7.0), -4.0);          // -4 t^3 + 7 t^4 - 3 t^5
+    const double b2 = 0.5 * t2 * fma(th, fma(th, fma(th, -1.0, 3.0), -3.0), 1.0);   // (t^2 - 3 t^3 + 3 t^4 - t^5)/2
+    const double b5 = 0.5 * t3 * fma(th, fma(th, 1.0, -2.0), 1.0);     // (t^3 - 2 t^4 + t^5)/2
+    return fma(s, y1 - y0, y0) + h * fma(b1, d0, b4 * d1) + (h * h) * fma(b2, e0, b5 * e1);
 }
 // Mdisc inside a step: the quintic while the step resolves the viscous time (z = h/tvisc < 1); beyond, Mdisc follows the
 // fallback rate quasi-steadily, a power law the cubic represents to 2e-10, and its derivatives, formed as differences of
 // nearly equal terms, carry the rounding of Mdisc amplified by z (z^2 for the second): the cubic then
-MP_DEV double hermite_mdisc(const StrideK &K, int i, double h, double z, double y0, double d0, double e0, double y1, double d1,
-                            double e1) {
-    return z < 1.0 ? hermite5(K.hq[i], h, y0, d0, e0, y1, d1, e1) : hermite(K.theta[i], h, y0, d0, y1, d1);
+MP_DEV double hermite_mdisc(double th, double h, double z, double y0, double d0, double e0, double y1, double d1, double e1) {
+    return z < 1.0 ? hermite5(th, h, y0, d0, e0, y1, d1, e1) : hermite(th, h, y0, d0, y1, d1);
 }
 
-// Q^k of the four tile kinds, k = 0 .. 64*SPL: the step end times of a tile are t_s Q^k (the grid is geometric).  Filled once
-// per kernel (every lane computes its own entries), read by every tile.
+// Q^k of the tile kinds 1 .. 4, k = 0 .. 64*SPL: the step end times of a tile are t_s Q^k (the grid is geometric).  Filled
+// once per kernel (every lane computes its own entries), read by every tile.  (The sub-stepped tiles at the start, kind 0,
+// compute theirs: there are one or two of them.)
 template <int SPL>
 struct TimeTable {
     static constexpr int kN = 64 * SPL + 1;
-    double E[4][kN];
+    double E[kKinds - 1][kN];
 };
 
 template <int SPL>
 MP_DEV void time_table_init(const DevShared &sh, TimeTable<SPL> &tt) {   // every thread of the (one-wavefront) workgroup calls this
     const int lane = threadIdx.x & 63;
 #pragma unroll
-    for (int kind = 0; kind < 4; ++kind) {
+    for (int kind = 1; kind < kKinds; ++kind) {
         Vd<SPL> ek;
 #pragma unroll
         for (int s = 0; s < SPL; ++s) ek[s] = (double)(lane * SPL + s + 1) * sh.sk[kind].lnQ;
         const Vd<SPL> E = exp_fast(ek);
 #pragma unroll
-        for (int s = 0; s < SPL; ++s) tt.E[kind][lane * SPL + s + 1] = E[s];
-        if (lane == 0) tt.E[kind][0] = 1.0;
+        for (int s = 0; s < SPL; ++s) tt.E[kind - 1][lane * SPL + s + 1] = E[s];
+        if (lane == 0) tt.E[kind - 1][0] = 1.0;
     }
     __syncthreads();
+}
+// Q^k of kind `kind` (wave-uniform or per-lane k)
+template <int SPL>
+MP_DEV double time_factor(const DevShared &sh, const TimeTable<SPL> &tt, int kind, int k) {
+    if (kind == 0) { const Vd<1> e{{(double)k * sh.sk[0].lnQ}}; return exp_fast(e)[0]; }
+    return tt.E[kind - 1][k];
 }
 
 // The image of the last kept tile in LDS: node 0 = the tile's start point, node e + 1 = step end e.  It serves the
@@ -301,35 +313,68 @@ struct TileImage {
     double R[kN];   // uncapped Alfven radius (the branch of the right-hand side at the start of the next tile)
 };
 
-// (Mdisc, omega) at position p8 (in eighths of a grid interval) inside the kept part of the image of a tile of kind
-// `kind` that started at pos8 / time t_s with steps of d8 eighths: the node itself when p8 is one, else the Hermite
-// interpolant over its step (strides 2 and 4 only; the remainder is then a whole number of grid intervals).
+// Mdisc at the i-th skipped grid point of step J (time t) of a tile of `keep` kept steps where the step is longer than the
+// viscous time: cubic Lagrange interpolation of the ratio Mdisc / (tvisc Mdotfb) through the four nodes around the step
+// (the first / last four of the kept part for its first / last step; weights: LDS table), times tvisc Mdotfb(t).
 template <int SPL>
-MP_DEV void image_state(const DevShared &sh, const TileImage<SPL> &im, const TimeTable<SPL> &tt, int kind, int pos8, int d8,
-                        double t_s, double inv_tau, int p8, double &Mv, double &Wv) {
-    const int rel = p8 - pos8, J = rel / d8, rem = rel - J * d8;
+MP_DEV double dense_mdisc_qs(const Walker &w, const TileImage<SPL> &im, int kind, int i, int J, int keep, double t) {
+    const int l0 = max(min(J - 1, keep - 3), 0), variant = J - l0;     // nodes l0 .. l0 + 3; the step is [l0 + variant, + 1]
+    const int base = kWtabDense + ((kind - 2) * 7 + (i - 1)) * 12 + variant * 4;
+    double r = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double mk = im.M[l0 + k] * w.inv_tau;                   // Mdisc/tvisc; Mdotfb = dMdisc/dt + Mdisc/tvisc
+        r = fma(g_wtab[base + k], mk / (im.D[l0 + k] + mk), r);       // Mdisc / (tvisc Mdotfb) at the node
+    }
+    const Vd<1> tv{{t}};
+    return r * mdot_fb(w, tv)[0] / w.inv_tau;
+}
+
+// (Mdisc, omega) at position p8 (in eighths of a grid interval) inside the kept part of the image of a tile of kind
+// `kind` that started at pos8 / time t_s with steps of d8 eighths: the node itself when p8 is one, else the dense output of
+// its step (strides 2, 4, 8 only; the remainder is then a whole number of grid intervals).
+template <int SPL>
+MP_DEV void image_state(const DevShared &sh, const Walker &w, const TileImage<SPL> &im, const TimeTable<SPL> &tt, int kind,
+                        int pos8, int keep, double t_s, int p8, double &Mv, double &Wv) {
+    const int sh8 = kind == 0 ? 0 : kind + 2;                        // d8 = 1 << sh8
+    const int rel = p8 - pos8, J = rel >> sh8, rem = rel - (J << sh8);
     Mv = im.M[J];
     Wv = im.W[J];
     if (rem != 0) {
-        const StrideK &K = sh.sk[kind];
-        const int i = (rem >> 3) & 3;
-        const double h = t_s * tt.E[kind][J + 1] * K.one_m_invQ;
-        Mv = hermite_mdisc(K, i, h, h * inv_tau, im.M[J], im.D[J], im.D2[J], im.M[J + 1], im.D[J + 1], im.D2[J + 1]);
-        Wv = hermite(K.theta[i], h, im.W[J], im.F[J], im.W[J + 1], im.F[J + 1]);
+        const int i = (rem >> 3) & 7;
+        const double th = wtab_theta(kind, i);
+        const double t1 = t_s * tt.E[kind - 1][J + 1], h = t1 * sh.sk[kind].one_m_invQ;
+        const double z = h * w.inv_tau;
+        if (z < 1.0 || keep < 3) Mv = hermite_mdisc(th, h, z, im.M[J], im.D[J], im.D2[J], im.M[J + 1], im.D[J + 1], im.D2[J + 1]);
+        else Mv = dense_mdisc_qs(w, im, kind, i, J, keep, fma(th - 1.0, h, t1));
+        Wv = hermite(th, h, im.W[J], im.F[J], im.W[J + 1], im.F[J + 1]);
     }
 }
+
+// Phase profile (developer build, `make -C magprop_amd/csrc phase-profile`, tools/phase_profile.py): the shader clock is read
+// between the sections of a tile and the per-section sums of one walker replace its tile log.  Compiles to nothing otherwise.
+#ifdef MP_PHASE_PROFILE
+#define MP_PHASE_DECL unsigned long long ph_t = __builtin_amdgcn_s_memtime(), ph_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define MP_PHASE(i) { const unsigned long long ph_n = __builtin_amdgcn_s_memtime(); ph_acc[i] += ph_n - ph_t; ph_t = ph_n; }
+#define MP_PHASE_DUMP if (a.tile_log && lane == 0) { for (int i = 0; i < 10; ++i) a.tile_log[(size_t)walker * MP_TILE_LOG + i] = (int32_t)min(ph_acc[i], 0x7FFFFFFFull); }
+#else
+#define MP_PHASE_DECL
+#define MP_PHASE(i)
+#define MP_PHASE_DUMP
+#endif
 
 // ---------------------------------------------------------------- the kernel
 // Evaluate ONE walker on the calling wavefront (all 64 lanes enter with identical arguments).
 // SPL = consecutive steps owned by one lane; a tile is 64*SPL steps.  par[] holds the sampler coordinates
 // (prior checked and log-masked coordinates un-logged here unless a.physical); walker indexes ds_id and the
-// optional curve outputs; im / Lbuf are the wave's LDS areas (Lbuf: [2*(4*64*SPL + 1)], staging of the curve outputs).
+// optional curve outputs; im / Lbuf are the wave's LDS areas (Lbuf: [8*64*SPL + 1], staging of the curve outputs).
 template <bool CURVES, int SPL, bool LONG>
 MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, double (&par)[MP_MAX_NDIM],
                         TileImage<SPL> &im, const TimeTable<SPL> &tt, double *Lbuf, double &lnp_out, int &status_out,
                         int &sweeps_out, int &tiles_out) {
     constexpr int kSPL = SPL, kTile = 64 * SPL, kMaxSweeps = kTile + kMaxSweepsMargin;
     const int lane = threadIdx.x & 63;
+    MP_PHASE_DECL
 
     const int n_grid = sh.n_grid;
     const int nsteps = n_grid - 1;
@@ -401,62 +446,65 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
             if (a.omega) a.omega[row] = om_s;
         }
         // ---- tile control (wave-uniform).  Positions in eighths of a grid interval: the first pre_fine intervals are
-        // covered with 1/8-interval sub-steps (kind 0), the rest with steps of 1, 2 or 4 intervals (kinds 1, 2, 3).
+        // covered with 1/8-interval sub-steps (kind 0), the rest with steps of 1, 2, 4 or 8 intervals (kinds 1 .. 4).
         const int end8 = 8 * nsteps, pre_end8 = 8 * sh.pre_fine;
         const int max_kind = sh.max_kind;
         int pos8 = 0, kind = 1;
         bool rec_valid = false;                  // the image holds a kept tile (the history of the next one)
-        int rec_kind = 0, rec_d8 = 1, rec_J = 0; // its kind, its step in eighths and the number of steps kept
+        int rec_kind = 0, rec_sh8 = 0, rec_J = 0; // its kind, log2 of its step in eighths and the number of steps kept
         int cool = 0;                            // tiles over single intervals for which the scaled indicator decides about coarsening
-        int cool4 = 0;                           // tiles over 2 intervals that stay at 2 after the sweeps of a stride-4 tile were slow
+        int hold = 0, hold_kind = 0;             // tiles of kind hold_kind that stay there after the sweeps of the next coarser kind were slow
+        int trouble = 0;                         // coarse tiles of this walker that were given up or kept nothing: after two of
+                                                 // them the walker stays at strides <= 4 (heavy discs around fast, strongly
+                                                 // magnetised stars: the sweeps of 2 048-interval tiles converge too slowly)
+        int opt_kind = max_kind;                 // the kind that is tried after a calm tile over single intervals: lowered when
+                                                 // such an attempt fails outright, raised when the indicator promotes a tile
         // Each lane owns kSPL consecutive steps of the tile: steps lane*kSPL + s, s = 0..kSPL-1.
+        MP_PHASE(0)
         while (pos8 < end8) {
             const bool pre = pos8 < pre_end8;
             if (pre) kind = 0;
-            int d8 = pre ? 1 : (4 << kind);                                 // 8, 16, 32 eighths
+            int d8 = pre ? 1 : (4 << kind);                                 // 8, 16, 32, 64 eighths
             const int left8 = (pre ? pre_end8 : end8) - pos8;
-            if (!pre) while (kind > 1 && (left8 % d8) != 0) { --kind; d8 >>= 1; }
-            const int nc = min(kTile, left8 / d8);                          // steps of this tile that exist
+            // (whole steps only; and at least three of them, for the dense output's four nodes)
+            if (!pre) while (kind > 1 && ((left8 & (d8 - 1)) != 0 || left8 < 3 * d8)) { --kind; d8 >>= 1; }
+            const int sh8 = pre ? 0 : kind + 2;                             // d8 = 1 << sh8
+            const int nc = min(kTile, left8 >> sh8);                        // steps of this tile that exist
             const StrideK &K = sh.sk[kind];
             const int wbase = kind * kWtabStride;                           // this kind's quadrature matrices in the LDS table
             ++tiles_total;
+            MP_PHASE(8)
 
             // ---------------- step end times (the grid is geometric: t_k = t_s Q^k) and step lengths
-            Vd<kSPL> h, S1, dS1;
+            Vd<kSPL> h, S1, dS1, iu1;
             {
                 Vd<kSPL> tb;
 #pragma unroll
                 for (int s = 0; s < kSPL; ++s) {
-                    tb[s] = t_s * tt.E[kind][min(lane * kSPL + s + 1, nc)];
+                    tb[s] = t_s * time_factor(sh, tt, kind, min(lane * kSPL + s + 1, nc));
                     h[s] = (lane * kSPL + s < nc) ? tb[s] * K.one_m_invQ : 0.0;   // 0 for the padding steps of a short tile
                 }
-                S1 = mdot_fb_d(w, tb, dS1);
+                S1 = mdot_fb_d(w, tb, dS1, iu1);
             }
 
-            // ---------------- history at this tile's spacing: the source of Mdisc is analytic; (omega_dot, omega) at the
-            // three (predictor: four) previous points come from the record of the last kept tile
-            double cS0, cS1, cS2, cS3, cdS0;
-            if (rec_valid && rec_kind == kind && rec_J >= 3) {
-                // same spacing as the record: its last nodes are the points (dMdisc/dt = Mdotfb - Mdisc/tvisc)
-                cS0 = fma(im.M[rec_J], w.inv_tau, im.D[rec_J]);
-                cS1 = fma(im.M[rec_J - 1], w.inv_tau, im.D[rec_J - 1]);
-                cS2 = fma(im.M[rec_J - 2], w.inv_tau, im.D[rec_J - 2]);
-                cS3 = fma(im.M[rec_J - 3], w.inv_tau, im.D[rec_J - 3]);
-                cdS0 = fma(im.D[rec_J], w.inv_tau, im.D2[rec_J]);
-            } else {
-                const double q2 = K.inv_Q * K.inv_Q;
-                const Vd<4> tg{{t_s, t_s * K.inv_Q, t_s * q2, t_s * q2 * K.inv_Q}};
-                Vd<4> dSg;
-                const Vd<4> Sg = mdot_fb_d(w, tg, dSg);
-                cS0 = Sg[0]; cS1 = Sg[1]; cS2 = Sg[2]; cS3 = Sg[3]; cdS0 = dSg[0];
+            // ---------------- the fallback rate at the tile's start (its derivative: d2Mdisc/dt2 of the image's node 0)
+            double cS0, cdS0, ciu0;
+            {
+                const Vd<1> tsv{{t_s}};
+                Vd<1> dS0, iu0;
+                cS0 = mdot_fb_d(w, tsv, dS0, iu0)[0];
+                cdS0 = dS0[0];
+                ciu0 = iu0[0];
             }
+            // ---------------- history at this tile's spacing: (omega_dot, omega) at the three (predictor: four) previous
+            // points come from the record of the last kept tile
             double cf1 = cf0, cf2 = cf0, cf3 = cf0, cw1 = om_s, cw2 = om_s, cw3 = om_s, cw4 = om_s;
             bool have4 = false, interp_hist = false;
             const bool startup = !rec_valid;
             if (rec_valid) {
                 // lane k-1 looks up the point k steps of this tile before its start (k = 1..4): node ja of the record,
                 // or `rem` eighths before it inside the record's step [ja - 1, ja]
-                const int o8 = (lane + 1) * d8, idx = o8 / rec_d8, rem = o8 - idx * rec_d8;
+                const int o8 = (lane + 1) << sh8, idx = o8 >> rec_sh8, rem = o8 - (idx << rec_sh8);
                 const int ja = rec_J - idx, jb = ja - (rem != 0 ? 1 : 0);
                 double wv = om_s, fv = cf0;
                 const bool avail = lane < 4 && jb >= 0;
@@ -482,26 +530,36 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 cw4 = have4 ? lane_bcast(wv, 3) : cw3;
             }
 
-            // ---------------- Mdisc: exponential Adams-Moulton step of order 5 (explicit: the source is known) + affine scan.
-            // ES[k]: source at the four points before this lane's first step (k = 0..3) and at its step ends (k = 4+s).
+            MP_PHASE(1)
+            // ---------------- Mdisc: exponential step with the analytic source + affine scan.  The source is a power law of
+            // t + tfb: inside a step Mdotfb(t_j + theta h) = Mdotfb(t_j) (1 + theta x)^(-5/3), x = h/(t_j + tfb) <= 1 - 1/Q, and
+            // its binomial series integrates term by term against the exponential kernel,
+            //   Mdisc_{j+1} = e^{-z} Mdisc_j + h Mdotfb(t_j) sum_k c_k (-x)^k phi_{k+1}(-z),  c_k = Gamma(k + 5/3)/Gamma(5/3),
+            // k = 0..5: where the step is much longer than tvisc the series is that of (1 + x)^(-5/3) itself and the first
+            // neglected term is 4 x^6 = 7e-12 at a stride of 8 grid intervals (oracle/mp_oracle.c).
             Vd<kSPL> M1;
             DiscPt<kSPL> d1;
             {
-                double ES[kSPL + 4];
-#pragma unroll
-                for (int s = 0; s < kSPL; ++s) ES[4 + s] = S1[s];
-                ES[3] = lane_prev(ES[kSPL + 3], cS0);
-                ES[2] = lane_prev(ES[kSPL + 2], cS1);
-                ES[1] = lane_prev(ES[kSPL + 1], cS2);
-                ES[0] = lane_prev(ES[kSPL + 0], cS3);
-                Vd<kSPL> zm, v0, v1, v2, v3, v4;
+                Vd<kSPL> zm, S0, x;
+                const double Sp = lane_prev(S1[kSPL - 1], cS0), iup = lane_prev(iu1[kSPL - 1], ciu0);   // at this lane's first step start
 #pragma unroll
                 for (int s = 0; s < kSPL; ++s) {
                     zm[s] = -h[s] * w.inv_tau;
-                    v0[s] = ES[4 + s]; v1[s] = ES[3 + s]; v2[s] = ES[2 + s]; v3[s] = ES[1 + s]; v4[s] = ES[s];
+                    S0[s] = s == 0 ? Sp : S1[s - 1];
+                    x[s] = h[s] * w.inv_tfb * (s == 0 ? iup : iu1[s - 1]);
                 }
                 const Phi5<kSPL> pm = phi12345(zm);
-                const Vd<kSPL> inc = eam5_increment_nodes(eam5_node_weights(wbase, pm), h, v0, v1, v2, v3, v4);
+                const Vd<kSPL> p6 = phi6(zm, pm);
+                Vd<kSPL> inc;
+#pragma unroll
+                for (int s = 0; s < kSPL; ++s) {
+                    double P = fma(-x[s] * (104720.0 / 243.0), p6[s], (6160.0 / 81.0) * pm.p5[s]);
+                    P = fma(x[s], P, (-440.0 / 27.0) * pm.p4[s]);
+                    P = fma(x[s], P, (40.0 / 9.0) * pm.p3[s]);
+                    P = fma(x[s], P, (-5.0 / 3.0) * pm.p2[s]);
+                    P = fma(x[s], P, pm.p1[s]);
+                    inc[s] = h[s] * S0[s] * P;                 // padding steps: h = 0
+                }
                 Vd<kSPL> am, bm;
                 double A = 1.0, B = 0.0;                  // composition of this lane's step maps
 #pragma unroll
@@ -520,6 +578,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 d1 = disc_point(sh, w, M1);
             }
 
+            MP_PHASE(2)
             // ---------------- omega: predictor = extrapolation of the last five values in the step index
             // (the grid is logarithmic, so power laws are smooth in the index) ...
             Vd<kSPL> wg;                                  // current guess of omega at this lane's step ends
@@ -539,6 +598,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                     wg[s] = fma(k, g1, fma(c2, g2, fma(c3, g3, fma(c3 * (k + 3.0) * 0.25, g4, om_s))));
                 }
             }
+            MP_PHASE(3)
             // ... then Newton-type sweeps of the linearised step maps.
             // E*[k]: values at the four points before this lane's first step (k = 0..3) and at its step ends (k = 4+s).
             double Ef[kSPL + 4], Ew[kSPL + 4];
@@ -557,9 +617,13 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
             Vd<kSPL> lam, ez, p5, n0, n1, n2, n3, n4;
             EamW5<kSPL> cw;
             bool light = false, ultra = false, early_stop = false;
-            // (a step over 2 or 4 grid intervals weighs an error of omega_dot 2 or 4 times as much: tighter sweeps there)
+            // (a step over 2, 4 or 8 grid intervals weighs an error of omega_dot that many times as much: tighter sweeps there)
             const double tol_k = kind >= 2 ? sh.coarse_tol_factor * sh.sweep_tol : sh.sweep_tol;
             const double ultra_k = kind >= 2 ? sh.coarse_ultra_factor * sh.ultra_tol : sh.ultra_tol;
+            // (the tile tried at a coarse stride right behind the sub-steps has no calm predecessor to vouch for it: a tenth;
+            // steps over 8 intervals: oracle/mp_oracle.c)
+            const double tile_tol = (kind >= 2 && rec_kind == 0) ? 0.1 * sh.stride_tol : (kind >= 4 ? sh.k4_tol_factor * sh.stride_tol : sh.stride_tol);
+            bool abort_tile = false;
             while (true) {
                 ++sweep;
                 if (!light) {   // (after a sweep that moved every lane by < 1e-4 the guesses are positive and finite)
@@ -668,6 +732,21 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 pending_tight = __ballot(!(dsum <= 0.01 * tol_k * mag));
                 if (pending == 0ull || flagged != 0ull || sweep >= kMaxSweeps) break;
                 if (kind >= 2 && sweep >= sh.coarse_max_sweeps) break;   // not worth it at this stride (the rest is redone finer)
+                // A coarse tile whose first lanes (the ones closest to the known start: they converge first) show a smoothness
+                // indicator beyond the bound after the third sweep (well beyond it after the second) will keep nothing: it is
+                // given up now instead of after coarse_max_sweeps sweeps.  (Measured on 8 000 coarse tiles of prior-wide walkers:
+                // tiles that went on to keep lanes had <= 0.8 of the bound there after sweep 3; of those that kept nothing,
+                // 90 % were beyond it after sweep 2 already.)
+                if (kind >= 2 && sweep >= 2) {
+                    const double margin = sweep == 2 ? 4.0 : 1.0;
+                    bool hot = false;
+#pragma unroll
+                    for (int s = 0; s < kSPL; ++s) {
+                        const double d4 = 120.0 * fabs(p5[s]) * h[s] * fabs((n0[s] + n4[s]) - 4.0 * (n1[s] + n3[s]) + 6.0 * n2[s]);
+                        hot = hot || d4 > margin * tile_tol * wg[s];
+                    }
+                    if ((__ballot(hot) & ((1ull << kMinKeepLanes) - 1ull)) != 0ull) { abort_tile = true; break; }
+                }
                 // Slow sweeps on single intervals (a poor extrapolated guess through a fast spin-up, far from the break-up
                 // limit): the lanes that have converged are final (a step depends on earlier ones only); they are kept
                 // and a new tile starts behind them with a fresh extrapolation, instead of sweeping on over all 64 lanes.
@@ -678,6 +757,16 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 if (over_sweeps >= kChatterSweeps) { flagged |= over_now ? over_now : pending; break; }
             }
             sweeps_total += sweep;
+            MP_PHASE(4)
+            if (abort_tile) {                                                   // redo at stride 1 (as after a tile that keeps nothing)
+                if (a.tile_log && lane == 0 && tiles_total <= MP_TILE_LOG)
+                    a.tile_log[(size_t)walker * MP_TILE_LOG + tiles_total - 1] = kind | (sweep << 4) | (64 << 24);
+                cool = 3;
+                ++trouble;
+                opt_kind = max(2, kind - 1);
+                kind = kind > 2 ? kind - 1 : 1;     // the next finer stride is tried at once
+                continue;
+            }
 
             // ---------------- failure detection in time order (oracle/mp_oracle.c).  Per lane: a NaN or an
             // infinity anywhere shows in the sum, a non-positive value in the minimum, the break-up limit in the largest
@@ -710,10 +799,8 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
             // smoothness indicator 120 |phi_5(h lambda)| h |4th difference of (f - lambda omega)| / omega against stride_tol, and against
             // stride_tol / 64 and / 2048 (what it would be at twice / four times the step: 5th-order scaling, margin 2).
             int keep_lanes = 64, next_kind = kind, why = 0;   // why: diagnostics (tile log)
-            // (the tile tried at a coarse stride right behind the sub-steps has no calm predecessor to vouch for it: a tenth)
-            const double tile_tol = (kind >= 2 && rec_kind == 0) ? 0.1 * sh.stride_tol : sh.stride_tol;
             {
-                bool brk = false, ind1 = false, ind64 = false, ind2048 = false;
+                bool brk = false, ind1 = false, ind64 = false, ind2048 = false, ind65536 = false;
 #pragma unroll
                 for (int s = 0; s < kSPL; ++s) {
                     const bool valid = lane * kSPL + s < nc;
@@ -725,53 +812,63 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                     ind1 = ind1 || d4 > lim;
                     ind64 = ind64 || 64.0 * d4 > lim;
                     ind2048 = ind2048 || 2048.0 * d4 > lim;
+                    ind65536 = ind65536 || 65536.0 * d4 > lim;
                 }
-                const unsigned long long B = __ballot(brk), I1 = __ballot(ind1), I64 = __ballot(ind64), I2048 = __ballot(ind2048);
+                const unsigned long long B = __ballot(brk), I1 = __ballot(ind1), I64 = __ballot(ind64), I2048 = __ballot(ind2048),
+                                         I65536 = __ballot(ind65536);
                 const int full_lanes = (nc + kSPL - 1) / kSPL;                 // lanes that hold steps of this tile
-                why = (B != 0ull ? 1 : 0) | (I1 != 0ull ? 2 : 0) | (I64 != 0ull ? 4 : 0) | (I2048 != 0ull ? 8 : 0) | (unconv != 0ull ? 16 : 0);
+                why = (B != 0ull ? 1 : 0) | (I1 != 0ull ? 2 : 0) | (I64 != 0ull ? 4 : 0) | (I2048 != 0ull ? 8 : 0) | (unconv != 0ull ? 16 : 0) |
+                      (I65536 != 0ull ? 32 : 0);
                 if (kind >= 2) {
                     const unsigned long long bad = B | I1 | unconv;
                     const int first = bad ? __ffsll(bad) - 1 : 64;
                     if (first < full_lanes) {
                         if (first < 2 * kMinKeepLanes) cool = 3;                // a coarse attempt that failed early
                         if (first < kMinKeepLanes) {                            // nothing worth keeping: redo at stride 1
+                            opt_kind = max(2, kind - 1);
+                            ++trouble;
                             if (a.tile_log && lane == 0 && tiles_total <= MP_TILE_LOG)
-                                a.tile_log[(size_t)walker * MP_TILE_LOG + tiles_total - 1] = kind | (sweep << 4);
-                            kind = 1;
+                                a.tile_log[(size_t)walker * MP_TILE_LOG + tiles_total - 1] = kind | (sweep << 4) | (why << 24);
+                            // a kink in those lanes: single intervals; else the next finer stride is tried at once
+                            kind = (kind > 2 && (B & ((1ull << kMinKeepLanes) - 1ull)) == 0ull) ? kind - 1 : 1;
                             continue;
                         }
                         keep_lanes = first;
-                        // a kink or a fast feature gets single intervals; slow sweeps alone, the next finer stride
+                        // a kink or a fast feature gets single intervals; slow sweeps alone, the next finer stride, which is
+                        // then held for a few tiles
                         next_kind = (((B | I1) >> first) & 1ull) ? 1 : kind - 1;
-                        if (next_kind == 2) cool4 = 3;                         // slow sweeps at stride 4: stay at 2 for a few tiles
-                    } else if (kind == 2 && nc == kTile) {
-                        if (cool4 > 0) --cool4;
-                        else next_kind = I64 == 0ull ? 3 : 2;
+                        if (next_kind >= 2) { hold_kind = next_kind; hold = 3; }
+                    } else if (kind < max_kind && nc == kTile) {
+                        if (hold > 0 && kind == hold_kind) --hold;
+                        else next_kind = I64 == 0ull ? kind + 1 : kind;
+                        opt_kind = max(opt_kind, min(next_kind, max_kind));
                     }
                 } else if (unconv != 0ull) {                                    // kinds 0, 1 stopped early: the converged lanes
                     keep_lanes = __ffsll(unconv) - 1;
                     if (pre) keep_lanes &= ~(8 / kSPL - 1);                    // (whole grid intervals of sub-steps)
                 } else if (kind == 1 && nc == kTile) {
                     // No kink in this tile: the scaled indicator decides while a recent coarse attempt has failed early
-                    // (cool > 0); otherwise the coarse stride is simply tried (a tile is cut where it does not hold): the
+                    // (cool > 0); otherwise the coarsest stride is simply tried (a tile is cut where it does not hold): the
                     // indicator of a tile whose sweeps stopped at the tolerance carries their residual, amplified by the 4th
                     // difference, and kept stiff late-time stretches at single intervals for a dozen tiles.
                     if (B == 0ull) {
-                        if (cool > 0) { --cool; next_kind = I2048 == 0ull ? 3 : (I64 == 0ull ? 2 : 1); }
-                        else next_kind = I1 == 0ull ? 3 : 1;
+                        if (cool > 0) { --cool; next_kind = I65536 == 0ull ? 4 : (I2048 == 0ull ? 3 : (I64 == 0ull ? 2 : 1)); }
+                        else next_kind = I1 == 0ull ? opt_kind : 1;
                     }
                     else {
                         // a kink inside this tile: the history of a coarse successor must lie behind it
                         const int first_clean = __ffsll(B) - 1 + 2;            // lanes from here on are past the kink
                         const int tail = kTile - first_clean * kSPL;           // steps in them
                         const unsigned long long post = first_clean < 64 ? ~0ull << first_clean : 0ull;
-                        if (tail >= 12 + kSPL && (I2048 & post) == 0ull) next_kind = 3;
+                        if (tail >= 24 + kSPL && (I65536 & post) == 0ull) next_kind = 4;
+                        else if (tail >= 12 + kSPL && (I2048 & post) == 0ull) next_kind = 3;
                         else if (tail >= 6 + kSPL && (I64 & post) == 0ull) next_kind = 2;
                     }
                 }
-                if (kind == 0) next_kind = 3;   // after the sub-stepped tiles: optimistic (a tile that meets a fast feature is cut)
-                next_kind = min(next_kind, max_kind);
+                if (kind == 0) next_kind = 4;   // after the sub-stepped tiles: optimistic (a tile that meets a fast feature is cut)
+                next_kind = min(next_kind, trouble >= sh.trouble_limit ? min(max_kind, 3) : max_kind);
             }
+            MP_PHASE(5)
             const int keep = min(keep_lanes * kSPL, nc);                       // steps kept
             if (a.tile_log && lane == 0 && tiles_total <= MP_TILE_LOG)
                 a.tile_log[(size_t)walker * MP_TILE_LOG + tiles_total - 1] = kind | (sweep << 4) | (keep_lanes << 16) | (why << 24);
@@ -793,6 +890,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
             }
             __syncthreads();
 
+            MP_PHASE(6)
             // ---------------- observations
             if constexpr (!CURVES) {
                 // The model is only needed at the two grid points bracketing each observation.  The lane holding an
@@ -803,8 +901,8 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 if (deferred) {
                     const int p8 = 8 * ob_g;
                     if (ob_g >= 0 && p8 >= pos8 && p8 < end_kept8) {
-                        image_state(sh, im, tt, kind, pos8, d8, t_s, w.inv_tau, p8, obM[0], obW[0]);
-                        image_state(sh, im, tt, kind, pos8, d8, t_s, w.inv_tau, p8 + 8, obM[1], obW[1]);
+                        image_state(sh, w, im, tt, kind, pos8, keep, t_s, p8, obM[0], obW[0]);
+                        image_state(sh, w, im, tt, kind, pos8, keep, t_s, p8 + 8, obM[1], obW[1]);
                     }
                     if (long_lc) {
                         // observations 64.. whose interval starts inside the kept range (64-interval buckets of the dataset)
@@ -815,8 +913,8 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                             const int g = sh.obs_g[dsd.obs_off + j];
                             if (g < g_lo || g >= g_hi) continue;
                             double Ma, Wa, Mb, Wb;
-                            image_state(sh, im, tt, kind, pos8, d8, t_s, w.inv_tau, 8 * g, Ma, Wa);
-                            image_state(sh, im, tt, kind, pos8, d8, t_s, w.inv_tau, 8 * g + 8, Mb, Wb);
+                            image_state(sh, w, im, tt, kind, pos8, keep, t_s, 8 * g, Ma, Wa);
+                            image_state(sh, w, im, tt, kind, pos8, keep, t_s, 8 * g + 8, Mb, Wb);
                             double *p = sc + (j - 64);
                             p[0] = Ma; p[sc_stride] = Mb;
                             p[2 * sc_stride] = Wa; p[3 * sc_stride] = Wb;
@@ -831,21 +929,24 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 // tile's start point, [0] = the start point itself) for the interpolation at the observed times and leaves
                 // for HBM from there with lane-contiguous addresses: every store instruction of the wavefront writes 512
                 // consecutive bytes of the walker's row.
-                const int ns = pre ? 1 : (d8 >> 3);                             // grid points per step (kinds 1, 2, 3)
+                const int ns = pre ? 1 : (d8 >> 3);                             // grid points per step (kinds 1 .. 4)
                 const int g0 = pos8 >> 3;                                       // grid index of the tile's start
-                const int n_here = pre ? keep / 8 : keep * ns;                  // grid points this tile adds
+                const int n_here = pre ? keep >> 3 : keep * ns;                 // grid points this tile adds
                 const size_t o0 = row + (size_t)g0 + 1;
-                double *S2 = Lbuf + 4 * kTile + 1;                              // second staging area
                 // which: 0 Ltot, 1 Lprop, 2 Ldip, 3 Mdisc, 4 omega -> stage[m], m = 1..n_here
                 auto stage_curve = [&](int which, double *stage) {
                     for (int i = 1; i <= ns; ++i) {
                         Vd<kSPL> Mv = M1, Wv = wg;                              // i == ns: the step ends themselves
                         if (i < ns) {
-                            const double th = K.theta[i];
+                            const double th = wtab_theta(kind, i);
 #pragma unroll
                             for (int s = 0; s < kSPL; ++s) {
                                 const int J = lane * kSPL + s;                 // nodes J (step start) and J + 1 of the image
-                                Mv[s] = hermite_mdisc(K, i, h[s], h[s] * w.inv_tau, im.M[J], im.D[J], im.D2[J], im.M[J + 1], im.D[J + 1], im.D2[J + 1]);
+                                const double z = h[s] * w.inv_tau;
+                                if (z < 1.0 || keep < 3 || J >= keep)
+                                    Mv[s] = hermite_mdisc(th, h[s], z, im.M[J], im.D[J], im.D2[J], im.M[J + 1], im.D[J + 1], im.D2[J + 1]);
+                                else
+                                    Mv[s] = dense_mdisc_qs(w, im, kind, i, J, keep, fma(th - 1.0, h[s], t_s * tt.E[kind - 1][J + 1]));
                                 Wv[s] = hermite(th, h[s], im.W[J], im.F[J], wg[s], Ef[4 + s]);
                             }
                         }
@@ -876,18 +977,6 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 if (lane == 0) Lbuf[0] = L_s;
                 __syncthreads();
                 if (a.ltot) store_curve(a.ltot, Lbuf, 1.0e50);
-                // the other curves (mp_model_lc only) go through the second staging area, one at a time
-                auto put = [&](double *dst, int which, double div) {
-                    if (!dst) return;                                           // wave-uniform
-                    stage_curve(which, S2);
-                    __syncthreads();
-                    store_curve(dst, S2, div);
-                    __syncthreads();
-                };
-                put(a.lprop, 1, 1.0e50);
-                put(a.ldip, 2, 1.0e50);
-                put(a.mdisc, 3, 1.0);
-                put(a.omega, 4, 1.0);
                 if (a.want_chi2) {
                     const int g_hi = end_kept8 >> 3;
                     if (ob_g >= g0 && ob_g < g_hi) {
@@ -913,21 +1002,34 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                     }
                 }
                 L_s = Lbuf[n_here];
-                __syncthreads();                                                // the next tile overwrites the staging area
+                __syncthreads();                                                // the staging area is reused below / by the next tile
+                // the other curves (mp_model_lc only) go through the same staging area, one at a time
+                auto put = [&](double *dst, int which, double div) {
+                    if (!dst) return;                                           // wave-uniform
+                    stage_curve(which, Lbuf);
+                    __syncthreads();
+                    store_curve(dst, Lbuf, div);
+                    __syncthreads();
+                };
+                put(a.lprop, 1, 1.0e50);
+                put(a.ldip, 2, 1.0e50);
+                put(a.mdisc, 3, 1.0);
+                put(a.omega, 4, 1.0);
             }
 
             // ---------------- carry the end of the kept steps to the next tile
-            t_s = t_s * tt.E[kind][keep];
+            t_s = t_s * time_factor(sh, tt, kind, keep);
             M_s = im.M[keep];
             om_s = im.W[keep];
             cf0 = im.F[keep];
             flags_s = branch_flags(w, im.R[keep], om_s);
             rec_valid = true;
             rec_kind = kind;
-            rec_d8 = d8;
+            rec_sh8 = sh8;
             rec_J = keep;
             pos8 = end_kept8;
             kind = next_kind;
+            MP_PHASE(7)
         }
         if (deferred && status == MP_STATUS_OK) {   // the luminosity evaluations of this walker: one per 64 observations
             const Vd<2> Mv{{obM[0], obM[1]}}, Wv{{obW[0], obW[1]}};
@@ -979,6 +1081,8 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
         lnp = -0.5 * wave_sum(chi);
         if (!isfinite(lnp)) { lnp = -INFINITY; status = MP_STATUS_NONFINITE; }
     }
+    MP_PHASE(9)
+    MP_PHASE_DUMP
     lnp_out = lnp;
     status_out = status;
     sweeps_out = sweeps_total;

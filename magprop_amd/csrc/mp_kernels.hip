@@ -2,16 +2,18 @@
 //
 // Layout: ONE WALKER PER WAVEFRONT, SPL CONSECUTIVE TIME STEPS PER LANE.  The 10 000 grid intervals are processed in
 // tiles of 64*SPL steps; inside a tile all steps advance at once (parallel in time).  Scheme = exponential
-// Adams-Moulton of order 4 on the geometric output grid (serial restatement:
-// oracle/mp_oracle.c mpo_trajectory).  Per tile (mp_eval.hpp, walker_eval):
+// Adams-Moulton of order 5 on geometric grids (serial restatement: oracle/mp_oracle.c
+// mpo_trajectory_mode): a tile's step spans 1/8 (the first 32 intervals), 1, 2, 4 or 8 grid intervals, chosen tile by tile
+// from the solution's smoothness; the states at skipped grid points come from the step's Hermite interpolant.
+// Per tile (mp_eval.hpp, walker_eval):
 //
 //   1. Mdisc obeys dM/dt = Mdotfb(t) - M/tvisc (linear, omega-independent; reference RHS
 //      code/synthetic_datasets/funcs.py:122-129, magnetar/funcs.py:86-92).  Every lane evaluates Mdotfb at its step
-//      ends, fetches the three previous values from its neighbour (DPP), builds and composes the affine maps
+//      ends, fetches the four previous values from its neighbour (DPP), builds and composes the affine maps
 //      M_{j+1} = e^{-h/tvisc} M_j + b_j of its steps; a wavefront scan of affine maps yields Mdisc at all step ends.
 //   2. omega obeys a scalar nonlinear ODE fed by Mdisc(t).  Every lane evaluates omega_dot and its Jacobian lambda
-//      ONCE per sweep at its current guess of omega at its step ends, fetches (omega_dot, omega) of the three
-//      previous grid points, and forms the step maps omega_{j+1} = e^{h lambda} omega_j + h sum_m phi_{m+1}(h lambda) g_m.
+//      ONCE per sweep at its current guess of omega at its step ends, fetches (omega_dot, omega) of the four
+//      previous points, and forms the step maps omega_{j+1} = e^{h lambda} omega_j + h sum_m phi_{m+1}(h lambda) g_m.
 //      A second affine scan propagates the tile's start value through all linearised maps.  This Newton-type sweep
 //      contracts by 1e-2..1e-3 per pass (about 2 sweeps from an extrapolated guess, the last one being the convergence
 //      check), terminates in any case after at most tile-length sweeps, and reproduces the serial recurrence to ~1e-11.
@@ -44,7 +46,7 @@ template <bool CURVES, int SPL, bool LONG>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPL >= 4 ? 1 : 2, SPL >= 4 ? 1 : 2))) void lnprob_kernel(const DevShared sh, const LaunchArgs a) {
     __shared__ TileImage<SPL> im;
     __shared__ TimeTable<SPL> tt;
-    __shared__ double Lbuf[CURVES ? 2 * (4 * 64 * SPL + 1) : 1];   // up to 4 grid points per step
+    __shared__ double Lbuf[CURVES ? 8 * 64 * SPL + 1 : 1];   // up to 8 grid points per step
     ktab_init();
     wtab_init(sh.wtab);
     time_table_init(sh, tt);

@@ -198,18 +198,19 @@ MP_DEV d2v ktab2(int k) {   // entries k, k+1 (k even); volatile: stays where it
     return *(volatile const __attribute__((address_space(3))) d2v *)&g_ktab[k];   // LDS pointer type: ds_read_b128, not flat
 }
 
-// The quadrature matrices of the four tile kinds (mp_device.h: kWtabStride doubles per kind), copied from the device table
+// The constants of the tile kinds (mp_device.h: kWtabStride doubles per kind), copied from the device table
 // at kernel entry and read with broadcast ds_read_b128 where they are used.
-__shared__ __attribute__((aligned(16))) double g_wtab[4 * kWtabStride];
+__shared__ __attribute__((aligned(16))) double g_wtab[kWtabSize];
 
 MP_DEV void wtab_init(const double *src) {   // every thread of the workgroup calls this once, before any table read
-    for (int i = threadIdx.x; i < 4 * kWtabStride; i += blockDim.x) g_wtab[i] = src[i];
+    for (int i = threadIdx.x; i < kWtabSize; i += blockDim.x) g_wtab[i] = src[i];
     __syncthreads();
 }
 
 MP_DEV d2v wtab2(int k) {   // entries k, k+1 (k even)
     return *(volatile const __attribute__((address_space(3))) d2v *)&g_wtab[k];
 }
+MP_DEV double wtab_theta(int kind, int i) { return g_wtab[kind * kWtabStride + kWtabTheta + i]; }
 
 // p <- (p*x + c[k])*x + c[k+1] on all N chains
 template <int N>
@@ -429,6 +430,30 @@ MP_DEV Phi5<N> phi12345(const Vd<N> &z) {
         }
     }
     return r;
+}
+
+// phi_6(z) next to a Phi5 of the same z (the Mdisc step, once per tile): Taylor series below |z| = 1/2 (12 terms, < 1e-16
+// relative), the recurrence phi_6 = (phi_5 - 1/5!)/z elsewhere.
+template <int N>
+MP_DEV Vd<N> phi6(const Vd<N> &z, const Phi5<N> &p) {
+    Vd<N> s;
+    FORN s[i] = 1.0 / 355687428096000.0;      // 1/17!
+    horner(s, z, 1.0 / 20922789888000.0);     // 1/16!
+    horner(s, z, 1.0 / 1307674368000.0);      // 1/15!
+    horner(s, z, 1.0 / 87178291200.0);        // 1/14!
+    horner(s, z, 1.0 / 6227020800.0);         // 1/13!
+    horner(s, z, 1.0 / 479001600.0);          // 1/12!
+    horner(s, z, 1.0 / 39916800.0);           // 1/11!
+    horner(s, z, 1.0 / 3628800.0);            // 1/10!
+    horner(s, z, 1.0 / 362880.0);             // 1/9!
+    horner(s, z, 1.0 / 40320.0);              // 1/8!
+    horner(s, z, 1.0 / 5040.0);               // 1/7!
+    horner(s, z, 1.0 / 720.0);                // 1/6!
+    Vd<N> zs;
+    FORN zs[i] = fabs(z[i]) < 0.5 ? 1.0 : z[i];
+    const Vd<N> rz = rcp_fast(zs);
+    FORN s[i] = fabs(z[i]) < 0.5 ? s[i] : (p.p5[i] - 1.0 / 120.0) * rz[i];
+    return s;
 }
 
 // The quadrature in node form: c_k = sum_m W[k][m] phi_{m+1}(z), increment = h * sum_k c_k v_k for the quartic through

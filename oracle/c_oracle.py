@@ -132,7 +132,7 @@ def lnlike(cfg, pars, tgrid, x, y, yerr):
 
 def lnprob_batch(cfg, pars, tgrid, x, y, yerr, lower=None, upper=None, log_mask=0, mode="fixed", spl=4, want_tiles=False):
     """(lnprob[n], status[n]) in sampler coordinates (box prior + un-logging per log_mask).  mode "fixed": every grid
-    interval is a step (after the sub-stepped first 32 intervals); "adaptive": tiles of 64*spl steps over 1, 2 or 4
+    interval is a step (after the sub-stepped first 32 intervals); "adaptive": tiles of 64*spl steps over 1, 2, 4 or 8
     intervals, the product default (mp_oracle.c mpo_trajectory_mode).  want_tiles: also [n][3] = tile solves, tiles cut
     short or redone, steps kept."""
     pars = np.atleast_2d(np.ascontiguousarray(pars, dtype=np.float64))

@@ -346,6 +346,17 @@ static double hermite_d(double th, double h, double y0, double d0, double y1, do
     return (h * d0 + th * (2.0 * (3.0 * D - h * (2.0 * d0 + d1)) + th * 3.0 * (h * (d0 + d1) - 2.0 * D))) / h;
 }
 
+/* cubic Lagrange interpolation on four nodes (values only) */
+static double lagrange4(const double x[4], const double y[4], double t) {
+    double p = 0.0;
+    for (int k = 0; k < 4; ++k) {
+        double l = 1.0;
+        for (int m = 0; m < 4; ++m) if (m != k) l *= (t - x[m]) / (x[k] - x[m]);
+        p += l * y[k];
+    }
+    return p;
+}
+
 /* quintic Hermite: values, first and second derivatives at both ends (Mdisc: its derivatives are analytic) */
 static double hermite5(double th, double h, double y0, double d0, double e0, double y1, double d1, double e1) {
     const double t2 = th * th, t3 = t2 * th, t4 = t3 * th, t5 = t4 * th;
@@ -369,7 +380,8 @@ static int branch_flags(const mpo_cfg *c, const wk *w, double Mdisc, double omeg
 /*
  * PRODUCTION SCHEME (what the HIP kernels implement): exponential Adams-Moulton of order 5 for both
  * equations (the source of the linear Mdisc equation is analytic) on geometric grids:
- *   Mdisc_{j+1} = e^{-z} Mdisc_j + h sum_m phi_{m+1}(-z) sum_k W5[k][m] Mdotfb(t_{j+1-k}),          z = h/tvisc
+ *   Mdisc_{j+1} = e^{-z} Mdisc_j + h Mdotfb(t_j) sum_k c_k (-x)^k phi_{k+1}(-z),   z = h/tvisc, x = h/(t_j + tfb),
+ *                 c_k = Gamma(k + 5/3)/Gamma(5/3), k = 0..5  (the power-law source expanded about the step start)
  *   omega_{j+1} = e^{h lam} omega_j + h sum_m phi_{m+1}(h lam) sum_k W5[k][m] (f_{j+1-k} - lam omega_{j+1-k})
  * with f_p = omega_dot(Mdisc_p, omega_p) and lam = d(omega_dot)/d(omega) frozen at the NEW point (implicit in omega_{j+1},
  * solved by fixed-point iteration).  The integration proceeds in TILES of 64*spl steps (one wavefront, spl steps per lane
@@ -377,7 +389,7 @@ static int branch_flags(const mpo_cfg *c, const wk *w, double Mdisc, double omeg
  *   - the first 32 grid intervals are covered with 1/8-interval sub-steps (the spin-up transient of heavy discs around
  *     strongly magnetised stars is faster than the output grid at t = 1 s);
  *   - mode 0 (FIXED): every later tile steps over single grid intervals;
- *   - mode 1 (ADAPTIVE, the product default): tiles step over 1, 2 or 4 grid intervals.  A tile at stride > 1 is kept only up
+ *   - mode 1 (ADAPTIVE, the product default): tiles step over 1, 2, 4 or 8 grid intervals.  A tile at stride > 1 is kept only up
  *     to the first lane in which (a) the solution changes the smooth branch of the right-hand side (Alfven-radius cap, torque
  *     arm: a kink no multistep formula can cross at a coarse step) or (b) the smoothness indicator
  *     120 |phi_5(h lam)| h |4th difference of (f - lam omega)| / omega (the formula's own error term) exceeds stride_tol; what follows is redone at stride 1.  Values at skipped grid points come
@@ -386,10 +398,12 @@ static int branch_flags(const mpo_cfg *c, const wk *w, double Mdisc, double omeg
  * (exact where the points coincide).  Start-up: Mdotfb is analytic (grid continued backwards); the missing (f, omega)
  * points continue points 0 and 1 linearly.  Failure ('flag'): the rotation parameter of an iterate at a step end exceeds
  * 0.27 in a tile at stride <= 1; at a coarser stride the tile is redone finer first.
+ * (The kernels additionally stop the sweeps of a coarse tile early when its first lanes show that nothing will be kept, and
+ * cut a tile whose sweeps are slow where they have converged; both lead to the same kind of redo as here.)
  */
 typedef struct { double t, M, dM, ddM, w, f; } mpo_node;
 typedef struct {
-    int tiles, tiles_pre, tiles_s1, tiles_s2, tiles_s4, tiles_cut;   /* tile solves by kind; tiles not (fully) kept */
+    int tiles, tiles_pre, tiles_s1, tiles_s2, tiles_s4, tiles_cut;   /* tile solves by kind (s4: stride >= 4); tiles not (fully) kept */
     int steps_kept;
 } mpo_stats;
 
@@ -419,7 +433,7 @@ int mpo_trajectory_mode(const mpo_cfg *c, const double *pars, int ndim, const do
     const int TILE = 64 * spl, nsteps = n - 1;
     const double q = exp(log(tgrid[n - 1] / tgrid[0]) / (double)nsteps);
     if (stride_tol <= 0.0) stride_tol = 1.0e-7;
-    if (max_stride <= 0) max_stride = 4;
+    if (max_stride <= 0) max_stride = 8;
     mpo_stats st_ = {0, 0, 0, 0, 0, 0, 0};
     for (int j = 0; j < n; ++j) { if (Mout) Mout[j] = NAN; if (Wout) Wout[j] = NAN; }
     mpo_node *nd = (mpo_node *)malloc(sizeof(mpo_node) * (size_t)(n + MPO_PRE_FINE * MPO_PRE_SUB + TILE + 8));
@@ -444,6 +458,9 @@ int mpo_trajectory_mode(const mpo_cfg *c, const double *pars, int ndim, const do
     int s = 1;           /* stride of the next grid tile */
     int last_was_pre = 0;
     int cool = 0;        /* tiles over single intervals for which the scaled indicator decides about coarsening */
+    int trouble = 0;     /* coarse tiles that kept nothing: after two of them the walker stays at strides <= 4 */
+    int opt_s = 0;       /* the stride that is tried after a calm tile over single intervals: lowered when such an attempt fails
+                            outright, raised when the indicator promotes a tile (0: max_stride) */
     while (status == MPO_OK && i0 < nsteps) {
         const int pre = i0 < pre_fine;
         const int after_pre = !pre && last_was_pre;
@@ -456,14 +473,14 @@ int mpo_trajectory_mode(const mpo_cfg *c, const double *pars, int ndim, const do
             s = 1;
         } else {
             if (mode == 0) s = 1;
-            while (s > 1 && ((nsteps - i0) % s != 0)) s /= 2;
+            /* (whole steps only; and at least three of them, for the dense output's four nodes) */
+            while (s > 1 && ((nsteps - i0) % s != 0 || (nsteps - i0) / s < 3)) s /= 2;
             nc = ((nsteps - i0) / s < TILE) ? (nsteps - i0) / s : TILE;
             Q = pow(q, (double)s);
         }
         double W5[25];
         mpo_eam_weights(Q, P, W5);
         const double t0 = nd[nn - 1].t;
-        double Sh[4] = {mdot_fb(&w, t0), mdot_fb(&w, t0 / Q), mdot_fb(&w, t0 / (Q * Q)), mdot_fb(&w, t0 / (Q * Q * Q))};
         double fh[P], wh[P];
         fh[0] = fcur; wh[0] = om;
         int startup = (nn == 1);
@@ -481,10 +498,17 @@ int mpo_trajectory_mode(const mpo_cfg *c, const double *pars, int ndim, const do
             /* ---- Mdisc */
             const double S1 = mdot_fb(&w, tJ1);
             double ez, ph[8], acc = 0.0;
-            phi_upto(-h / w.tvisc, &ez, ph, P);
-            for (int m = 0; m < P; ++m)
-                acc += ph[m] * (W5[0 * P + m] * S1 + W5[1 * P + m] * Sh[0] + W5[2 * P + m] * Sh[1] + W5[3 * P + m] * Sh[2] +
-                                W5[4 * P + m] * Sh[3]);
+            phi_upto(-h / w.tvisc, &ez, ph, 6);
+            /* the source is a power law of t + tfb: inside the step Mdotfb(tJ + theta h) = Mdotfb(tJ) (1 + theta x)^(-5/3),
+               x = h / (tJ + tfb) <= 1 - 1/Q; its binomial series integrates term by term against the exponential kernel,
+               int_0^1 e^{-z (1 - theta)} theta^k dtheta = k! phi_{k+1}(-z).  Terms up to x^5: where the step is much longer
+               than tvisc (phi_{k+1}(-z) -> 1/(k! z)) the series is the binomial series of (1 + x)^(-5/3) itself and the
+               first neglected term is 4 x^6 = 7e-12 at a stride of 8 grid intervals (1e-13 at 4). */
+            {
+                const double x = h / (tJ + w.tfb);
+                acc = mdot_fb(&w, tJ) * (ph[0] + x * (-(5.0 / 3.0) * ph[1] + x * ((40.0 / 9.0) * ph[2] +
+                                         x * (-(440.0 / 27.0) * ph[3] + x * ((6160.0 / 81.0) * ph[4] - x * (104720.0 / 243.0) * ph[5])))));
+            }
             const double M1 = ez * Mt + h * acc;
             /* ---- omega: fixed-point iteration on the implicit step */
             double wn = ot + h * fh[0], fnew = 0.0, lam = 0.0, Nv[P];
@@ -521,7 +545,6 @@ int mpo_trajectory_mode(const mpo_cfg *c, const double *pars, int ndim, const do
                                             : 120.0 * fabs(ph[4]) * h * fabs(Nv[0] - 4.0 * Nv[1] + 6.0 * Nv[2] - 4.0 * Nv[3] + Nv[4]) / fabs(wn);
             tn[J] = (mpo_node){tJ1, M1, S1 - M1 / w.tvisc, mdot_fb_dt(&w, tJ1) - (S1 - M1 / w.tvisc) / w.tvisc, wn, fnew};
             if (startup && J == 0) { f1 = fnew; w1 = wn; }
-            Sh[3] = Sh[2]; Sh[2] = Sh[1]; Sh[1] = Sh[0]; Sh[0] = S1;
             for (int k = P - 2; k >= 1; --k) { fh[k] = fh[k - 1]; wh[k] = wh[k - 1]; }
             fh[0] = fnew; wh[0] = wn;
             Mt = M1; ot = wn;
@@ -534,8 +557,10 @@ int mpo_trajectory_mode(const mpo_cfg *c, const double *pars, int ndim, const do
         if (pre || s == 1) {
             if (tstatus != MPO_OK) { status = tstatus; break; }            /* a verdict only at stride <= 1 */
         } else {
-            /* the tile tried at a coarse stride right behind the sub-steps has no calm predecessor to vouch for it: a tenth */
-            const double tile_tol = after_pre ? 0.1 * stride_tol : stride_tol;
+            /* the tile tried at a coarse stride right behind the sub-steps has no calm predecessor to vouch for it: a tenth;
+               steps over 8 intervals: likewise (with the plain bound the prior-wide golden points come out up to 1.0e-7 off
+               the reference's tight values instead of 0.5e-7; with 0.3 one soak walker in 32 768 is 1.01e-7 off the fixed steps) */
+            const double tile_tol = (after_pre || s >= 8) ? 0.1 * stride_tol : stride_tol;
             int first = (nsolved < nc) ? nsolved / spl : 64;
             for (int l = 0; l < first && l * spl < nc; ++l)
                 for (int e = l * spl; e < (l + 1) * spl && e < nsolved; ++e)
@@ -544,7 +569,15 @@ int mpo_trajectory_mode(const mpo_cfg *c, const double *pars, int ndim, const do
             if (first < 64) {
                 ++st_.tiles_cut;
                 if (first < 2 * MPO_MIN_KEEP) cool = 3;                      /* a coarse attempt that failed early */
-                if (first < MPO_MIN_KEEP) { s = 1; continue; }               /* nothing worth keeping: redo at stride 1 */
+                if (first < MPO_MIN_KEEP) {
+                    /* nothing worth keeping: redone at the next finer stride at once (over single intervals after a kink) */
+                    int kink = 0;
+                    for (int e = 0; e < MPO_MIN_KEEP * spl && e < nsolved; ++e) kink |= brk[e];
+                    opt_s = s / 2 > 2 ? s / 2 : 2;
+                    ++trouble;
+                    s = (s > 2 && !kink) ? s / 2 : 1;
+                    continue;
+                }
                 keep = first * spl;
                 next_s = 1;                                                  /* the offending region gets single intervals */
             }
@@ -559,23 +592,31 @@ int mpo_trajectory_mode(const mpo_cfg *c, const double *pars, int ndim, const do
                    otherwise the coarse stride is simply tried (the tile is cut where it does not hold): the indicator of
                    a tile whose sweeps stopped at the tolerance carries their residual, amplified by the 4th difference */
                 if (lastbrk < 0) {
-                    if (cool > 0) { --cool; next_s = (imax * 2048.0 < stride_tol) ? 4 : (imax * 64.0 < stride_tol) ? 2 : 1; }
-                    else next_s = (imax > stride_tol) ? 1 : 4;
+                    if (cool > 0) {
+                        --cool;
+                        next_s = (imax * 65536.0 < stride_tol) ? 8 : (imax * 2048.0 < stride_tol) ? 4 : (imax * 64.0 < stride_tol) ? 2 : 1;
+                    } else next_s = (imax > stride_tol) ? 1 : (opt_s ? opt_s : max_stride);
                 }
                 else {
                     /* a kink inside this tile: the history of a coarse successor must lie behind it */
                     const int first_clean = (lastbrk + 2) * spl, tail = keep - first_clean;   /* steps after the kink lane + 1 */
                     for (int e = first_clean > 0 ? first_clean : 0; e < keep; ++e) if (ind[e] > ipost) ipost = ind[e];
-                    if (tail >= 3 * 4 + spl && ipost * 2048.0 < stride_tol) next_s = 4;
+                    if (tail >= 3 * 8 + spl && ipost * 65536.0 < stride_tol) next_s = 8;
+                    else if (tail >= 3 * 4 + spl && ipost * 2048.0 < stride_tol) next_s = 4;
                     else if (tail >= 3 * 2 + spl && ipost * 64.0 < stride_tol) next_s = 2;
                     else next_s = 1;
                 }
-            } else if (s == 2) next_s = (imax * 64.0 < stride_tol) ? 4 : 2;
+            } else {
+                next_s = (imax * 64.0 < stride_tol && 2 * s <= max_stride) ? 2 * s : s;
+                if (opt_s && next_s > opt_s) opt_s = next_s;
+            }
             if (next_s > max_stride) next_s = max_stride;
+            if (trouble >= 2 && next_s > 4) next_s = 4;
         }
         if (pre) next_s = (mode == 1 && sub_done + keep >= pre_fine * MPO_PRE_SUB) ? max_stride : 1;   /* optimistic after the sub-steps */
         /* ---- commit the kept steps: nodes, and the grid points they contain */
         mpo_node prev = nd[nn - 1];
+        const mpo_node tile_start = prev;
         for (J = 0; J < keep; ++J) {
             if (pre) {
                 const int k = sub_done + J + 1;
@@ -583,14 +624,34 @@ int mpo_trajectory_mode(const mpo_cfg *c, const double *pars, int ndim, const do
             } else {
                 const int ib = i0 + J * s;
                 const double h = tn[J].t - prev.t;
+                /* N[0] = the tile's start, N[j + 1] = step end j: the four nodes around this step (first / last step of the
+                   kept part: the first / last four) */
+#define NODE(j) ((j) == 0 ? &tile_start : &tn[(j) - 1])
+                int l0 = J - 1;
+                if (l0 + 3 > keep) l0 = keep - 3;
+                if (l0 < 0) l0 = 0;
                 for (int i = 1; i < s; ++i) {
-                    const double th = (tgrid[ib + i] - prev.t) / h;
-                    /* quintic while the step resolves the viscous time; beyond, the derivatives of the quasi-steady Mdisc are
-                       differences of nearly equal terms (rounding amplified by h/tvisc): the cubic, good to 2e-10 on a power law */
-                    if (Mout) Mout[ib + i] = (h / w.tvisc < 1.0) ? hermite5(th, h, prev.M, prev.dM, prev.ddM, tn[J].M, tn[J].dM, tn[J].ddM)
-                                                                 : hermite(th, h, prev.M, prev.dM, tn[J].M, tn[J].dM);
+                    const double tg = tgrid[ib + i], th = (tg - prev.t) / h;
+                    /* Mdisc: the quintic while the step resolves the viscous time.  Beyond, Mdisc follows the fallback rate
+                       quasi-steadily and dMdisc/dt = Mdotfb - Mdisc/tvisc, a difference of nearly equal terms, carries the
+                       node's rounding amplified by h/tvisc: the smooth ratio Mdisc / (tvisc Mdotfb) = 1 + O(tvisc/t) is
+                       interpolated instead, through four node values (1.7e-10 at a stride of 8 where h = tvisc, falling as 1/t;
+                       the two-node cubic in Mdisc itself is 3e-9 off there).  Fewer than three kept steps: that cubic. */
+                    if (Mout) {
+                        if (h / w.tvisc < 1.0) Mout[ib + i] = hermite5(th, h, prev.M, prev.dM, prev.ddM, tn[J].M, tn[J].dM, tn[J].ddM);
+                        else if (keep >= 3) {
+                            double xl[4], rl[4];
+                            for (int k = 0; k < 4; ++k) {
+                                const mpo_node *nk = NODE(l0 + k);
+                                xl[k] = nk->t;
+                                rl[k] = nk->M / (nk->M + w.tvisc * nk->dM);              /* Mdisc / (tvisc Mdotfb) at the node */
+                            }
+                            Mout[ib + i] = lagrange4(xl, rl, tg) * w.tvisc * mdot_fb(&w, tg);
+                        } else Mout[ib + i] = hermite(th, h, prev.M, prev.dM, tn[J].M, tn[J].dM);
+                    }
                     if (Wout) Wout[ib + i] = hermite(th, h, prev.w, prev.f, tn[J].w, tn[J].f);
                 }
+#undef NODE
                 if (Mout) Mout[ib + s] = tn[J].M;
                 if (Wout) Wout[ib + s] = tn[J].w;
             }

@@ -11,7 +11,7 @@ lp.handle.tile_log(True)
 rng = np.random.default_rng(1)
 P = np.array([1.0, 5.0, -3.0, 2.0, -1.0, 0.0]) + 1e-4 * rng.standard_normal((1024, 6))
 wide = lo + (hi - lo) * rng.random((1024, 6))
-def fmt(log): return " ".join(f"{'P124'[k]}:{s}:{l}:{w:x}" for k, s, l, w in log)
+def fmt(log): return " ".join(f"{'P1248'[k]}:{s}:{l}:{w:x}" for k, s, l, w in log)
 lp(P); print("near-truth walker 0:", fmt(lp.handle.last_tile_log(0)))
 out, st = lp.handle.lnprob_batch(wide, want_status=True)
 sw = lp.handle.last_sweeps(1024)
@@ -20,6 +20,6 @@ for i in range(1024):
     if st[i] != 0: continue
     for k, s, l, w_ in lp.handle.last_tile_log(i):
         hist.setdefault(k, []).append(s)
-print("prior-wide: sweeps per tile by kind:", {('P124'[k]): (len(v), round(float(np.mean(v)), 2), int(np.max(v))) for k, v in sorted(hist.items())})
+print("prior-wide: sweeps per tile by kind:", {('P1248'[k]): (len(v), round(float(np.mean(v)), 2), int(np.max(v))) for k, v in sorted(hist.items())})
 for i in np.argsort(sw)[::-1][:6]:
     print(f"walker {i} status {st[i]} sweeps {sw[i]} pars {np.round(wide[i], 3).tolist()}:", fmt(lp.handle.last_tile_log(i)))

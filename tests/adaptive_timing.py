@@ -15,7 +15,7 @@ rng = np.random.default_rng(1)
 for n in (512, 1024, 2048, 4096, 8192):
     P = np.array(truth) + 1e-4 * rng.standard_normal((n, 6))
     wide = lo + (hi - lo) * rng.random((n, 6))
-    for ms in (4, 1):
+    for ms in (8, 4):
         lp = LogProb(*data, max_stride=ms)
         for nm, X in (("near", P), ("wide", wide)):
             dP = torch.from_numpy(X).cuda()

@@ -67,19 +67,25 @@ def pytest_configure(config):
 
 
 def _gpu_count():
-    """HIP devices visible to this process, asked of the runtime directly (no torch import, no product code)."""
-    import ctypes
-    for name in ("libamdhip64.so", "libamdhip64.so.7", "/opt/rocm/lib/libamdhip64.so"):
-        try:
-            hip = ctypes.CDLL(name)
-        except OSError:
-            continue
-        n = ctypes.c_int(0)
-        try:
-            return n.value if hip.hipGetDeviceCount(ctypes.byref(n)) == 0 else 0
-        except Exception:  # noqa: BLE001
-            return 0
-    return 0
+    """HIP devices visible, asked of the runtime in a CHILD process (no torch import, no product code): a second HIP
+    runtime initialised in this process would leave the one the product shares with torch without a device."""
+    import subprocess
+    probe = ("import ctypes\n"
+             "for name in ('libamdhip64.so', 'libamdhip64.so.7', '/opt/rocm/lib/libamdhip64.so'):\n"
+             "    try:\n"
+             "        hip = ctypes.CDLL(name)\n"
+             "    except OSError:\n"
+             "        continue\n"
+             "    n = ctypes.c_int(0)\n"
+             "    print(n.value if hip.hipGetDeviceCount(ctypes.byref(n)) == 0 else 0)\n"
+             "    break\n"
+             "else:\n"
+             "    print(0)\n")
+    try:
+        out = subprocess.run([sys.executable, "-c", probe], capture_output=True, text=True, timeout=120).stdout.split()
+        return int(out[-1]) if out else 0
+    except Exception:  # noqa: BLE001
+        return 0
 
 
 def pytest_collection_modifyitems(config, items):

@@ -64,7 +64,7 @@ def test_every_kernel_variant_against_the_c_oracle(gsynth, tarr):
 
     summary = {"n": N_SOAK, "oracle_status_counts": np.bincount(rst, minlength=4).tolist(), "variants": {}}
     # strict: sweep tolerance 1e-9 and every grid interval a step, i.e. the scheme the serial C restatement integrates
-    # (mode 0); product defaults: sweep tolerance 1e-7, steps over 1, 2 or 4 grid intervals (include/magprop_amd.h)
+    # (mode 0); product defaults: sweep tolerance 1e-7, steps over 1, 2, 4 or 8 grid intervals (include/magprop_amd.h)
     for batch, label, env in ((256, "4 steps per lane, small batches", {}),
                               (1024, "4 steps per lane", {}),
                               (4096, "2 steps per lane", {}),

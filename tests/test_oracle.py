@@ -322,7 +322,7 @@ def test_lsoda_port_reference_cost_mode_gives_the_same_numbers(gsynth, tarr):
 
 @pytest.mark.parametrize("spl", [4, 2])
 def test_adaptive_stride_restatement(gsynth, gflag, gflag2, tarr, cfg, spl):
-    """The product's default mode restated serially (mpo_trajectory_mode, mode 1: tiles of 64*spl steps over 1, 2 or 4 grid
+    """The product's default mode restated serially (mpo_trajectory_mode, mode 1: tiles of 64*spl steps over 1, 2, 4 or 8 grid
     intervals, cut at kinks and fast features): same verdicts as the reference on every prior-wide golden point, values
     inside the same bounds as the fixed-step scheme, and a third of the tiles."""
     x, y, yerr = gsynth["Humped_x"], gsynth["Humped_y"], gsynth["Humped_yerr"]
