@@ -320,14 +320,15 @@ template <int SPL>
 MP_DEV double dense_mdisc_qs(const Walker &w, const TileImage<SPL> &im, int kind, int i, int J, int keep, double t) {
     const int l0 = max(min(J - 1, keep - 3), 0), variant = J - l0;     // nodes l0 .. l0 + 3; the step is [l0 + variant, + 1]
     const int base = kWtabDense + ((kind - 2) * 7 + (i - 1)) * 12 + variant * 4;
-    double r = 0.0;
+    Vd<4> M, S;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const double mk = im.M[l0 + k] * w.inv_tau;                   // Mdisc/tvisc; Mdotfb = dMdisc/dt + Mdisc/tvisc
-        r = fma(g_wtab[base + k], mk / (im.D[l0 + k] + mk), r);       // Mdisc / (tvisc Mdotfb) at the node
-    }
+    for (int k = 0; k < 4; ++k) { M[k] = im.M[l0 + k]; S[k] = fma(M[k], w.inv_tau, im.D[l0 + k]); }   // Mdotfb = dMdisc/dt + Mdisc/tvisc
+    const Vd<4> iS = rcp_fast(S);
+    double r = 0.0;                                                    // tvisc x the interpolated ratio
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r = fma(g_wtab[base + k], M[k] * iS[k], r);
     const Vd<1> tv{{t}};
-    return r * mdot_fb(w, tv)[0] / w.inv_tau;
+    return r * mdot_fb(w, tv)[0];
 }
 
 // (Mdisc, omega) at position p8 (in eighths of a grid interval) inside the kept part of the image of a tile of kind
