@@ -527,13 +527,26 @@ def main():
     if not a.no_mcmc and a.config != 5 and n_global % 2 == 0:
         p0 = (truth + 1.0e-4 * torch.randn(n_global, 6, dtype=torch.float64, device=dev, generator=gen)).cpu().numpy()
         es = EnsembleSampler(n_global, 6, x, y, yerr, seed=a.seed, device=c.dev_index)
+        half_step_launches = None
         if world == 1:
             es.run_mcmc(p0, 5, store=False)
             tm = time.perf_counter()
             es.run_mcmc(None, a.mcmc_steps, store=False)
             tm = time.perf_counter() - tm
-            note = "emcee-style stretch move, 2 fused kernel launches per step (propose+lnprob+accept+store)"
+            whole = 3 * (n_global // 2) <= 2 * es.handle.n_simd
+            note = ("emcee-style stretch move; a whole step per launch: the proposals of the first half and both candidate "
+                    "proposals of every walker of the second half (3/2 x walkers evaluations, a third of them discarded), then "
+                    "the decisions in emcee's order" if whole else
+                    "emcee-style stretch move, 2 fused kernel launches per step (propose+lnprob+accept+store)")
             acc = float(es.acceptance_fraction.mean())
+            if whole:   # the same chain with one launch per half-step (what larger ensembles get)
+                es2 = EnsembleSampler(n_global, 6, x, y, yerr, seed=a.seed, device=c.dev_index, whole_step=False)
+                es2.run_mcmc(p0, 5, store=False)
+                t2 = time.perf_counter()
+                es2.run_mcmc(None, a.mcmc_steps, store=False)
+                t2 = time.perf_counter() - t2
+                half_step_launches = n_global * a.mcmc_steps / t2
+                es2.close()
         else:
             dsam = DistributedEnsembleSampler(HipShardEngine(es, dev), via_host=(a.backend == "gloo"))
             dsam.run_mcmc(p0, 5, store=False)
@@ -551,6 +564,8 @@ def main():
             acc = float(np.mean(dsam.acceptance_fraction))
         mcmc = {"walkers": n_global, "steps": a.mcmc_steps, "walker_steps_per_sec": n_global * a.mcmc_steps / tm,
                 "ms_per_step": 1e3 * tm / a.mcmc_steps, "acceptance_fraction": acc, "note": note}
+        if world == 1 and half_step_launches:
+            mcmc["walker_steps_per_sec_one_launch_per_half_step"] = half_step_launches
         es.close()
 
     # ---- N = 1 extras: harder inputs for the same kernel, the reference's golden walkers, sustained run, config 1

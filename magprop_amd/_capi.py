@@ -23,7 +23,7 @@ EXPORTS = (
     "mp_abi_version", "mp_last_error", "mp_cfg_synth", "mp_cfg_lib", "mp_create", "mp_destroy",
     "mp_set_dataset", "mp_set_prior", "mp_lnprob_batch", "mp_lnprob_batch_dev", "mp_model_lc", "mp_rhs_batch",
     "mp_synchronize", "mp_device", "mp_stream", "mp_n_grid", "mp_last_mean_sweeps", "mp_last_mean_tiles",
-    "mp_sampler_create", "mp_sampler_destroy", "mp_sampler_set_positions", "mp_sampler_run", "mp_sampler_get_state",
+    "mp_sampler_create", "mp_sampler_destroy", "mp_sampler_set_positions", "mp_sampler_run", "mp_sampler_set_whole_step", "mp_sampler_get_state",
     "mp_sampler_get_bad", "mp_sampler_n_slots", "mp_sampler_row_doubles", "mp_sampler_halfstep_shard",
     "mp_sampler_halfstep_apply", "mp_sampler_state_ptrs", "mp_sweep_tol", "mp_n_simd", "mp_last_sweeps", "mp_last_tiles", "mp_tile_log", "mp_last_tile_log",
 )
@@ -131,6 +131,7 @@ def lib():
     L.mp_sampler_destroy.argtypes = [vp]
     L.mp_sampler_set_positions.argtypes = [vp, dp]
     L.mp_sampler_run.argtypes = [vp, C.c_int, dp, dp]
+    L.mp_sampler_set_whole_step.argtypes = [vp, C.c_int]
     L.mp_sampler_get_state.argtypes = [vp, dp, dp, i64p, i64p]
     L.mp_last_mean_sweeps.argtypes = [vp]
     L.mp_last_mean_sweeps.restype = C.c_double
@@ -155,7 +156,7 @@ def lib():
     L.mp_sampler_state_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
     for name in ("mp_destroy", "mp_set_dataset", "mp_set_prior", "mp_lnprob_batch", "mp_lnprob_batch_dev",
                  "mp_model_lc", "mp_rhs_batch", "mp_synchronize", "mp_device", "mp_n_grid", "mp_sampler_destroy",
-                 "mp_sampler_set_positions", "mp_sampler_run", "mp_sampler_get_state", "mp_sampler_get_bad",
+                 "mp_sampler_set_positions", "mp_sampler_run", "mp_sampler_set_whole_step", "mp_sampler_get_state", "mp_sampler_get_bad",
                  "mp_sampler_n_slots", "mp_sampler_row_doubles", "mp_sampler_halfstep_shard",
                  "mp_sampler_halfstep_apply", "mp_sampler_state_ptrs", "mp_n_simd"):
         getattr(L, name).restype = C.c_int

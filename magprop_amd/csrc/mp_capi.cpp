@@ -728,7 +728,8 @@ struct mp_sampler {
     double a = 2.0;
     uint64_t steps_done = 0;
     bool have_state = false;
-    DevBuf<double> d_pos, d_lnprob, d_chain, d_chain_lnp, d_bad;
+    DevBuf<double> d_pos, d_lnprob, d_chain, d_chain_lnp, d_bad, d_spec;
+    int whole_step = 1;   // mp_sampler_run: one launch per step where the ensemble is small enough (mp_sampler_set_whole_step)
     DevBuf<int64_t> d_acc;
     DevBuf<int32_t> d_perm, d_dsid, d_status;
     DevBuf<uint32_t> d_bad_count;
@@ -907,7 +908,12 @@ int mp_sampler_run(mp_sampler *s, int n_steps, double *chain, double *chain_lnpr
         chain ? std::max<size_t>(1, std::min<size_t>(perm_cap, (256u << 20) / (row * sizeof(double)))) : perm_cap);
     constexpr int kSub = 8;   // steps per batch of splits: the host draws the next batch while the GPU runs this one
     int rc;
-    if ((rc = ensure_scratch(h, s->n_total))) return rc;
+    // A whole step per launch (mp_kernels.hip stretch_step_kernel: 3 n/2 evaluations, a third of them speculative) while
+    // those fit the device two waves per SIMD; larger ensembles fill it with one half-step at a time.
+    const int n_slots = (s->n_walkers / 2) * s->n_ensembles;
+    const bool whole = s->whole_step && 3 * (int64_t)n_slots <= 2 * (int64_t)h->sh.n_simd;
+    if ((rc = ensure_scratch(h, whole ? std::max(s->n_total, 3 * n_slots) : s->n_total))) return rc;
+    if (whole && (rc = s->d_spec.ensure((size_t)3 * n_slots * (size_t)(s->ndim + mp::kSpecExtra)))) return rc;
     if (s->ext_stream_work) {   // sharded half-steps on a caller's stream may still be updating the state
         HIP_TRY(hipDeviceSynchronize());
         s->ext_stream_work = false;
@@ -927,6 +933,17 @@ int mp_sampler_run(mp_sampler *s, int n_steps, double *chain, double *chain_lnpr
             HIP_TRY(hipMemcpyAsync(s->d_perm.p + (size_t)sub * nt, perm + (size_t)sub * nt,
                                    (size_t)(sub_end - sub) * nt * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
             for (int st = sub; st < sub_end; ++st) {
+                if (whole) {
+                    mp::StretchArgs g = stretch_args(s, s->d_perm.p + (size_t)st * nt, s->steps_done + (uint64_t)st, 0);
+                    g.chain = chain ? s->d_chain.p : nullptr;
+                    g.chain_lnp = chain ? s->d_chain_lnp.p : nullptr;
+                    g.chain_row = st;
+                    g.spec = s->d_spec.p;
+                    int e = mp::launch_stretch_step(h->sh, g, h->stream);
+                    if (!e) e = mp::launch_stretch_step_commit(g, h->stream);
+                    if (e) return fail(MP_EHIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+                    continue;
+                }
                 for (int half = 0; half < 2; ++half) {
                     mp::StretchArgs g = stretch_args(s, s->d_perm.p + (size_t)st * nt, s->steps_done + (uint64_t)st, half);
                     g.chain = chain ? s->d_chain.p : nullptr;
@@ -951,6 +968,13 @@ int mp_sampler_run(mp_sampler *s, int n_steps, double *chain, double *chain_lnpr
         s->steps_done += (uint64_t)chunk;
         done += chunk;
     }
+    return MP_OK;
+}
+
+int mp_sampler_set_whole_step(mp_sampler *s, int enable) {
+    if (!s) return fail(MP_EINVAL, "mp_sampler_set_whole_step: NULL sampler");
+    Lock lock(s->h->mu);
+    s->whole_step = enable != 0;
     return MP_OK;
 }
 

@@ -125,6 +125,8 @@ struct StretchArgs {
     double *chain_lnp;      // [n_rows][n_total]
     double *upd;            // nullptr: update in place.  Else outcome rows [slots][ndim + 3] = (proposal, lnprob, accepted,
                             // status): written by stretch_kernel (row = slot - slot_lo), read by stretch_apply_kernel (row = slot)
+    double *spec;           // whole-step launches (stretch_step_kernel / stretch_step_commit_kernel): outcome rows
+                            // [3][slots][ndim + kSpecExtra], see mp_kernels.hip
     double *bad_log;        // [bad_cap][ndim] or nullptr: proposals inside the prior whose model failed (the reference's fbad file)
     uint32_t *bad_count;    // number of such proposals so far (may exceed bad_cap)
     uint32_t bad_cap;
@@ -163,5 +165,9 @@ int launch_rhs(const DevShared &sh, const RhsArgs &r, void *stream);
 int launch_lnprob(const DevShared &sh, const LaunchArgs &a, void *stream);
 int launch_stretch(const DevShared &sh, const StretchArgs &g, int n_blocks, void *stream);
 int launch_stretch_apply(const StretchArgs &g, void *stream);
+int launch_stretch_step(const DevShared &sh, const StretchArgs &g, void *stream);          // 3 * n_half * n_ensembles evaluations
+int launch_stretch_step_commit(const StretchArgs &g, void *stream);
+// columns behind the proposal in an outcome row of a whole-step launch
+constexpr int kSpecExtra = 6;   // lnprob, status, (ndim - 1) ln z, ln u, lnprob of the walker before the move, partner's slot
 
 }  // namespace mp

@@ -372,7 +372,7 @@ MP_DEV void image_state(const DevShared &sh, const Walker &w, const TileImage<SP
 template <bool CURVES, int SPL, bool LONG>
 MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, double (&par)[MP_MAX_NDIM],
                         TileImage<SPL> &im, const TimeTable<SPL> &tt, double *Lbuf, double &lnp_out, int &status_out,
-                        int &sweeps_out, int &tiles_out) {
+                        int &sweeps_out, int &tiles_out, int scratch_row = -1) {
     constexpr int kSPL = SPL, kTile = 64 * SPL, kMaxSweeps = kTile + kMaxSweepsMargin;
     const int lane = threadIdx.x & 63;
     MP_PHASE_DECL
@@ -433,7 +433,8 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
     const bool long_lc = (CURVES || LONG) && a.want_chi2 && dsd.n_obs > 64;
     const bool deferred = !CURVES && a.want_chi2;               // see "observations" below
     const size_t sc_stride = (size_t)sh.scratch_stride;
-    double *sc = sh.obs_scratch + (size_t)walker * 4 * sc_stride;   // [4][stride]: observations 64.. of this walker
+    // [4][stride]: observations 64.. of this walker (scratch_row: evaluations that share a walker index, mp_kernels.hip stretch_step_kernel)
+    double *sc = sh.obs_scratch + (size_t)(scratch_row >= 0 ? scratch_row : walker) * 4 * sc_stride;
     double obM[2] = {1.0e30, 1.0e30}, obW[2] = {1.0e3, 1.0e3};  // (Mdisc, omega) at the observation's bracketing grid points
     double chi = 0.0;
     int sweeps_total = 0, tiles_total = 0;

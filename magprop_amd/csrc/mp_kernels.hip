@@ -214,6 +214,142 @@ __global__ __launch_bounds__(256) void stretch_apply_kernel(const StretchArgs g)
     }
 }
 
+// ---------------------------------------------------------------- a whole stretch-move step in one launch
+// A half-step of a small ensemble leaves most of the chip idle: 512 proposals on the 1 024 SIMDs of an MI355X, and the second
+// half-step cannot start before the first has decided.  But everything the second half needs is known up front except those
+// decisions: walker k of the second half moves along the line to its partner j of the first half, who will stand either
+// where it stands now or at its own proposal Y_j, and Y_j is known before it is evaluated.  One launch therefore evaluates
+// the n/2 proposals of the first half AND, for every walker of the second half, BOTH candidate proposals (3 n/2 evaluations,
+// n/2 of them discarded); stretch_step_commit_kernel then takes the first half's decisions, picks the candidate that matches
+// the partner's outcome and decides on it.  The chain is the one the two half-step launches produce, bit for bit (same
+// random numbers, same arithmetic, same order of decisions).  Used when 3 n/2 waves fit the device two per SIMD.
+//
+// Block b of 3 * slots: type = b / slots (0: first half; 1: second half, partner where it stands; 2: second half, partner at
+// its proposal), slot = b % slots.  Outcome row [type][slot] = proposal[ndim], lnprob, status, (ndim - 1) ln z, ln u,
+// lnprob of the walker before the move, partner's slot.
+MP_DEV void stretch_draw(const StretchArgs &g, int half, int k, int n_comp, int &jc, double &zz, double &logu) {
+    uint32_t r[4], r2[4];
+    philox4x32_10((uint32_t)g.seed, (uint32_t)(g.seed >> 32), (uint32_t)g.step, (uint32_t)half, (uint32_t)k, 0u, r);
+    philox4x32_10((uint32_t)g.seed, (uint32_t)(g.seed >> 32), (uint32_t)g.step, (uint32_t)half, (uint32_t)k, 1u, r2);
+    jc = min((int)(u01(r[0], r[1]) * n_comp), n_comp - 1);
+    const double zr = add_rn(mul_rn(g.a - 1.0, u01(r[2], r[3])), 1.0);
+    zz = mul_rn(zr, zr) / g.a;
+    logu = log(u01(r2[0], r2[1]));
+}
+
+template <int SPL, bool LONG>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPL >= 4 ? 1 : 2, SPL >= 4 ? 1 : 2))) void stretch_step_kernel(const DevShared sh, const StretchArgs g) {
+    __shared__ TileImage<SPL> im;
+    __shared__ TimeTable<SPL> tt;
+    __shared__ double lds[1];
+    ktab_init();
+    wtab_init(sh.wtab);
+    time_table_init(sh, tt);
+    const int n_slots = g.n_half * g.n_ensembles;
+    const int type = (int)blockIdx.x / n_slots, gs = (int)blockIdx.x - type * n_slots;
+    const int half = type == 0 ? 0 : 1;
+    const int w_ens = gs / g.n_half, slot = gs - w_ens * g.n_half;
+    const int32_t *perm = g.perm + (size_t)w_ens * g.n_walkers;
+    const int base = w_ens * g.n_walkers;
+    const int n_comp = g.n_walkers - g.n_half;
+    const int k = base + perm[half * g.n_half + slot];
+    int jc;
+    double zz, logu;
+    stretch_draw(g, half, k, n_comp, jc, zz, logu);
+    const int j = base + perm[(1 - half) * g.n_half + jc];
+    double xj[MP_MAX_NDIM];
+#pragma unroll
+    for (int i = 0; i < MP_MAX_NDIM; ++i) xj[i] = i < g.ndim ? g.pos[(size_t)j * g.ndim + i] : 0.0;
+    bool skip = false;
+    if (type == 2) {
+        // the partner's own proposal of the first half-step (the arithmetic of its type-0 block, bit for bit)
+        int jcj;
+        double zzj, loguj;
+        stretch_draw(g, 0, j, n_comp, jcj, zzj, loguj);
+        const int jj = base + perm[g.n_half + jcj];
+        bool outside = false;
+#pragma unroll
+        for (int i = 0; i < MP_MAX_NDIM; ++i) {
+            const double xjj = i < g.ndim ? g.pos[(size_t)jj * g.ndim + i] : 0.0;
+            xj[i] = sub_rn(xjj, mul_rn(sub_rn(xjj, xj[i]), zzj));
+            if (g.target == 0 && i < sh.n_prior && (!(xj[i] >= sh.lower[i]) || !(xj[i] <= sh.upper[i]))) outside = true;
+        }
+        skip = outside;   // a proposal outside the prior box is never accepted: this candidate cannot be the one
+    }
+    double par[MP_MAX_NDIM], prop[MP_MAX_NDIM];
+#pragma unroll
+    for (int i = 0; i < MP_MAX_NDIM; ++i) {
+        const double xk = i < g.ndim ? g.pos[(size_t)k * g.ndim + i] : 0.0;
+        par[i] = sub_rn(xj[i], mul_rn(sub_rn(xj[i], xk), zz));
+        prop[i] = par[i];
+    }
+    LaunchArgs a{};
+    a.ds_id = g.ds_id;
+    a.ndim = g.ndim;
+    a.physical = 0;
+    a.want_chi2 = 1;
+    double lnp = -INFINITY;
+    int status = MP_STATUS_PRIOR, sweeps, tiles;
+    if (!skip) {
+        if (g.target == 1) {   // isotropic unit Gaussian: exercises the move itself (tests)
+            lnp = 0.0;
+            status = MP_STATUS_OK;
+#pragma unroll
+            for (int i = 0; i < MP_MAX_NDIM; ++i) lnp = i < g.ndim ? sub_rn(lnp, mul_rn(mul_rn(0.5, prop[i]), prop[i])) : lnp;
+        } else {
+            walker_eval<false, SPL, LONG>(sh, a, k, par, im, tt, lds, lnp, status, sweeps, tiles, (int)blockIdx.x);
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+        double *u = g.spec + (size_t)blockIdx.x * (g.ndim + kSpecExtra);
+        for (int i = 0; i < g.ndim; ++i) u[i] = prop[i];
+        u[g.ndim] = lnp;
+        u[g.ndim + 1] = (double)status;
+        u[g.ndim + 2] = mul_rn(g.ndim - 1.0, log(zz));
+        u[g.ndim + 3] = logu;
+        u[g.ndim + 4] = g.lnprob[k];
+        u[g.ndim + 5] = (double)jc;
+    }
+}
+
+// The decisions of a whole step from the outcome rows of stretch_step_kernel: one thread per walker.
+__global__ __launch_bounds__(256) void stretch_step_commit_kernel(const StretchArgs g) {
+    const int n_slots = g.n_half * g.n_ensembles, R = g.ndim + kSpecExtra;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= 2 * n_slots) return;
+    const int half = idx / n_slots, gs = idx - half * n_slots;
+    const int w_ens = gs / g.n_half, slot = gs - w_ens * g.n_half;
+    const int k = w_ens * g.n_walkers + g.perm[(size_t)w_ens * g.n_walkers + half * g.n_half + slot];
+    auto accepted = [&](const double *u) {   // emcee: lnpdiff = (ndim - 1) ln z + lnprob(proposal) - lnprob(walker) > ln u
+        return sub_rn(add_rn(u[g.ndim + 2], u[g.ndim]), u[g.ndim + 4]) > u[g.ndim + 3];
+    };
+    const double *u = g.spec + (size_t)gs * R;
+    if (half == 1) {
+        const double *u1 = g.spec + (size_t)(n_slots + gs) * R;
+        const int gs_j = w_ens * g.n_half + (int)u1[g.ndim + 5];                  // the partner's slot in the first half
+        const bool moved = accepted(g.spec + (size_t)gs_j * R);
+        u = moved ? g.spec + (size_t)(2 * n_slots + gs) * R : u1;
+    }
+    const bool accept = accepted(u);
+    const double lnp_old = u[g.ndim + 4];
+    if (accept) {
+        for (int i = 0; i < g.ndim; ++i) g.pos[(size_t)k * g.ndim + i] = u[i];
+        g.lnprob[k] = u[g.ndim];
+        g.n_accepted[k] += 1;
+    }
+    if (g.chain) {
+        double *c = g.chain + ((size_t)g.chain_row * g.n_total + k) * g.ndim;
+        for (int i = 0; i < g.ndim; ++i) c[i] = accept ? u[i] : g.pos[(size_t)k * g.ndim + i];
+        g.chain_lnp[(size_t)g.chain_row * g.n_total + k] = accept ? u[g.ndim] : lnp_old;
+    }
+    const int status = (int)u[g.ndim + 1];
+    if (g.bad_log && (status == MP_STATUS_FLAG || status == MP_STATUS_NONFINITE)) {
+        const unsigned slot_b = atomicAdd(g.bad_count, 1u);
+        if (slot_b < g.bad_cap)
+            for (int i = 0; i < g.ndim; ++i) g.bad_log[(size_t)slot_b * g.ndim + i] = u[i];
+    }
+}
+
 // ---------------------------------------------------------------- the right-hand side at arbitrary states
 // One state per lane, evaluated by the device functions the solver kernels use (mdot_fb, disc_point, omega_rhs):
 // dMdisc/dt = Mdotfb - Mdisc/tvisc (eta1 + eta2 = 1, code/synthetic_datasets/funcs.py:122-129) and domega/dt
@@ -287,6 +423,29 @@ int launch_stretch(const DevShared &sh, const StretchArgs &g, int n_blocks, void
         if (lng) hipLaunchKernelGGL((stretch_kernel<2, true>), grid, dim3(64), 0, st, sh, g);
         else hipLaunchKernelGGL((stretch_kernel<2, false>), grid, dim3(64), 0, st, sh, g);
     }
+    return (int)hipGetLastError();
+}
+
+int launch_stretch_step(const DevShared &sh, const StretchArgs &g, void *stream) {
+    const int n_blocks = 3 * g.n_half * g.n_ensembles;
+    if (n_blocks <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)n_blocks);
+    const bool lng = sh.scratch_stride > 0;
+    if ((sh.force_spl ? sh.force_spl : kernel_spl(sh, n_blocks)) == 4) {
+        if (lng) hipLaunchKernelGGL((stretch_step_kernel<4, true>), grid, dim3(64), 0, st, sh, g);
+        else hipLaunchKernelGGL((stretch_step_kernel<4, false>), grid, dim3(64), 0, st, sh, g);
+    } else {
+        if (lng) hipLaunchKernelGGL((stretch_step_kernel<2, true>), grid, dim3(64), 0, st, sh, g);
+        else hipLaunchKernelGGL((stretch_step_kernel<2, false>), grid, dim3(64), 0, st, sh, g);
+    }
+    return (int)hipGetLastError();
+}
+
+int launch_stretch_step_commit(const StretchArgs &g, void *stream) {
+    const int n = 2 * g.n_half * g.n_ensembles;
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(stretch_step_commit_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g);
     return (int)hipGetLastError();
 }
 

@@ -21,8 +21,10 @@ from . import _capi, engine, synth
 class EnsembleSampler:
     def __init__(self, nwalkers, ndim=6, x=None, y=None, yerr=None, variant="synth", GRBtype=None, seed=0, a=2.0,
                  datasets=None, lower="default", upper="default", log_mask=None, device=-1, target="posterior",
-                 fbad=None, sweep_tol=None, max_stride=None):
+                 fbad=None, sweep_tol=None, max_stride=None, whole_step=True):
         """One ensemble on dataset (x, y, yerr), or one ensemble per entry of `datasets` = [(x, y, yerr), ...].
+        whole_step: small ensembles run a whole step per launch (include/magprop_amd.h mp_sampler_set_whole_step; same
+        chain bit for bit as one launch per half-step, which False selects).
         fbad: file that receives the proposals whose model failed, like the reference's lnprob(…, fbad)
         (code/synthetic_datasets/mcmc_eqns.py:72-79); written after every run_mcmc call."""
         if nwalkers % 2 or nwalkers < 2:
@@ -61,6 +63,7 @@ class EnsembleSampler:
                                             C.c_double(a), self._target)
         if not self._s:
             raise _capi.MagpropAmdError("mp_sampler_create failed: " + _capi.last_error())
+        _capi.check(self._L.mp_sampler_set_whole_step(self._s, int(bool(whole_step))), "mp_sampler_set_whole_step")
         self.seed = int(seed)
         self._chain = None
         self._lnp = None

@@ -93,6 +93,44 @@ def test_humped_posterior_run(gsynth):
     assert np.all(np.abs(med - np.array(TRUTHS["Humped"])) < np.array([0.5, 1.0, 0.5, 0.5, 1.0, 1.0]))
 
 
+def test_whole_step_launch_equals_half_step_launches(gsynth):
+    """Small ensembles run a whole step per launch (the proposals of the first half plus both candidate proposals of every
+    walker of the second half, include/magprop_amd.h mp_sampler_set_whole_step): the chain, the acceptance counts and the
+    failed proposals are those of one launch per half-step, bit for bit."""
+    from magprop_amd import EnsembleSampler
+    rng = np.random.default_rng(31)
+    p0 = rng.normal(size=(256, 6)) * 0.1 + 3.0
+    runs = [EnsembleSampler(256, 6, target="gaussian", seed=9, whole_step=w) for w in (True, False)]
+    for s in runs:
+        s.run_mcmc(p0, 60)
+    assert np.array_equal(runs[0].get_chain(), runs[1].get_chain())
+    assert np.array_equal(runs[0].acceptance_fraction, runs[1].acceptance_fraction)
+    # posterior: one ensemble near the truth; four ensembles, each on its own dataset; walkers all over the prior box
+    # (failed proposals); a 600-point light curve (scratch rows: the two candidates of a walker must not share one)
+    sets = [(gsynth[n + "_x"], gsynth[n + "_y"], gsynth[n + "_yerr"]) for n in TYPES]
+    lo, hi = gsynth["prior_lower"], gsynth["prior_upper"]
+    xl = np.sort(10.0 ** rng.uniform(0.0, 6.0, 600))
+    yl = np.interp(xl, sets[1][0], sets[1][1])
+    cases = [("near truth", dict(x=sets[0][0], y=sets[0][1], yerr=sets[0][2]), 64,
+              np.array(TRUTHS["Humped"]) + 1.0e-4 * rng.standard_normal((64, 6))),
+             ("four ensembles", dict(datasets=sets), 32,
+              np.concatenate([np.array(TRUTHS[n]) + 1.0e-4 * rng.standard_normal((32, 6)) for n in TYPES])),
+             ("prior-wide", dict(x=sets[0][0], y=sets[0][1], yerr=sets[0][2]), 128, lo + (hi - lo) * rng.random((128, 6))),
+             ("long light curve", dict(x=xl, y=yl, yerr=0.2 * yl), 32,
+              np.array(TRUTHS["Classic"]) + 1.0e-4 * rng.standard_normal((32, 6)))]
+    for label, kw, nwalk, pos in cases:
+        out = []
+        for w in (True, False):
+            s = EnsembleSampler(nwalk, 6, seed=17, whole_step=w, **kw)
+            s.run_mcmc(pos, 40)
+            nbad, bad = s.get_bad()
+            out.append((s.get_chain(), s.get_log_prob(), s.acceptance_fraction, nbad, bad[np.lexsort(bad.T)] if len(bad) else bad))
+        for a_, b_ in zip(out[0], out[1]):
+            assert np.array_equal(a_, b_), label
+        if label == "prior-wide":
+            assert out[0][3] > 0                                   # failed proposals occurred and were logged alike
+
+
 def test_four_grb_ensembles_in_one_launch(gsynth):
     """config 5 shape: one ensemble per GRB type advanced together, each against its own dataset."""
     from magprop_amd import EnsembleSampler, LogProb
