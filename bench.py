@@ -355,7 +355,7 @@ def run_passes(c, config, scaling, steps, warmup, curve=False, nwalk=None, grb=N
     n_simd = lp.handle.n_simd
     variant = ("curve kernel, " if curve else "") + ("4 steps per lane, one wavefront per SIMD" if n_local <= n_simd
                                                       else "2 steps per lane, two wavefronts per SIMD")
-    variant += "; order-5 exponential Adams-Moulton, steps over 1/2/4 grid intervals (adaptive)"
+    variant += "; order-5 exponential Adams-Moulton, steps over 1/2/4/8 grid intervals (adaptive)"
     if config == 5:
         workload = (f"BASELINE config 5: four GRB types x {n_global // 4} walkers at truth+{a.spread:g}*randn, {len(n_obs_desc)} light "
                     f"curves of {n_obs_desc} points selected per walker, {n_global} walkers in one launch per pass")

@@ -104,11 +104,11 @@ typedef struct mp_model_cfg {
 } mp_model_cfg;
 
 /* Stride adaptivity of the solver: where the solution is smooth on the scale of the output grid the
- * order-5 formula steps over 2, 4 or 8 grid intervals at once and the states at the skipped grid points come from the cubic
- * Hermite interpolant of the step (<= 1e-11 relative); tiles that contain a kink of the right-hand side (Alfven-radius
- * cap, torque arm) or a fast transient are redone over single intervals.  Measured on the 6 256 golden prior-wide points:
- * same maximum deviation from the reference's tight-integrator values as with max_stride = 1 (5e-8), 13 instead of 40
- * tiles per walker. */
+ * order-5 formula steps over 2, 4 or 8 grid intervals at once and the states at the skipped grid points come from the
+ * step's dense output (<= 4e-10 relative); tiles that contain a kink of the right-hand side (Alfven-radius cap, torque
+ * arm) or a fast transient are cut there and continued finer.  Measured on the 6 256 golden prior-wide points: same
+ * maximum deviation from the reference's tight-integrator values as with max_stride = 1 (5e-8), 13.6 instead of 40 tiles
+ * per walker (9 near the truths). */
 #define MP_MAX_STRIDE_DEFAULT 8
 #define MP_STRIDE_TOL_DEFAULT 1.0e-7
 
@@ -198,7 +198,8 @@ int mp_rhs_batch(mp_handle *h, const double *pars, int ndim, const double *t, co
  * split per step, as driven by code/synthetic_datasets/synth_mcmc.py:175-185
  * (em.EnsembleSampler(Nwalk, Npars, lnprob, ...).run_mcmc(pos, Nstep)).  Positions, log-posteriors,
  * acceptance counters and the chain stay resident on the device; every half-step is ONE kernel launch that
- * proposes, evaluates the log-posterior, accepts/rejects and stores the chain row.
+ * proposes, evaluates the log-posterior, accepts/rejects and stores the chain row (small ensembles: a whole step per
+ * launch, mp_sampler_set_whole_step).
  *   n_walkers   walkers per ensemble (even, >= 2*ndim recommended as in emcee)
  *   n_ensembles independent ensembles advanced together (e.g. one per GRB dataset); ens_ds_id[e] is the
  *               dataset of ensemble e (NULL: dataset 0 for all)
@@ -272,8 +273,11 @@ double mp_last_mean_tiles(const mp_handle *h);
 /* total Newton sweeps of every walker of that batch (all tiles; 0 for walkers that never started); returns the count copied */
 int mp_last_sweeps(const mp_handle *h, int32_t *out, int n);
 /* Diagnostics of the solver: with mp_tile_log(h, 1) every later host-buffer batch records, per walker, one word per tile it
- * solved (the first MP_TILE_LOG of them): kind (0: 1/8-interval sub-steps, 1, 2, 3: steps over 1, 2, 4 grid intervals) |
- * sweeps << 4 | lanes kept << 16.  mp_last_tile_log copies walker i's words of the most recent batch; returns how many. */
+ * solved (the first MP_TILE_LOG of them): kind (0: 1/8-interval sub-steps, 1 .. 4: steps over 1, 2, 4, 8 grid intervals) |
+ * sweeps << 4 | lanes kept << 16 | why << 24 (bits: 1 a branch of the right-hand side changed inside the tile; 2 / 4 / 8 /
+ * 32 the smoothness indicator exceeded stride_tol / its 64th / 2048th / 65536th; 16 lanes had not converged when the
+ * sweeps were stopped; 64 the tile was given up after its second or third sweep).  mp_last_tile_log copies walker i's
+ * words of the most recent batch; returns how many. */
 #define MP_TILE_LOG 96
 int mp_tile_log(mp_handle *h, int enable);
 int mp_last_tile_log(const mp_handle *h, int walker, int32_t *out, int n);

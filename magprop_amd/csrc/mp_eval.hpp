@@ -457,8 +457,9 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
         int cool = 0;                            // tiles over single intervals for which the scaled indicator decides about coarsening
         int hold = 0, hold_kind = 0;             // tiles of kind hold_kind that stay there after the sweeps of the next coarser kind were slow
         int trouble = 0;                         // coarse tiles of this walker that were given up or kept nothing: after two of
-                                                 // them the walker stays at strides <= 4 (heavy discs around fast, strongly
-                                                 // magnetised stars: the sweeps of 2 048-interval tiles converge too slowly)
+                                                 // them stride 8 is no longer TRIED (heavy discs around fast, strongly magnetised
+                                                 // stars: the sweeps of 2 048-interval tiles converge too slowly), only reached
+                                                 // when the indicator of a full tile over 4 intervals promotes it
         int opt_kind = max_kind;                 // the kind that is tried after a calm tile over single intervals: lowered when
                                                  // such an attempt fails outright, raised when the indicator promotes a tile
         // Each lane owns kSPL consecutive steps of the tile: steps lane*kSPL + s, s = 0..kSPL-1.
@@ -802,7 +803,9 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
             // stride_tol / 64 and / 2048 (what it would be at twice / four times the step: 5th-order scaling, margin 2).
             int keep_lanes = 64, next_kind = kind, why = 0;   // why: diagnostics (tile log)
             {
-                bool brk = false, ind1 = false, ind64 = false, ind2048 = false, ind65536 = false;
+                bool brk = false, ind1 = false, ind64 = false, ind2048 = false, ind65536 = false, indp8 = false;
+                const double prom8 = 64.0 / sh.k4_tol_factor;   // a tile over 8 intervals is held to k4_tol_factor x the bound: its
+                                                                // promotion asks the same of the scaled indicator
 #pragma unroll
                 for (int s = 0; s < kSPL; ++s) {
                     const bool valid = lane * kSPL + s < nc;
@@ -815,9 +818,10 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                     ind64 = ind64 || 64.0 * d4 > lim;
                     ind2048 = ind2048 || 2048.0 * d4 > lim;
                     ind65536 = ind65536 || 65536.0 * d4 > lim;
+                    indp8 = indp8 || prom8 * d4 > lim;
                 }
                 const unsigned long long B = __ballot(brk), I1 = __ballot(ind1), I64 = __ballot(ind64), I2048 = __ballot(ind2048),
-                                         I65536 = __ballot(ind65536);
+                                         I65536 = __ballot(ind65536), Ip8 = __ballot(indp8);
                 const int full_lanes = (nc + kSPL - 1) / kSPL;                 // lanes that hold steps of this tile
                 why = (B != 0ull ? 1 : 0) | (I1 != 0ull ? 2 : 0) | (I64 != 0ull ? 4 : 0) | (I2048 != 0ull ? 8 : 0) | (unconv != 0ull ? 16 : 0) |
                       (I65536 != 0ull ? 32 : 0);
@@ -842,7 +846,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                         if (next_kind >= 2) { hold_kind = next_kind; hold = 3; }
                     } else if (kind < max_kind && nc == kTile) {
                         if (hold > 0 && kind == hold_kind) --hold;
-                        else next_kind = I64 == 0ull ? kind + 1 : kind;
+                        else next_kind = (kind == 3 ? Ip8 : I64) == 0ull ? kind + 1 : kind;
                         opt_kind = max(opt_kind, min(next_kind, max_kind));
                     }
                 } else if (unconv != 0ull) {                                    // kinds 0, 1 stopped early: the converged lanes
@@ -855,7 +859,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                     // difference, and kept stiff late-time stretches at single intervals for a dozen tiles.
                     if (B == 0ull) {
                         if (cool > 0) { --cool; next_kind = I65536 == 0ull ? 4 : (I2048 == 0ull ? 3 : (I64 == 0ull ? 2 : 1)); }
-                        else next_kind = I1 == 0ull ? opt_kind : 1;
+                        else next_kind = I1 == 0ull ? (trouble >= sh.trouble_limit ? min(opt_kind, 3) : opt_kind) : 1;
                     }
                     else {
                         // a kink inside this tile: the history of a coarse successor must lie behind it
@@ -868,7 +872,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                     }
                 }
                 if (kind == 0) next_kind = 4;   // after the sub-stepped tiles: optimistic (a tile that meets a fast feature is cut)
-                next_kind = min(next_kind, trouble >= sh.trouble_limit ? min(max_kind, 3) : max_kind);
+                next_kind = min(next_kind, max_kind);
             }
             MP_PHASE(5)
             const int keep = min(keep_lanes * kSPL, nc);                       // steps kept

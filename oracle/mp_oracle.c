@@ -458,7 +458,8 @@ int mpo_trajectory_mode(const mpo_cfg *c, const double *pars, int ndim, const do
     int s = 1;           /* stride of the next grid tile */
     int last_was_pre = 0;
     int cool = 0;        /* tiles over single intervals for which the scaled indicator decides about coarsening */
-    int trouble = 0;     /* coarse tiles that kept nothing: after two of them the walker stays at strides <= 4 */
+    int trouble = 0;     /* coarse tiles that kept nothing: after two of them stride 8 is no longer tried, only reached when the
+                            indicator of a full tile over 4 intervals promotes it */
     int opt_s = 0;       /* the stride that is tried after a calm tile over single intervals: lowered when such an attempt fails
                             outright, raised when the indicator promotes a tile (0: max_stride) */
     while (status == MPO_OK && i0 < nsteps) {
@@ -595,7 +596,10 @@ int mpo_trajectory_mode(const mpo_cfg *c, const double *pars, int ndim, const do
                     if (cool > 0) {
                         --cool;
                         next_s = (imax * 65536.0 < stride_tol) ? 8 : (imax * 2048.0 < stride_tol) ? 4 : (imax * 64.0 < stride_tol) ? 2 : 1;
-                    } else next_s = (imax > stride_tol) ? 1 : (opt_s ? opt_s : max_stride);
+                    } else {
+                        next_s = (imax > stride_tol) ? 1 : (opt_s ? opt_s : max_stride);
+                        if (trouble >= 2 && next_s > 4) next_s = 4;
+                    }
                 }
                 else {
                     /* a kink inside this tile: the history of a coarse successor must lie behind it */
@@ -607,11 +611,11 @@ int mpo_trajectory_mode(const mpo_cfg *c, const double *pars, int ndim, const do
                     else next_s = 1;
                 }
             } else {
-                next_s = (imax * 64.0 < stride_tol && 2 * s <= max_stride) ? 2 * s : s;
+                /* (a tile over 8 intervals is held to a tenth of the bound: its promotion asks the same of the scaled indicator) */
+                next_s = (imax * (s == 4 ? 640.0 : 64.0) < stride_tol && 2 * s <= max_stride) ? 2 * s : s;
                 if (opt_s && next_s > opt_s) opt_s = next_s;
             }
             if (next_s > max_stride) next_s = max_stride;
-            if (trouble >= 2 && next_s > 4) next_s = 4;
         }
         if (pre) next_s = (mode == 1 && sub_done + keep >= pre_fine * MPO_PRE_SUB) ? max_stride : 1;   /* optimistic after the sub-steps */
         /* ---- commit the kept steps: nodes, and the grid points they contain */
