@@ -558,9 +558,15 @@ def main():
             tt = torch.tensor([tm], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             tm = float(tt.item())
-            note = (f"walker-sharded stretch move: per half-step every rank runs the fused kernel over its {dsam.hi - dsam.lo} "
-                    f"of the {es.n_slots} proposals, ONE all-gather of the outcome rows ({es.row_doubles * 8} B each), commit "
-                    "on every rank; dependent launches, nothing overlapped")
+            if dsam.whole_step:
+                note = (f"walker-sharded stretch move, a whole step per launch: every rank evaluates its {dsam.hi - dsam.lo} of the "
+                        f"{es.step_blocks} blocks of a step (the first half's proposals and both candidate proposals of every walker "
+                        f"of the second half), ONE all-gather of the outcome rows per step ({es.step_row_doubles * 8} B each), "
+                        "commit on every rank; dependent launches, nothing overlapped")
+            else:
+                note = (f"walker-sharded stretch move: per half-step every rank runs the fused kernel over its {dsam.hi - dsam.lo} "
+                        f"of the {es.n_slots} proposals, ONE all-gather of the outcome rows ({es.row_doubles * 8} B each), commit "
+                        "on every rank; dependent launches, nothing overlapped")
             acc = float(np.mean(dsam.acceptance_fraction))
         mcmc = {"walkers": n_global, "steps": a.mcmc_steps, "walker_steps_per_sec": n_global * a.mcmc_steps / tm,
                 "ms_per_step": 1e3 * tm / a.mcmc_steps, "acceptance_fraction": acc, "note": note}

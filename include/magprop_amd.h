@@ -256,6 +256,22 @@ int mp_sampler_row_doubles(const mp_sampler *s);
 int mp_sampler_halfstep_shard(mp_sampler *s, int half, int slot_lo, int slot_hi, double *d_rows, void *stream);
 int mp_sampler_halfstep_apply(mp_sampler *s, int half, const double *d_rows, double *d_chain_row,
                               double *d_chain_lnp_row, void *stream);
+/*
+ * The same with a WHOLE step per launch and ONE all-gather per step (mp_sampler_set_whole_step describes the launch):
+ * a step has mp_sampler_step_blocks() = 3 * n_slots evaluations; every process runs
+ *     mp_sampler_step_shard(s, block_lo, block_hi, d_rows, stream)
+ * on its share of them, which writes one row of R' = mp_sampler_step_row_doubles() doubles per block to d_rows[b - block_lo]
+ * (proposal[ndim], its lnprob, status, (ndim - 1) ln z, ln u, the walker's lnprob before the move, its partner's slot);
+ * after the rows of all processes have been gathered every process commits the step with
+ *     mp_sampler_step_apply(s, d_rows, d_chain_row, d_chain_lnp_row, stream)
+ * (d_rows[3 * n_slots][R'], row index = block index).  Two launches and one collective per step instead of four and two;
+ * a third of the evaluations is discarded, so this pays while a rank's share of the blocks fits its device two wavefronts
+ * per SIMD (magprop_amd/distributed.py decides).  Same chain as the half-step protocol and as mp_sampler_run.
+ */
+int mp_sampler_step_blocks(const mp_sampler *s);
+int mp_sampler_step_row_doubles(const mp_sampler *s);
+int mp_sampler_step_shard(mp_sampler *s, int block_lo, int block_hi, double *d_rows, void *stream);
+int mp_sampler_step_apply(mp_sampler *s, const double *d_rows, double *d_chain_row, double *d_chain_lnp_row, void *stream);
 /* device pointers of the resident state: pos[n_total][ndim], lnprob[n_total] (read-only for the caller) */
 int mp_sampler_state_ptrs(mp_sampler *s, double **d_pos, double **d_lnprob);
 

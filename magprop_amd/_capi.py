@@ -25,7 +25,8 @@ EXPORTS = (
     "mp_synchronize", "mp_device", "mp_stream", "mp_n_grid", "mp_last_mean_sweeps", "mp_last_mean_tiles",
     "mp_sampler_create", "mp_sampler_destroy", "mp_sampler_set_positions", "mp_sampler_run", "mp_sampler_set_whole_step", "mp_sampler_get_state",
     "mp_sampler_get_bad", "mp_sampler_n_slots", "mp_sampler_row_doubles", "mp_sampler_halfstep_shard",
-    "mp_sampler_halfstep_apply", "mp_sampler_state_ptrs", "mp_sweep_tol", "mp_n_simd", "mp_last_sweeps", "mp_last_tiles", "mp_tile_log", "mp_last_tile_log",
+    "mp_sampler_halfstep_apply", "mp_sampler_step_blocks", "mp_sampler_step_row_doubles", "mp_sampler_step_shard",
+    "mp_sampler_step_apply", "mp_sampler_state_ptrs", "mp_sweep_tol", "mp_n_simd", "mp_last_sweeps", "mp_last_tiles", "mp_tile_log", "mp_last_tile_log",
 )
 ABI_VERSION = 3
 
@@ -154,11 +155,16 @@ def lib():
     L.mp_sampler_halfstep_shard.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp]
     L.mp_sampler_halfstep_apply.argtypes = [vp, C.c_int, vp, vp, vp, vp]
     L.mp_sampler_state_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
+    L.mp_sampler_step_blocks.argtypes = [vp]
+    L.mp_sampler_step_row_doubles.argtypes = [vp]
+    L.mp_sampler_step_shard.argtypes = [vp, C.c_int, C.c_int, vp, vp]
+    L.mp_sampler_step_apply.argtypes = [vp, vp, vp, vp, vp]
     for name in ("mp_destroy", "mp_set_dataset", "mp_set_prior", "mp_lnprob_batch", "mp_lnprob_batch_dev",
                  "mp_model_lc", "mp_rhs_batch", "mp_synchronize", "mp_device", "mp_n_grid", "mp_sampler_destroy",
                  "mp_sampler_set_positions", "mp_sampler_run", "mp_sampler_set_whole_step", "mp_sampler_get_state", "mp_sampler_get_bad",
                  "mp_sampler_n_slots", "mp_sampler_row_doubles", "mp_sampler_halfstep_shard",
-                 "mp_sampler_halfstep_apply", "mp_sampler_state_ptrs", "mp_n_simd"):
+                 "mp_sampler_halfstep_apply", "mp_sampler_step_blocks", "mp_sampler_step_row_doubles",
+                 "mp_sampler_step_shard", "mp_sampler_step_apply", "mp_sampler_state_ptrs", "mp_n_simd"):
         getattr(L, name).restype = C.c_int
     _lib = L
     return L

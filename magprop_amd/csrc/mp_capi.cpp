@@ -939,7 +939,7 @@ int mp_sampler_run(mp_sampler *s, int n_steps, double *chain, double *chain_lnpr
                     g.chain_lnp = chain ? s->d_chain_lnp.p : nullptr;
                     g.chain_row = st;
                     g.spec = s->d_spec.p;
-                    int e = mp::launch_stretch_step(h->sh, g, h->stream);
+                    int e = mp::launch_stretch_step(h->sh, g, 3 * n_slots, h->stream);
                     if (!e) e = mp::launch_stretch_step_commit(g, h->stream);
                     if (e) return fail(MP_EHIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
                     continue;
@@ -1054,6 +1054,63 @@ int mp_sampler_halfstep_apply(mp_sampler *s, int half, const double *d_rows, dou
     const int e = mp::launch_stretch_apply(g, stream);
     if (e) return fail(MP_EHIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
     if (half == 1) s->steps_done += 1;
+    return MP_OK;
+}
+
+// ---- the same for a whole step per launch (mp_kernels.hip stretch_step_kernel): the caller runs, per STEP,
+//        mp_sampler_step_shard(its share of the 3 * n_slots blocks) -> ONE all-gather of the rows -> mp_sampler_step_apply.
+int mp_sampler_step_blocks(const mp_sampler *s) { return s ? 3 * (s->n_walkers / 2) * s->n_ensembles : 0; }
+int mp_sampler_step_row_doubles(const mp_sampler *s) { return s ? s->ndim + mp::kSpecExtra : 0; }
+
+int mp_sampler_step_shard(mp_sampler *s, int block_lo, int block_hi, double *d_rows, void *stream) {
+    if (!s) return fail(MP_EINVAL, "mp_sampler_step_shard: NULL sampler");
+    if (!s->have_state) return fail(MP_ESTATE, "mp_sampler_step_shard: call mp_sampler_set_positions first");
+    const int n_blocks = 3 * (s->n_walkers / 2) * s->n_ensembles;
+    if (block_lo < 0 || block_hi > n_blocks || block_lo > block_hi) return fail(MP_EINVAL, "mp_sampler_step_shard: blocks [%d, %d) outside [0, %d)", block_lo, block_hi, n_blocks);
+    if (block_hi > block_lo && !d_rows) return fail(MP_EINVAL, "mp_sampler_step_shard: NULL row buffer");
+    mp_handle *h = s->h;
+    Lock lock(h->mu);
+    DeviceScope scope(h->device);
+    hipStream_t st = (hipStream_t)stream;
+    const int32_t *d_perm = nullptr;
+    int rc;
+    if ((rc = current_split(s, st, &d_perm)) || (rc = ensure_scratch(h, std::max(s->n_total, block_hi - block_lo)))) return rc;
+    s->ext_stream_work = true;
+    if (block_hi == block_lo) return MP_OK;
+    const bool uses_scratch = h->sh.scratch_stride > 0;
+    if (uses_scratch && h->scratch_busy && h->scratch_stream != st) HIP_TRY(hipStreamWaitEvent(st, h->scratch_done, 0));
+    mp::StretchArgs g = stretch_args(s, d_perm, s->steps_done, 0);
+    g.spec = d_rows;
+    g.slot_lo = block_lo;
+    const int e = mp::launch_stretch_step(h->sh, g, block_hi - block_lo, stream);
+    if (e) return fail(MP_EHIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+    if (uses_scratch) {
+        HIP_TRY(hipEventRecord(h->scratch_done, st));
+        h->scratch_stream = st;
+        h->scratch_busy = true;
+    }
+    return MP_OK;
+}
+
+int mp_sampler_step_apply(mp_sampler *s, const double *d_rows, double *d_chain_row, double *d_chain_lnp_row, void *stream) {
+    if (!s || !d_rows) return fail(MP_EINVAL, "mp_sampler_step_apply: bad argument");
+    if ((d_chain_row == nullptr) != (d_chain_lnp_row == nullptr)) return fail(MP_EINVAL, "mp_sampler_step_apply: chain row and lnprob row go together");
+    if (!s->have_state) return fail(MP_ESTATE, "mp_sampler_step_apply: call mp_sampler_set_positions first");
+    mp_handle *h = s->h;
+    Lock lock(h->mu);
+    DeviceScope scope(h->device);
+    const int32_t *d_perm = nullptr;
+    int rc;
+    if ((rc = current_split(s, (hipStream_t)stream, &d_perm))) return rc;
+    s->ext_stream_work = true;
+    mp::StretchArgs g = stretch_args(s, d_perm, s->steps_done, 0);
+    g.spec = const_cast<double *>(d_rows);
+    g.chain = d_chain_row;
+    g.chain_lnp = d_chain_lnp_row;
+    g.chain_row = 0;
+    const int e = mp::launch_stretch_step_commit(g, stream);
+    if (e) return fail(MP_EHIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+    s->steps_done += 1;
     return MP_OK;
 }
 

@@ -165,7 +165,7 @@ int launch_rhs(const DevShared &sh, const RhsArgs &r, void *stream);
 int launch_lnprob(const DevShared &sh, const LaunchArgs &a, void *stream);
 int launch_stretch(const DevShared &sh, const StretchArgs &g, int n_blocks, void *stream);
 int launch_stretch_apply(const StretchArgs &g, void *stream);
-int launch_stretch_step(const DevShared &sh, const StretchArgs &g, void *stream);          // 3 * n_half * n_ensembles evaluations
+int launch_stretch_step(const DevShared &sh, const StretchArgs &g, int n_blocks, void *stream);   // blocks [g.slot_lo, + n_blocks) of 3 * n_half * n_ensembles
 int launch_stretch_step_commit(const StretchArgs &g, void *stream);
 // columns behind the proposal in an outcome row of a whole-step launch
 constexpr int kSpecExtra = 6;   // lnprob, status, (ndim - 1) ln z, ln u, lnprob of the walker before the move, partner's slot

@@ -225,8 +225,9 @@ __global__ __launch_bounds__(256) void stretch_apply_kernel(const StretchArgs g)
 // random numbers, same arithmetic, same order of decisions).  Used when 3 n/2 waves fit the device two per SIMD.
 //
 // Block b of 3 * slots: type = b / slots (0: first half; 1: second half, partner where it stands; 2: second half, partner at
-// its proposal), slot = b % slots.  Outcome row [type][slot] = proposal[ndim], lnprob, status, (ndim - 1) ln z, ln u,
-// lnprob of the walker before the move, partner's slot.
+// its proposal), slot = b % slots.  Outcome row of block b = proposal[ndim], lnprob, status, (ndim - 1) ln z, ln u,
+// lnprob of the walker before the move, partner's slot; written at row b - slot_lo of g.spec (walker-sharded ensembles: every
+// rank evaluates its share of the blocks, the rows are all-gathered, stretch_step_commit_kernel runs on every rank).
 MP_DEV void stretch_draw(const StretchArgs &g, int half, int k, int n_comp, int &jc, double &zz, double &logu) {
     uint32_t r[4], r2[4];
     philox4x32_10((uint32_t)g.seed, (uint32_t)(g.seed >> 32), (uint32_t)g.step, (uint32_t)half, (uint32_t)k, 0u, r);
@@ -246,7 +247,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPL >= 4 ? 1
     wtab_init(sh.wtab);
     time_table_init(sh, tt);
     const int n_slots = g.n_half * g.n_ensembles;
-    const int type = (int)blockIdx.x / n_slots, gs = (int)blockIdx.x - type * n_slots;
+    const int blk = g.slot_lo + (int)blockIdx.x;                    // a launch covers blocks [slot_lo, slot_lo + gridDim.x) (sharded: a rank's share)
+    const int type = blk / n_slots, gs = blk - type * n_slots;
     const int half = type == 0 ? 0 : 1;
     const int w_ens = gs / g.n_half, slot = gs - w_ens * g.n_half;
     const int32_t *perm = g.perm + (size_t)w_ens * g.n_walkers;
@@ -426,8 +428,7 @@ int launch_stretch(const DevShared &sh, const StretchArgs &g, int n_blocks, void
     return (int)hipGetLastError();
 }
 
-int launch_stretch_step(const DevShared &sh, const StretchArgs &g, void *stream) {
-    const int n_blocks = 3 * g.n_half * g.n_ensembles;
+int launch_stretch_step(const DevShared &sh, const StretchArgs &g, int n_blocks, void *stream) {
     if (n_blocks <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)n_blocks);

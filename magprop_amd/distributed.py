@@ -116,6 +116,28 @@ class HipShardEngine:
         self.s.halfstep_apply(half, rows.data_ptr(), chain_row.data_ptr() if chain_row is not None else 0,
                               lnp_row.data_ptr() if lnp_row is not None else 0, stream=self._stream())
 
+    # whole-step protocol
+    @property
+    def step_blocks(self):
+        return self.s.step_blocks
+
+    @property
+    def step_row_doubles(self):
+        return self.s.step_row_doubles
+
+    def whole_step_ok(self, world):
+        """A rank's share of the 3/2 x walkers evaluations of a whole step fits its device two wavefronts per SIMD."""
+        return -(-self.s.step_blocks // world) <= 2 * self.s.handle.n_simd
+
+    def step_shard(self, lo, hi, rows):
+        assert rows.is_contiguous() and rows.dtype == torch.float64 and rows.shape[0] >= hi - lo
+        self.s.step_shard(lo, hi, rows.data_ptr() if hi > lo else 0, stream=self._stream())
+
+    def step_apply(self, rows, chain_row=None, lnp_row=None):
+        assert rows.is_contiguous() and rows.shape[0] >= self.step_blocks
+        self.s.step_apply(rows.data_ptr(), chain_row.data_ptr() if chain_row is not None else 0,
+                          lnp_row.data_ptr() if lnp_row is not None else 0, stream=self._stream())
+
     def state(self):
         """(pos, lnprob, n_accepted) as numpy arrays (synchronises)."""
         return self.s.get_last_sample()
@@ -137,15 +159,20 @@ class DistributedEnsembleSampler:
     restatement of the move).
     """
 
-    def __init__(self, engine, group=None, via_host=False, always_gather=False):
+    def __init__(self, engine, group=None, via_host=False, always_gather=False, whole_step=None):
+        """whole_step: None = a whole step per launch and ONE all-gather per step when the engine offers it and a rank's
+        share of the 3/2 x walkers evaluations fits its device (engine.whole_step_ok); False = one launch and one gather
+        per half-step (larger ensembles get that anyway).  Same chain either way."""
         self.engine = engine
         self.group = group
         self.via_host = via_host       # gather through host memory: gloo rehearsal with GPU engines
         self.always_gather = always_gather   # run the collective even in a group of one (exercises RCCL on a 1-GPU box)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        self.lo, self.hi, self.per = shard_range(engine.n_slots, self.rank, self.world)
-        R = engine.row_doubles
+        self.whole_step = (hasattr(engine, "step_shard") and engine.whole_step_ok(self.world)) if whole_step is None else bool(whole_step)
+        n_units = engine.step_blocks if self.whole_step else engine.n_slots        # what is sharded: blocks of a step / slots of a half
+        self.lo, self.hi, self.per = shard_range(n_units, self.rank, self.world)
+        R = engine.step_row_doubles if self.whole_step else engine.row_doubles
         dev = engine.device
         self.send = torch.zeros(self.per, R, dtype=torch.float64, device=dev)                 # this rank's outcome rows
         alone = self.world == 1 and not always_gather
@@ -173,6 +200,12 @@ class DistributedEnsembleSampler:
             chain = torch.empty(nsteps, e.ntotal, e.ndim, dtype=torch.float64, device=e.device)
             lnp = torch.empty(nsteps, e.ntotal, dtype=torch.float64, device=e.device)
         for step in range(nsteps):
+            if self.whole_step:
+                e.step_shard(self.lo, self.hi, self.send)
+                self._gather()     # row index == block index
+                e.step_apply(self.rows, chain[step] if store else None, lnp[step] if store else None)
+                self.iteration += 1
+                continue
             for half in (0, 1):
                 e.halfstep_shard(half, self.lo, self.hi, self.send)
                 self._gather()     # rank r's block lands at rows [r*per, (r+1)*per): row index == slot index (shard_range)

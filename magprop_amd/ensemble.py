@@ -172,6 +172,25 @@ class EnsembleSampler:
         if half == 1:
             self.iteration += 1
 
+    # whole-step protocol (include/magprop_amd.h mp_sampler_step_shard / _apply)
+    @property
+    def step_blocks(self):
+        return self._L.mp_sampler_step_blocks(self._s)
+
+    @property
+    def step_row_doubles(self):
+        return self._L.mp_sampler_step_row_doubles(self._s)
+
+    def step_shard(self, lo, hi, d_rows, stream=0):
+        _capi.check(self._L.mp_sampler_step_shard(self._s, int(lo), int(hi), C.c_void_p(d_rows or None), C.c_void_p(stream or None)),
+                    "mp_sampler_step_shard")
+
+    def step_apply(self, d_rows, d_chain_row=0, d_chain_lnp_row=0, stream=0):
+        _capi.check(self._L.mp_sampler_step_apply(self._s, C.c_void_p(d_rows), C.c_void_p(d_chain_row or None),
+                                                  C.c_void_p(d_chain_lnp_row or None), C.c_void_p(stream or None)),
+                    "mp_sampler_step_apply")
+        self.iteration += 1
+
     def get_last_sample(self):
         pos = np.empty((self.ntotal, self.ndim))
         lnp = np.empty(self.ntotal)

@@ -174,6 +174,78 @@ def apply_rows(pos, lnp, acc, perms, half, rows, n, chain_row=None, lnp_row=None
             lnp_row[k] = lnp[k]
 
 
+# ---------------------------------------------------------------- the whole-step protocol (include/magprop_amd.h:
+# mp_sampler_step_shard / mp_sampler_step_apply): block b of 3 * slots evaluates, type = b // slots,
+#   0: the proposal of slot b % slots of the first half; 1 / 2: the proposal of that slot of the second half with its partner
+#   of the first half where it stands / at the partner's own proposal.
+# Row = proposal, lnprob, status, (ndim - 1) ln z, ln u, lnprob of the walker before the move, partner's slot.
+def _draw(seed, step, half, k, n_comp, a):
+    r = philox4x32_10(seed & M32, seed >> 32, step, half, k, 0)
+    r2 = philox4x32_10(seed & M32, seed >> 32, step, half, k, 1)
+    jc = min(int(u01(r[0], r[1]) * n_comp), n_comp - 1)
+    zr = (a - 1.0) * u01(r[2], r[3]) + 1.0
+    with np.errstate(divide="ignore"):
+        logu = np.log(u01(r2[0], r2[1]))
+    return jc, zr * zr / a, logu
+
+
+def step_rows(pos, lnp, perms, seed, step, lo, hi, n, a=2.0, lnprob_fn=gaussian_lnprob):
+    """Outcome rows of blocks [lo, hi) of a whole step.  Reads pos / lnp, changes nothing."""
+    ndim = pos.shape[1]
+    half_n = n // 2
+    n_slots = half_n * len(perms)
+    n_comp = n - half_n
+    rows = np.zeros((hi - lo, ndim + 6))
+    for b in range(lo, hi):
+        typ, gs = divmod(b, n_slots)
+        half = 0 if typ == 0 else 1
+        e, slot = divmod(gs, half_n)
+        base, perm = e * n, perms[e]
+        k = base + perm[half * half_n + slot]
+        jc, zz, logu = _draw(seed, step, half, k, n_comp, a)
+        j = base + perm[(1 - half) * half_n + jc]
+        xj = pos[j]
+        if typ == 2:   # the partner's own proposal of the first half
+            jcj, zzj, _ = _draw(seed, step, 0, j, n_comp, a)
+            jj = base + perm[half_n + jcj]
+            xj = pos[jj] - (pos[jj] - pos[j]) * zzj
+        prop = xj - (xj - pos[k]) * zz
+        rows[b - lo, :ndim] = prop
+        rows[b - lo, ndim] = lnprob_fn(prop)
+        rows[b - lo, ndim + 2] = (ndim - 1.0) * np.log(zz)
+        rows[b - lo, ndim + 3] = logu
+        rows[b - lo, ndim + 4] = lnp[k]
+        rows[b - lo, ndim + 5] = jc
+    return rows
+
+
+def apply_step_rows(pos, lnp, acc, perms, rows, n, chain_row=None, lnp_row=None):
+    """Commit the gathered rows of a whole step (rows[block]) in emcee's order: the first half decides, every walker of the
+    second half takes the candidate that matches its partner's outcome and decides on it."""
+    ndim = pos.shape[1]
+    half_n = n // 2
+    n_slots = half_n * len(perms)
+
+    def accepted(u):
+        return (u[ndim + 2] + u[ndim]) - u[ndim + 4] > u[ndim + 3]
+    moved0 = [accepted(rows[gs]) for gs in range(n_slots)]
+    for half in range(2):
+        for gs in range(n_slots):
+            e, slot = divmod(gs, half_n)
+            k = e * n + perms[e][half * half_n + slot]
+            u = rows[gs]
+            if half == 1:
+                u1 = rows[n_slots + gs]
+                u = rows[2 * n_slots + gs] if moved0[e * half_n + int(u1[ndim + 5])] else u1
+            if accepted(u):
+                pos[k] = u[:ndim]
+                lnp[k] = u[ndim]
+                acc[k] += 1
+            if chain_row is not None:
+                chain_row[k] = pos[k]
+                lnp_row[k] = lnp[k]
+
+
 class NumpyShardEngine:
     """The engine protocol of magprop_amd.distributed.DistributedEnsembleSampler on CPU tensors (tests of the sharding,
     the gather layout and the commit order without a GPU)."""
@@ -206,6 +278,27 @@ class NumpyShardEngine:
                    None if chain_row is None else chain_row.numpy(), None if lnp_row is None else lnp_row.numpy())
         if half == 1:
             self.step += 1
+
+    # whole-step protocol
+    @property
+    def step_blocks(self):
+        return 3 * self.n_slots
+
+    @property
+    def step_row_doubles(self):
+        return self.ndim + 6
+
+    def whole_step_ok(self, world):
+        return True
+
+    def step_shard(self, lo, hi, rows):
+        self.calls += hi - lo
+        rows.numpy()[: hi - lo] = step_rows(self.pos, self.lnp, self._perms(), self.seed, self.step, lo, hi, self.n, self.a, self.fn)
+
+    def step_apply(self, rows, chain_row=None, lnp_row=None):
+        apply_step_rows(self.pos, self.lnp, self.acc, self._perms(), rows.numpy(), self.n,
+                        None if chain_row is None else chain_row.numpy(), None if lnp_row is None else lnp_row.numpy())
+        self.step += 1
 
     def state(self):
         return self.pos.copy(), self.lnp.copy(), self.acc.copy()

@@ -19,7 +19,8 @@ def run(rank, world, port, case, q):
     try:
         s = EnsembleSampler(case["nwalkers"], case["ndim"], datasets=case.get("datasets"), seed=case["seed"],
                             target=case["target"], device=0)
-        ds = DistributedEnsembleSampler(HipShardEngine(s, "cuda:0"), via_host=True)
+        ds = DistributedEnsembleSampler(HipShardEngine(s, "cuda:0"), via_host=True, whole_step=case.get("whole_step"))
+        assert ds.whole_step == bool(case.get("whole_step", True))
         c1, l1 = ds.run_mcmc(case["pos"], case["nsteps"] // 2)
         c2, l2 = ds.run_mcmc(None, case["nsteps"] - case["nsteps"] // 2)
         torch.cuda.synchronize()

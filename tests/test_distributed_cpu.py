@@ -90,29 +90,33 @@ def _start_positions():
     return np.random.default_rng(5).normal(size=(N_W * N_ENS, N_DIM)) * 2.0 + 1.0
 
 
-def _sampler_worker(rank, world, port, q):
+def _sampler_worker(rank, world, port, q, whole):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     sys.path.insert(0, ROOT)
     from magprop_amd.distributed import DistributedEnsembleSampler
     from oracle.stretch_oracle import NumpyShardEngine
     dist.init_process_group("gloo", rank=rank, world_size=world)
     eng = NumpyShardEngine(N_W, N_DIM, SEED, n_ensembles=N_ENS)
-    s = DistributedEnsembleSampler(eng)
+    s = DistributedEnsembleSampler(eng, whole_step=whole)
+    assert s.whole_step == whole
     chain, lnp = s.run_mcmc(_start_positions(), N_STEPS)
     q.put((rank, chain.numpy().copy(), lnp.numpy().copy(), s.acceptance_fraction.copy(), eng.calls, (s.lo, s.hi, s.per)))
     dist.barrier()
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("whole", [False, True])
 @pytest.mark.parametrize("world", [2, 3])
-def test_distributed_ensemble_sampler_equals_the_single_process_chain(world):
+def test_distributed_ensemble_sampler_equals_the_single_process_chain(world, whole):
     """Sharding the half-step's proposals over the ranks changes nothing: every rank ends with the chain of the
-    unsharded restatement of the move (oracle/stretch_oracle.run), bit for bit, having evaluated only its own block."""
+    unsharded restatement of the move (oracle/stretch_oracle.run), bit for bit, having evaluated only its own block.
+    whole: the whole-step protocol (one gather per step; the blocks of a step are the first half's proposals and both
+    candidate proposals of every walker of the second half: 3/2 x walkers evaluations, each exactly once across the group)."""
     from oracle import stretch_oracle as so
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29700 + (os.getpid() + world) % 200
-    procs = [ctx.Process(target=_sampler_worker, args=(r, world, port, q)) for r in range(world)]
+    port = 29700 + (os.getpid() + world + 7 * whole) % 200
+    procs = [ctx.Process(target=_sampler_worker, args=(r, world, port, q, whole)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=180) for _ in procs], key=lambda r: r[0])
@@ -121,20 +125,22 @@ def test_distributed_ensemble_sampler_equals_the_single_process_chain(world):
         assert p.exitcode == 0
     chain, lnp, acc = so.run(_start_positions(), N_STEPS, SEED, n_ensembles=N_ENS)
     n_slots = (N_W // 2) * N_ENS
+    units, launches = (3 * n_slots, 1) if whole else (n_slots, 2)   # what a launch shards, launches per step
     total_calls = 0
     for rank, c, l, af, calls, (lo, hi, per) in res:
         assert np.array_equal(c, chain) and np.array_equal(l, lnp)
         assert np.array_equal(af, acc / N_STEPS)
-        assert calls == (hi - lo) * 2 * N_STEPS and lo == min(rank * per, n_slots)
+        assert calls == (hi - lo) * launches * N_STEPS and lo == min(rank * per, units)
         total_calls += calls
-    assert total_calls == n_slots * 2 * N_STEPS                     # every proposal evaluated exactly once across the group
+    assert total_calls == units * launches * N_STEPS                # every evaluation exactly once across the group
 
 
-def test_distributed_ensemble_sampler_single_process_and_continuation():
+@pytest.mark.parametrize("whole", [False, True])
+def test_distributed_ensemble_sampler_single_process_and_continuation(whole):
     from magprop_amd.distributed import DistributedEnsembleSampler
     from oracle import stretch_oracle as so
     eng = so.NumpyShardEngine(N_W, N_DIM, SEED, n_ensembles=N_ENS)
-    s = DistributedEnsembleSampler(eng)
+    s = DistributedEnsembleSampler(eng, whole_step=whole)
     c1, l1 = s.run_mcmc(_start_positions(), 10)
     c2, l2 = s.run_mcmc(None, N_STEPS - 10)                          # continue from the resident state
     chain, lnp, acc = so.run(_start_positions(), N_STEPS, SEED, n_ensembles=N_ENS)

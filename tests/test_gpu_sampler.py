@@ -313,15 +313,18 @@ def test_sharded_sampler_gaussian_two_ranks_equal_the_fused_chain_and_the_oracle
     rng = np.random.default_rng(21)
     case = {"nwalkers": 66, "ndim": 3, "seed": 4242, "target": "gaussian", "nsteps": 40, "datasets": None,
             "pos": rng.normal(size=(66, 3)) * 1.5}
-    res = _sharded_case(case)                                  # one ensemble of 66 walkers: slots 0..32 split 17 / 16
     s = EnsembleSampler(66, 3, target="gaussian", seed=4242)
     s.run_mcmc(case["pos"], 40)
     ref_chain, ref_lnp, ref_acc = so.run(case["pos"], 40, 4242)
     assert np.array_equal(s.get_chain(), ref_chain)
-    for rank, chain, lnp, af, (lo, hi), _ in res:
-        assert np.array_equal(chain, ref_chain) and np.array_equal(lnp, ref_lnp), rank
-        assert np.array_equal(af, ref_acc / 40)
-    assert [r[4] for r in res] == [(0, 17), (17, 33)]
+    # one ensemble of 66 walkers: the 33 slots of a half-step split 17 / 16; the 99 blocks of a whole step (one gather per
+    # step: the first half's proposals and both candidates of every walker of the second half) split 50 / 49
+    for whole, ranges in ((False, [(0, 17), (17, 33)]), (True, [(0, 50), (50, 99)])):
+        res = _sharded_case(dict(case, whole_step=whole))
+        for rank, chain, lnp, af, (lo, hi), _ in res:
+            assert np.array_equal(chain, ref_chain) and np.array_equal(lnp, ref_lnp), (whole, rank)
+            assert np.array_equal(af, ref_acc / 40)
+        assert [r[4] for r in res] == ranges
 
 
 def test_sharded_sampler_posterior_two_ranks_equal_the_fused_chain(gsynth):
@@ -339,13 +342,14 @@ def test_sharded_sampler_posterior_two_ranks_equal_the_fused_chain(gsynth):
                           np.array(TRUTHS["Classic"]) + 1.0e-3 * rng.standard_normal((48, 6))])
     pos = np.clip(pos, gsynth["prior_lower"] + 1e-6, gsynth["prior_upper"] - 1e-6)
     case = {"nwalkers": 48, "ndim": 6, "seed": 99, "target": "posterior", "nsteps": 30, "datasets": sets, "pos": pos}
-    res = _sharded_case(case)
     s = EnsembleSampler(48, 6, datasets=sets, seed=99)
     s.run_mcmc(pos, 30)
     n_bad = s.get_bad()[0]
-    for rank, chain, lnp, af, (lo, hi), nb in res:
-        assert np.array_equal(chain, s.get_chain()) and np.array_equal(lnp, s.get_log_prob()), rank
-        assert np.array_equal(af, s.acceptance_fraction) and nb == n_bad
+    for whole in (False, True):                                # one gather per half-step / per step
+        res = _sharded_case(dict(case, whole_step=whole))
+        for rank, chain, lnp, af, (lo, hi), nb in res:
+            assert np.array_equal(chain, s.get_chain()) and np.array_equal(lnp, s.get_log_prob()), (whole, rank)
+            assert np.array_equal(af, s.acceptance_fraction) and nb == n_bad
     assert tarr[0] <= x[0]
 
 

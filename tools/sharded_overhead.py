@@ -26,15 +26,19 @@ rng = np.random.default_rng(1)
 for nwalk in (1024, 2048, 8192):
     pos = np.array([1, 5, -3, 2, -1, 0.0]) + 1e-4 * rng.standard_normal((nwalk, 6))
     steps = 200
-    a = EnsembleSampler(nwalk, 6, x, y, yerr, seed=3)
+    a = EnsembleSampler(nwalk, 6, x, y, yerr, seed=3)   # fused: a whole step per launch where it fits
     a.run_mcmc(pos, 5, store=False)
     t0 = time.perf_counter()
     a.run_mcmc(None, steps, store=False)
     t_fused = (time.perf_counter() - t0) / steps
     res = {}
-    for label, gather in (("commit only", False), ("RCCL all-gather + commit", True)):
+    for label, gather, whole in (("half-steps, commit only", False, False), ("half-steps, RCCL all-gather + commit", True, False),
+                                 ("whole steps, commit only", False, True), ("whole steps, RCCL all-gather + commit", True, True)):
         b = EnsembleSampler(nwalk, 6, x, y, yerr, seed=3)
-        d = DistributedEnsembleSampler(HipShardEngine(b, dev), always_gather=gather)
+        if whole and not HipShardEngine(b, dev).whole_step_ok(1):
+            b.close()
+            continue
+        d = DistributedEnsembleSampler(HipShardEngine(b, dev), always_gather=gather, whole_step=whole)
         d.run_mcmc(pos, 5, store=False)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
