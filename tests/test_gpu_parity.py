@@ -460,6 +460,41 @@ def test_rhs_vs_reference(mpa, co, grhs, name):
     engine.clear()
 
 
+@pytest.mark.parametrize("n_grid", [2, 3, 9, 33, 34, 100, 257, 1000, 4097, 20001])
+def test_unusual_grid_sizes_through_the_c_abi(co, gsynth, n_grid):
+    """The front ends only build the reference's two 10 001-point grids, the C ABI takes any geometric grid: grids shorter
+    than the sub-stepped start, shorter than one tile, one point past a tile boundary, twice the usual length (tail tiles
+    of one or two coarse steps, tiles cut to whole steps) against the serial C oracle on the same grid."""
+    from magprop_amd import _capi
+    rng = np.random.default_rng(n_grid)
+    tg = np.logspace(0.0, 6.0 * min(1.0, (n_grid - 1) / 10000.0), n_grid)   # the reference's step ratio (half of it for 20 001)
+    n_obs = min(50, max(1, n_grid))
+    x = np.sort(np.exp(rng.uniform(np.log(tg[0]), np.log(tg[-1]), n_obs)))
+    x[0], x[-1] = tg[0], tg[-1]                                    # both ends of the grid are legal observation times
+    y = 10.0 ** rng.uniform(-2, 2, n_obs)
+    yerr = 0.3 * y
+    lo, hi = gsynth["prior_lower"], gsynth["prior_upper"]
+    P = np.concatenate([np.array(TRUTHS[n]) + 0.05 * rng.standard_normal((6, 6)) for n in TYPES] + [lo + (hi - lo) * rng.random((40, 6))])
+    P = np.clip(P, lo, hi)
+    ref, rst = co.lnprob_batch(co.cfg_synth(), P, tg, x, y, yerr, lo, hi, LOG_MASK)
+    for kw, rtol in (({"sweep_tol": _capi.SWEEP_TOL_STRICT, "max_stride": 1}, 1e-9), ({}, 2e-7)):
+        h = _capi.Handle(_capi.cfg_synth(**kw), tg)
+        h.set_prior(lo, hi, LOG_MASK)
+        h.set_dataset(0, x, y, yerr)
+        for batch in (len(P), 7):
+            out = np.empty(len(P)); st = np.empty(len(P), dtype=np.int32)
+            for a_ in range(0, len(P), batch):
+                out[a_:a_ + batch], st[a_:a_ + batch] = h.lnprob_batch(P[a_:a_ + batch], want_status=True)
+            assert np.array_equal(st, rst), (n_grid, kw, np.nonzero(st != rst)[0][:5])
+            ok = rst == 0
+            assert np.all(np.abs(out[ok] - ref[ok]) <= rtol * np.maximum(np.abs(ref[ok]), 1.0)), (n_grid, kw)
+            assert np.all(out[~ok] == -np.inf)
+        # mode B on the same grid: the light curve rows are defined and reproduce lnprob
+        lt = h.lnprob_batch(P[:8], want_ltot=True)
+        assert lt[-1].shape == (8, n_grid)
+        h.close()
+
+
 def _capi_cfg(name):
     from magprop_amd import _capi
     return _capi.cfg_synth() if name == "synth" else _capi.cfg_lib()
