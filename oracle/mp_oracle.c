@@ -392,11 +392,13 @@ static int branch_flags(const mpo_cfg *c, const wk *w, double Mdisc, double omeg
  *   - mode 1 (ADAPTIVE, the product default): tiles step over 1, 2, 4 or 8 grid intervals.  A tile at stride > 1 is kept only up
  *     to the first lane in which (a) the solution changes the smooth branch of the right-hand side (Alfven-radius cap, torque
  *     arm: a kink no multistep formula can cross at a coarse step) or (b) the smoothness indicator
- *     120 |phi_5(h lam)| h |4th difference of (f - lam omega)| / omega (the formula's own error term) exceeds stride_tol; what follows is redone at stride 1.  Values at skipped grid points come
- *     from Hermite interpolants over the step: cubic in (omega, f), quintic in (Mdisc, dMdisc/dt, d2Mdisc/dt2).
- * History for a tile whose step differs from its predecessor's: the same Hermite interpolant on the predecessor's steps
- * (exact where the points coincide).  Start-up: Mdotfb is analytic (grid continued backwards); the missing (f, omega)
- * points continue points 0 and 1 linearly.  Failure ('flag'): the rotation parameter of an iterate at a step end exceeds
+ *     120 |phi_5(h lam)| h |4th difference of (f - lam omega)| / omega (the formula's own error term) exceeds stride_tol
+ *     (a tenth of it for tiles over 8 intervals and for the tile behind the sub-steps); what follows is redone finer.
+ *     The stride that is tried adapts per walker (opt_s, trouble).  Values at skipped grid points: omega from the
+ *     step's cubic Hermite interpolant in (omega, f); Mdisc from the quintic in (Mdisc, dMdisc/dt, d2Mdisc/dt2) while the
+ *     step resolves tvisc, from the cubic Lagrange interpolant of Mdisc / (tvisc Mdotfb) through four nodes beyond.
+ * History for a tile whose step differs from its predecessor's: the Hermite interpolant on the predecessor's steps
+ * (exact where the points coincide).  Start-up: the missing (f, omega) points continue points 0 and 1 linearly.  Failure ('flag'): the rotation parameter of an iterate at a step end exceeds
  * 0.27 in a tile at stride <= 1; at a coarser stride the tile is redone finer first.
  * (The kernels additionally stop the sweeps of a coarse tile early when its first lanes show that nothing will be kept, and
  * cut a tile whose sweeps are slow where they have converged; both lead to the same kind of redo as here.)
