@@ -237,6 +237,22 @@ def test_sampler_argument_validation(gsynth):
     from magprop_amd import _capi
     with pytest.raises(_capi.MagpropAmdError):
         s.run_mcmc(None, 1)              # no state yet
+    # the sharded entry points refuse to run without a state, outside their ranges, or without a row buffer
+    assert s.n_slots == 8 and s.step_blocks == 24 and s.step_row_doubles == 6 + 6 and s.row_doubles == 6 + 3
+    with pytest.raises(_capi.MagpropAmdError):
+        s.step_shard(0, 24, 0)
+    s.set_positions(np.array(TRUTHS["Humped"]) + 1.0e-4 * np.random.default_rng(0).standard_normal((16, 6)))
+    for lo, hi in ((-1, 4), (0, 25), (5, 4)):
+        with pytest.raises(ValueError):
+            s.step_shard(lo, hi, 1)
+        with pytest.raises(ValueError):
+            s.halfstep_shard(0, lo, min(hi, 9) if hi != 25 else 9, 1)
+    with pytest.raises(ValueError):
+        s.step_shard(0, 24, 0)           # NULL rows for a non-empty range
+    with pytest.raises(ValueError):
+        s.step_apply(0)
+    s.step_shard(3, 3, 0)                # an empty share is legal (more ranks than blocks)
+    assert _capi.lib().mp_sampler_set_whole_step(None, 1) != 0
 
 
 def test_sharded_lnprob_pipelined_over_rccl(gsynth):
