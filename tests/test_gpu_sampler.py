@@ -105,6 +105,15 @@ def test_whole_step_launch_equals_half_step_launches(gsynth):
         s.run_mcmc(p0, 60)
     assert np.array_equal(runs[0].get_chain(), runs[1].get_chain())
     assert np.array_equal(runs[0].acceptance_fraction, runs[1].acceptance_fraction)
+    # the smallest ensembles (one walker per half: its partner is the only other walker) against the numpy restatement
+    from oracle import stretch_oracle as so
+    for nwalk in (2, 4):
+        q0 = rng.normal(size=(nwalk, 3))
+        for w in (True, False):
+            s = EnsembleSampler(nwalk, 3, target="gaussian", seed=23, whole_step=w)
+            s.run_mcmc(q0, 50)
+            ref_chain, ref_lnp, ref_acc = so.run(q0, 50, 23)
+            assert np.array_equal(s.get_chain(), ref_chain) and np.array_equal(s.acceptance_fraction, ref_acc / 50), (nwalk, w)
     # posterior: one ensemble near the truth; four ensembles, each on its own dataset; walkers all over the prior box
     # (failed proposals); a 600-point light curve (scratch rows: the two candidates of a walker must not share one)
     sets = [(gsynth[n + "_x"], gsynth[n + "_y"], gsynth[n + "_yerr"]) for n in TYPES]
