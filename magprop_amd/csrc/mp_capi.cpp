@@ -372,6 +372,8 @@ mp_handle *mp_create(const mp_model_cfg *cfg, const double *tgrid, int n_grid, i
     }
     s.coarse_max_sweeps = 5;
     s.trouble_limit = 2;
+    s.early_hold = 1024; s.pad2 = 0;                               // oracle/mp_oracle.c MPO_EARLY_HOLD
+    if (const char *e = std::getenv("MAGPROP_AMD_EARLY_HOLD")) { const int v = std::atoi(e); if (v >= 0) s.early_hold = v; }   // experiments only
     if (const char *e = std::getenv("MAGPROP_AMD_TROUBLE_LIMIT")) { const int v = std::atoi(e); if (v >= 0 && v <= 1000) s.trouble_limit = v; }   // experiments only
     s.fine_max_sweeps = 8;
     if (const char *e = std::getenv("MAGPROP_AMD_COARSE_MAX_SWEEPS")) { const int v = std::atoi(e); if (v >= 2 && v <= 64) s.coarse_max_sweeps = v; }   // experiments only

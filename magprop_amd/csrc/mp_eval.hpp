@@ -624,8 +624,9 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
             const double tol_k = kind >= 2 ? sh.coarse_tol_factor * sh.sweep_tol : sh.sweep_tol;
             const double ultra_k = kind >= 2 ? sh.coarse_ultra_factor * sh.ultra_tol : sh.ultra_tol;
             // (the tile tried at a coarse stride right behind the sub-steps has no calm predecessor to vouch for it: a tenth;
-            // steps over 8 intervals: oracle/mp_oracle.c)
-            const double tile_tol = (kind >= 2 && rec_kind == 0) ? 0.1 * sh.stride_tol : (kind >= 4 ? sh.k4_tol_factor * sh.stride_tol : sh.stride_tol);
+            // likewise every coarse tile that starts within the first early_hold grid intervals, and steps over 8 intervals:
+            // oracle/mp_oracle.c)
+            const double tile_tol = (kind >= 2 && (rec_kind == 0 || pos8 < 8 * sh.early_hold)) ? 0.1 * sh.stride_tol : (kind >= 4 ? sh.k4_tol_factor * sh.stride_tol : sh.stride_tol);
             bool abort_tile = false;
             while (true) {
                 ++sweep;
