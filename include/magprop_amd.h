@@ -36,10 +36,10 @@
  *     that takes one serialises on a mutex inside the handle for the duration of the call.  The host-buffer
  *     entry points (mp_lnprob_batch, mp_model_lc, mp_rhs_batch, mp_sampler_run ...) run on the handle's own
  *     stream and return when their results are in the caller's buffers.
- *   - mp_lnprob_batch_dev and the mp_sampler_halfstep_* calls only enqueue work on the stream they are given.
- *     Launches on different streams may overlap on the device, with one exception the library orders itself:
- *     a handle that holds a light curve of more than 64 points owns per-walker scratch rows, and a launch that
- *     uses them waits (stream-side, through an event) for the previous such launch of the same handle.
+ *   - mp_lnprob_batch_dev and the mp_sampler_halfstep_* / mp_sampler_step_* calls only enqueue work on the stream
+ *     they are given.  Launches of one handle on different streams may overlap on the device: a launch writes nothing
+ *     but its own outputs (since ABI 4 also for handles that hold light curves of more than 64 points, which until
+ *     ABI 3 owned per-walker scratch rows and were ordered by the library).
  *   - Buffers passed to an asynchronous call must stay valid until the work has completed on that stream;
  *     replacing a dataset (mp_set_dataset) waits for the device first.
  *   - All mp_sampler_halfstep_* calls of one sampler must use one stream.

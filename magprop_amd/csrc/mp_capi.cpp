@@ -128,34 +128,20 @@ struct mp_handle {
     std::vector<int32_t> last_tile_log;
     DevBuf<unsigned char> w_io;   // mp_lnprob_batch: [pars | ds_id] in, [lnprob | status | sweeps] out, one copy each way
     PinnedBuf h_io;
-    DevBuf<double> w_scratch;   // DevShared::obs_scratch (only allocated once a light curve longer than 64 points is set)
     double last_mean_sweeps = 0.0;
     std::vector<int32_t> last_sweeps, last_tiles;   // per walker, most recent host-buffer batch (diagnostic)
     // Threading / stream contract (include/magprop_amd.h): every entry point that takes a handle or a sampler holds
-    // `mu` for its duration.  The scratch rows are indexed by walker, so two launches that use them must not overlap:
-    // each records `scratch_done` on its stream and the next one, if it runs on another stream, waits for it there.
+    // `mu` for its duration.  Launches share nothing writable but their own outputs (round 4: no per-walker scratch rows),
+    // so launches of one handle on different streams may overlap freely.
     std::recursive_mutex mu;
-    hipEvent_t scratch_done = nullptr;
-    hipStream_t scratch_stream = nullptr;
-    bool scratch_busy = false;
 };
 
 namespace {
 using Lock = std::lock_guard<std::recursive_mutex>;
 
-// launch_lnprob with the scratch rows ordered across streams (only handles that hold a light curve of more than 64 points
-// have scratch rows; all others launch freely)
 int launch_lnprob_ordered(mp_handle *h, const mp::LaunchArgs &a, hipStream_t st) {
-    const bool uses_scratch = h->sh.scratch_stride > 0;
-    if (uses_scratch && h->scratch_busy && h->scratch_stream != st)
-        HIP_TRY(hipStreamWaitEvent(st, h->scratch_done, 0));
     const int e = mp::launch_lnprob(h->sh, a, (void *)st);
     if (e) return fail(MP_EHIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
-    if (uses_scratch) {
-        HIP_TRY(hipEventRecord(h->scratch_done, st));
-        h->scratch_stream = st;
-        h->scratch_busy = true;
-    }
     return MP_OK;
 }
 }  // namespace
@@ -172,7 +158,7 @@ static void publish_datasets(mp_handle *h) {
     h->sh.obs_idt = h->d_obs_idt.p;
     h->sh.obs_y = h->d_obs_y.p;
     h->sh.obs_yerr = h->d_obs_yerr.p;
-    h->sh.scratch_stride = (extra + 63) / 64 * 64;
+    h->sh.has_long = extra > 0 ? 1 : 0;
 }
 
 // Copy light curve d behind the arena's last entry and publish its descriptor (slots never set keep n_obs = 0, which
@@ -223,19 +209,6 @@ static int upload_dataset(mp_handle *h, int d, bool replaced) {
     const int rc = append_dataset(h, d);
     if (rc) return rc;
     publish_datasets(h);
-    return MP_OK;
-}
-
-// Rows of DevShared::obs_scratch for a launch over walker indices [0, n_walkers).  Growing the buffer waits for the
-// device first (kernels in flight still write the old one); launches that fit never synchronise.
-static int ensure_scratch(mp_handle *h, int n_walkers) {
-    const size_t need = (size_t)n_walkers * 4 * (size_t)h->sh.scratch_stride;
-    if (need > h->w_scratch.cap) {
-        HIP_TRY(hipDeviceSynchronize());
-        const int rc = h->w_scratch.ensure(need);
-        if (rc) return rc;
-    }
-    h->sh.obs_scratch = h->w_scratch.p;
     return MP_OK;
 }
 
@@ -308,7 +281,6 @@ mp_handle *mp_create(const mp_model_cfg *cfg, const double *tgrid, int n_grid, i
     DeviceScope scope(device);
     hipDeviceProp_t prop;
     if (!scope.ok || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&h->scratch_done, hipEventDisableTiming) != hipSuccess ||
         hipGetDeviceProperties(&prop, device) != hipSuccess) {
         fail(MP_EHIP, "mp_create: cannot select device %d / create stream", device);
         mp_destroy(h);
@@ -479,9 +451,8 @@ int mp_destroy(mp_handle *h) {
     h->d_tgrid.release(); h->d_obs_dx.release(); h->d_obs_idt.release(); h->d_obs_y.release();
     h->d_obs_yerr.release(); h->d_obs_g.release(); h->d_tile_ptr.release(); h->d_ds.release();
     h->w_pars.release(); h->w_lnprob.release(); h->w_curves.release();
-    h->w_dsid.release(); h->w_status.release(); h->w_sweeps.release(); h->w_scratch.release(); h->w_tile_log.release();
+    h->w_dsid.release(); h->w_status.release(); h->w_sweeps.release(); h->w_tile_log.release();
     h->w_io.release(); h->h_io.release();
-    if (h->scratch_done) (void)hipEventDestroy(h->scratch_done);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return MP_OK;
@@ -562,7 +533,6 @@ int mp_lnprob_batch_dev(mp_handle *h, const double *d_pars, const int32_t *d_ds_
     a.lnprob = d_lnprob;
     a.status = d_status;
     a.ltot = d_ltot;
-    if ((rc = ensure_scratch(h, n))) return rc;
     return launch_lnprob_ordered(h, a, (hipStream_t)stream);
 }
 
@@ -586,7 +556,7 @@ int mp_lnprob_batch(mp_handle *h, const double *pars, const int32_t *ds_id, int 
     const size_t in_bytes = (in_pars + in_ids + 7) & ~(size_t)7;
     const size_t out_bytes = (sizeof(double) + 4 * sizeof(int32_t)) * (size_t)n;   // lnprob | status | sweeps | tiles (+ pad)
     if ((rc = h->w_io.ensure(in_bytes + out_bytes)) || (rc = h->h_io.ensure(in_bytes + out_bytes)) ||
-        (ltot_out && (rc = h->w_curves.ensure((size_t)n * ng))) || (rc = ensure_scratch(h, n)))
+        (ltot_out && (rc = h->w_curves.ensure((size_t)n * ng))))
         return rc;
     hipStream_t st = h->stream;
     std::memcpy(h->h_io.p, pars, in_pars);
@@ -885,9 +855,8 @@ int mp_sampler_set_positions(mp_sampler *s, const double *pos) {
         mp::LaunchArgs a{};
         a.pars = s->d_pos.p; a.ds_id = s->d_dsid.p; a.n = s->n_total; a.ndim = s->ndim; a.want_chi2 = 1;
         a.lnprob = s->d_lnprob.p; a.status = s->d_status.p;
-        int rc = ensure_scratch(h, s->n_total);
+        const int rc = launch_lnprob_ordered(h, a, h->stream);
         if (rc) return rc;
-        if ((rc = launch_lnprob_ordered(h, a, h->stream))) return rc;
         HIP_TRY(hipStreamSynchronize(h->stream));
     }
     s->have_state = true;
@@ -914,14 +883,11 @@ int mp_sampler_run(mp_sampler *s, int n_steps, double *chain, double *chain_lnpr
     // those fit the device two waves per SIMD; larger ensembles fill it with one half-step at a time.
     const int n_slots = (s->n_walkers / 2) * s->n_ensembles;
     const bool whole = s->whole_step && 3 * (int64_t)n_slots <= 2 * (int64_t)h->sh.n_simd;
-    if ((rc = ensure_scratch(h, whole ? std::max(s->n_total, 3 * n_slots) : s->n_total))) return rc;
     if (whole && (rc = s->d_spec.ensure((size_t)3 * n_slots * (size_t)(s->ndim + mp::kSpecExtra)))) return rc;
     if (s->ext_stream_work) {   // sharded half-steps on a caller's stream may still be updating the state
         HIP_TRY(hipDeviceSynchronize());
         s->ext_stream_work = false;
     }
-    if (h->sh.scratch_stride > 0 && h->scratch_busy && h->scratch_stream != h->stream)
-        HIP_TRY(hipStreamWaitEvent(h->stream, h->scratch_done, 0));
     for (int done = 0; done < n_steps;) {
         const int chunk = std::min(chunk_max, n_steps - done);
         if ((rc = s->h_perm.ensure((size_t)chunk * nt * sizeof(int32_t))) || (rc = s->d_perm.ensure((size_t)chunk * nt))) return rc;
@@ -959,11 +925,6 @@ int mp_sampler_run(mp_sampler *s, int n_steps, double *chain, double *chain_lnpr
         if (chain) {
             HIP_TRY(hipMemcpyAsync(chain + (size_t)done * row, s->d_chain.p, (size_t)chunk * row * sizeof(double), hipMemcpyDeviceToHost, h->stream));
             HIP_TRY(hipMemcpyAsync(chain_lnprob + (size_t)done * nt, s->d_chain_lnp.p, (size_t)chunk * nt * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        }
-        if (h->sh.scratch_stride > 0) {
-            HIP_TRY(hipEventRecord(h->scratch_done, h->stream));
-            h->scratch_stream = h->stream;
-            h->scratch_busy = true;
         }
         HIP_TRY(hipStreamSynchronize(h->stream));
         if ((rc = drain_bad(s))) return rc;
@@ -1018,21 +979,14 @@ int mp_sampler_halfstep_shard(mp_sampler *s, int half, int slot_lo, int slot_hi,
     hipStream_t st = (hipStream_t)stream;
     const int32_t *d_perm = nullptr;
     int rc;
-    if ((rc = current_split(s, st, &d_perm)) || (rc = ensure_scratch(h, s->n_total))) return rc;
+    if ((rc = current_split(s, st, &d_perm))) return rc;
     s->ext_stream_work = true;
     if (slot_hi == slot_lo) return MP_OK;
-    const bool uses_scratch = h->sh.scratch_stride > 0;
-    if (uses_scratch && h->scratch_busy && h->scratch_stream != st) HIP_TRY(hipStreamWaitEvent(st, h->scratch_done, 0));
     mp::StretchArgs g = stretch_args(s, d_perm, s->steps_done, half);
     g.upd = d_rows;
     g.slot_lo = slot_lo;
     const int e = mp::launch_stretch(h->sh, g, slot_hi - slot_lo, stream);
     if (e) return fail(MP_EHIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
-    if (uses_scratch) {
-        HIP_TRY(hipEventRecord(h->scratch_done, st));
-        h->scratch_stream = st;
-        h->scratch_busy = true;
-    }
     return MP_OK;
 }
 
@@ -1076,21 +1030,14 @@ int mp_sampler_step_shard(mp_sampler *s, int block_lo, int block_hi, double *d_r
     hipStream_t st = (hipStream_t)stream;
     const int32_t *d_perm = nullptr;
     int rc;
-    if ((rc = current_split(s, st, &d_perm)) || (rc = ensure_scratch(h, std::max(s->n_total, block_hi - block_lo)))) return rc;
+    if ((rc = current_split(s, st, &d_perm))) return rc;
     s->ext_stream_work = true;
     if (block_hi == block_lo) return MP_OK;
-    const bool uses_scratch = h->sh.scratch_stride > 0;
-    if (uses_scratch && h->scratch_busy && h->scratch_stream != st) HIP_TRY(hipStreamWaitEvent(st, h->scratch_done, 0));
     mp::StretchArgs g = stretch_args(s, d_perm, s->steps_done, 0);
     g.spec = d_rows;
     g.slot_lo = block_lo;
     const int e = mp::launch_stretch_step(h->sh, g, block_hi - block_lo, stream);
     if (e) return fail(MP_EHIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
-    if (uses_scratch) {
-        HIP_TRY(hipEventRecord(h->scratch_done, st));
-        h->scratch_stream = st;
-        h->scratch_busy = true;
-    }
     return MP_OK;
 }
 

@@ -64,10 +64,7 @@ struct DevShared {
     const double *obs_idt;    // 1 / (tgrid[g + 1] - tgrid[g])
     const double *obs_y;
     const double *obs_yerr;
-    // light curves longer than 64 points: per walker [4][scratch_stride] doubles, (Mdisc, omega) at the two grid points
-    // bracketing observation j >= 64 in column j - 64 (written tile by tile, read by the luminosity stage)
-    double *obs_scratch;
-    int32_t scratch_stride;   // max over datasets of (n_obs - 64), rounded up to 64; 0 = no long light curve
+    int32_t has_long;         // 1: some registered light curve has more than 64 points (the launchers pick the LONG kernel builds)
     int32_t pre_fine;         // grid intervals at the start that are covered with 1/8-interval sub-steps (32, or fewer on a tiny grid)
     // prior
     double lower[MP_MAX_NDIM];

@@ -372,7 +372,7 @@ MP_DEV void image_state(const DevShared &sh, const Walker &w, const TileImage<SP
 template <bool CURVES, int SPL, bool LONG>
 MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, double (&par)[MP_MAX_NDIM],
                         TileImage<SPL> &im, const TimeTable<SPL> &tt, double *Lbuf, double &lnp_out, int &status_out,
-                        int &sweeps_out, int &tiles_out, int scratch_row = -1) {
+                        int &sweeps_out, int &tiles_out) {
     constexpr int kSPL = SPL, kTile = 64 * SPL, kMaxSweeps = kTile + kMaxSweepsMargin;
     const int lane = threadIdx.x & 63;
     MP_PHASE_DECL
@@ -417,7 +417,8 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
     if (a.want_chi2 && dsd.n_obs <= 0) status = MP_STATUS_BADDATASET;
     const int32_t *tptr = sh.tile_ptr + dsd.tile_off;
     // The first 64 observations of the walker's light curve live in registers, one per lane (time-sorted;
-    // every synthetic set has 50).  Longer light curves park the states they need in the walker's scratch rows.
+    // every synthetic set has 50).  The further observations of a longer light curve are scored tile by tile, when the
+    // tile that brackets them is committed (below).
     int ob_g = -1;
     double ob_dx = 0.0, ob_idt = 0.0, ob_y = 0.0, ob_ye = 1.0;
     if (a.want_chi2 && lane < dsd.n_obs) {
@@ -428,15 +429,12 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
         ob_y = sh.obs_y[jj];
         ob_ye = sh.obs_yerr[jj];
     }
-    // LONG: compiled with the scratch-row path for light curves of more than 64 points (the launcher picks this
-    // variant when the handle holds such a dataset; the short variant keeps that code out of the register budget)
+    // LONG: compiled with the path for light curves of more than 64 points (the launcher picks this variant when the
+    // handle holds such a dataset; the short variant keeps that code out of the register budget)
     const bool long_lc = (CURVES || LONG) && a.want_chi2 && dsd.n_obs > 64;
     const bool deferred = !CURVES && a.want_chi2;               // see "observations" below
-    const size_t sc_stride = (size_t)sh.scratch_stride;
-    // [4][stride]: observations 64.. of this walker (scratch_row: evaluations that share a walker index, mp_kernels.hip stretch_step_kernel)
-    double *sc = sh.obs_scratch + (size_t)(scratch_row >= 0 ? scratch_row : walker) * 4 * sc_stride;
     double obM[2] = {1.0e30, 1.0e30}, obW[2] = {1.0e3, 1.0e3};  // (Mdisc, omega) at the observation's bracketing grid points
-    double chi = 0.0;
+    double chi = 0.0, chi_long = 0.0;
     int sweeps_total = 0, tiles_total = 0;
 
     if (status == MP_STATUS_OK) {
@@ -900,31 +898,42 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
             MP_PHASE(6)
             // ---------------- observations
             if constexpr (!CURVES) {
-                // The model is only needed at the two grid points bracketing each observation.  The lane holding an
-                // observation picks (Mdisc, omega) at those two points out of the tile's image as the tile goes by
-                // (observations beyond the 64 register-resident ones: into the walker's scratch rows); the luminosity
-                // stage runs after the last tile on those captured states, once per 64 observations (the 10 001-point
-                // light curve is never formed).
+                // The model is only needed at the two grid points bracketing each observation.  The lane holding one of the
+                // first 64 observations picks (Mdisc, omega) at those two points out of the tile's image as the tile goes by;
+                // the luminosity stage runs after the last tile on those captured states (the 10 001-point light curve is
+                // never formed).  Observations 64.. of a longer light curve are scored here and now, 64 at a time, while the
+                // image of the tile that brackets them is in LDS: states -> luminosity -> np.interp -> chi^2 term.  (Until
+                // round 3 their states were parked in per-walker rows in HBM and read back after the last tile: 95 MB of
+                // traffic per 4 096-walker launch of BASELINE config 5, and an ordering constraint between launches.)
                 if (deferred) {
                     const int p8 = 8 * ob_g;
                     if (ob_g >= 0 && p8 >= pos8 && p8 < end_kept8) {
                         image_state(sh, w, im, tt, kind, pos8, keep, t_s, p8, obM[0], obW[0]);
                         image_state(sh, w, im, tt, kind, pos8, keep, t_s, p8 + 8, obM[1], obW[1]);
                     }
-                    if (long_lc) {
-                        // observations 64.. whose interval starts inside the kept range (64-interval buckets of the dataset)
-                        const int g_lo = pos8 >> 3, g_hi = end_kept8 >> 3;                 // grid intervals [g_lo, g_hi)
-                        const int b_lo = g_lo / kTile64, b_hi = min((g_hi + kTile64 - 1) / kTile64, sh.n_tiles);
-                        const int j0 = max(tptr[b_lo], 64), j1 = tptr[b_hi];
-                        for (int j = j0 + lane; j < j1; j += 64) {
-                            const int g = sh.obs_g[dsd.obs_off + j];
-                            if (g < g_lo || g >= g_hi) continue;
-                            double Ma, Wa, Mb, Wb;
-                            image_state(sh, w, im, tt, kind, pos8, keep, t_s, 8 * g, Ma, Wa);
-                            image_state(sh, w, im, tt, kind, pos8, keep, t_s, 8 * g + 8, Mb, Wb);
-                            double *p = sc + (j - 64);
-                            p[0] = Ma; p[sc_stride] = Mb;
-                            p[2 * sc_stride] = Wa; p[3 * sc_stride] = Wb;
+                    if constexpr (LONG) {
+                        if (long_lc) {
+                            // observations 64.. whose interval starts inside the kept range (64-interval buckets of the dataset)
+                            const int g_lo = pos8 >> 3, g_hi = end_kept8 >> 3;                 // grid intervals [g_lo, g_hi)
+                            const int b_lo = g_lo / kTile64, b_hi = min((g_hi + kTile64 - 1) / kTile64, sh.n_tiles);
+                            const int j0 = max(tptr[b_lo], 64), j1 = tptr[b_hi];
+                            for (int jb = j0; jb < j1; jb += 64) {                             // (wave-uniform trip count)
+                                const int j = jb + lane;
+                                const int jj = dsd.obs_off + min(j, j1 - 1);
+                                const int g = sh.obs_g[jj];
+                                const bool mine = j < j1 && g >= g_lo && g < g_hi;
+                                const int q8 = mine ? 8 * g : pos8;                            // idle lanes: the tile's first interval
+                                double Ma, Wa, Mb, Wb;
+                                image_state(sh, w, im, tt, kind, pos8, keep, t_s, q8, Ma, Wa);
+                                image_state(sh, w, im, tt, kind, pos8, keep, t_s, q8 + 8, Mb, Wb);
+                                const Vd<2> Mx{{Ma, Mb}}, Wx{{Wa, Wb}};
+                                const DiscPt<2> dx = disc_point(sh, w, Mx);
+                                Vd<2> Lx, Lpx, Ldx;
+                                luminosity(sh, w, dx, Wx, Lx, Lpx, Ldx);
+                                const double mod = fma((Lx[1] - Lx[0]) * sh.obs_idt[jj], sh.obs_dx[jj], Lx[0]) / 1.0e50;
+                                const double res = (sh.obs_y[jj] - mod) / sh.obs_yerr[jj];
+                                if (mine) chi_long = fma(res, res, chi_long);
+                            }
                         }
                     }
                 }
@@ -1048,22 +1057,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 const double res = (ob_y - mod) / ob_ye;
                 chi = res * res;
             }
-            if (long_lc) {
-                __syncthreads();   // scratch rows written by other lanes
-                for (int jb = 64; jb < dsd.n_obs; jb += 64) {
-                    const bool valid = jb + lane < dsd.n_obs;
-                    const int j = valid ? jb + lane : dsd.n_obs - 1;
-                    const double *p = sc + (j - 64);
-                    const Vd<2> Mx{{p[0], p[sc_stride]}}, Wx{{p[2 * sc_stride], p[3 * sc_stride]}};
-                    const DiscPt<2> dx = disc_point(sh, w, Mx);
-                    Vd<2> Lx, Lpx, Ldx;
-                    luminosity(sh, w, dx, Wx, Lx, Lpx, Ldx);
-                    const int jj = dsd.obs_off + j;
-                    const double mod = fma((Lx[1] - Lx[0]) * sh.obs_idt[jj], sh.obs_dx[jj], Lx[0]) / 1.0e50;
-                    const double res = (sh.obs_y[jj] - mod) / sh.obs_yerr[jj];
-                    if (valid) chi = fma(res, res, chi);
-                }
-            }
+            chi += chi_long;                                         // observations 64.., scored tile by tile above
         }
     }
 

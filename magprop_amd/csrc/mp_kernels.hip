@@ -19,16 +19,16 @@
 //      check), terminates in any case after at most tile-length sweeps, and reproduces the serial recurrence to ~1e-11.
 //   3. Observations.  np.interp needs the model only at the two grid points bracketing each observed time: when an
 //      observation falls in the tile, the tile's (Mdisc, omega) image goes to LDS and the lane that owns the
-//      observation keeps the two bracketing states (register-resident observations) or parks them in the walker's
-//      scratch rows (light curves of more than 64 points).  The luminosity (reference luminosity stage,
-//      code/synthetic_datasets/funcs.py:175-229, magnetar/funcs.py:157-210) is evaluated after the last tile, once per
-//      64 observations.  When curve outputs are requested (CURVES) it is evaluated at every step end instead, the
+//      observation keeps the two bracketing states (the first 64 observations, register-resident; their luminosity --
+//      reference luminosity stage, code/synthetic_datasets/funcs.py:175-229, magnetar/funcs.py:157-210 -- is evaluated
+//      once, after the last tile) or scores it at once from the image (observations 64.. of a longer light curve).
+//      When curve outputs are requested (CURVES) the luminosity is evaluated at every step end instead, the
 //      tile's light curve is staged in LDS for the interpolation and written to HBM with coalesced stores.
 //   4. A wavefront reduction of the per-lane chi^2 terms gives -0.5*chi^2 (code/synthetic_datasets/mcmc_eqns.py:25).
 //
 // Kernels: lnprob_kernel<CURVES, SPL, LONG> (one wavefront per walker), stretch_kernel<SPL, LONG> (emcee's stretch
 // move fused around it) and stretch_apply_kernel (the state update of a half-step whose proposals were evaluated
-// on several GPUs); LONG = built with the scratch-row path for light curves of more than 64 points.
+// on several GPUs); LONG = built with the path for light curves of more than 64 points.
 // No MFMA (no dense contraction anywhere on this path), fp64 throughout; bound by the VALU issue rate of one wave per
 // SIMD (profiles/, tools/ubench).  The arithmetic is algebraically simplified with respect to the reference formulas
 // (e.g. fastness w = (Rm/Rc)^1.5 = omega*Rm^1.5/sqrt(GM), eta1-eta2 = -tanh); oracle/mp_oracle.c keeps the literal
@@ -114,6 +114,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPL >= 4 ? 1
     __shared__ TileImage<SPL> im;
     __shared__ TimeTable<SPL> tt;
     __shared__ double lds[1];
+    __shared__ double park[MP_MAX_NDIM + 3];
     ktab_init();
     wtab_init(sh.wtab);
     time_table_init(sh, tt);
@@ -139,49 +140,57 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPL >= 4 ? 1
         const double xj = i < g.ndim ? g.pos[(size_t)j * g.ndim + i] : 0.0;
         par[i] = sub_rn(xj, mul_rn(sub_rn(xj, xk), zz));
     }
-    double prop[MP_MAX_NDIM];
-#pragma unroll
-    for (int i = 0; i < MP_MAX_NDIM; ++i) prop[i] = par[i];
-    LaunchArgs a{};
-    a.ds_id = g.ds_id;
-    a.ndim = g.ndim;
-    a.physical = 0;
-    a.want_chi2 = 1;
-    double lnp;
-    int status = MP_STATUS_OK, sweeps, tiles;
+    // Nothing of the draw stays live across walker_eval (which needs every register): lane 0 parks the proposal, the
+    // acceptance threshold and the walker's current value in LDS and reads them back behind the evaluation.
+    //   park[0 .. ndim-1] proposal, [ndim] (ndim - 1) ln z, [ndim + 1] ln u, [ndim + 2] lnprob of the walker now
+    const bool lane0 = (threadIdx.x & 63) == 0;
+    double lnp = 0.0;
     if (g.target == 1) {   // isotropic unit Gaussian: exercises the move itself (tests)
-        lnp = 0.0;
 #pragma unroll
-        for (int i = 0; i < MP_MAX_NDIM; ++i) lnp = i < g.ndim ? sub_rn(lnp, mul_rn(mul_rn(0.5, prop[i]), prop[i])) : lnp;
-    } else {
+        for (int i = 0; i < MP_MAX_NDIM; ++i) lnp = i < g.ndim ? sub_rn(lnp, mul_rn(mul_rn(0.5, par[i]), par[i])) : lnp;
+    }
+    if (lane0) {
+#pragma unroll
+        for (int i = 0; i < MP_MAX_NDIM; ++i) park[i] = par[i];
+        park[MP_MAX_NDIM] = mul_rn(g.ndim - 1.0, log(zz));
+        park[MP_MAX_NDIM + 1] = log(u01(r2[0], r2[1]));
+        park[MP_MAX_NDIM + 2] = g.lnprob[k];
+    }
+    int status = MP_STATUS_OK, sweeps, tiles;
+    if (g.target != 1) {
+        LaunchArgs a{};
+        a.ds_id = g.ds_id;
+        a.ndim = g.ndim;
+        a.physical = 0;
+        a.want_chi2 = 1;
         walker_eval<false, SPL, LONG>(sh, a, k, par, im, tt, lds, lnp, status, sweeps, tiles);
     }
-    if ((threadIdx.x & 63) == 0) {   // lane 0 of the evaluating wavefront
-        const double lnp_old = g.lnprob[k];
-        const double lnpdiff = sub_rn(add_rn(mul_rn(g.ndim - 1.0, log(zz)), lnp), lnp_old);
-        const bool accept = lnpdiff > log(u01(r2[0], r2[1]));      // false for NaN / -inf proposals
+    if (lane0) {   // lane 0 of the evaluating wavefront
+        const double lnp_old = park[MP_MAX_NDIM + 2];
+        const double lnpdiff = sub_rn(add_rn(park[MP_MAX_NDIM], lnp), lnp_old);
+        const bool accept = lnpdiff > park[MP_MAX_NDIM + 1];      // false for NaN / -inf proposals
         if (g.upd) {
             double *u = g.upd + (size_t)blockIdx.x * (g.ndim + 3);
-            for (int i = 0; i < g.ndim; ++i) u[i] = prop[i];
+            for (int i = 0; i < g.ndim; ++i) u[i] = park[i];
             u[g.ndim] = lnp;
             u[g.ndim + 1] = accept ? 1.0 : 0.0;
             u[g.ndim + 2] = (double)status;
         } else {
             if (accept) {
-                for (int i = 0; i < g.ndim; ++i) g.pos[(size_t)k * g.ndim + i] = prop[i];
+                for (int i = 0; i < g.ndim; ++i) g.pos[(size_t)k * g.ndim + i] = park[i];
                 g.lnprob[k] = lnp;
                 g.n_accepted[k] += 1;
             }
             if (g.chain) {
                 double *c = g.chain + ((size_t)g.chain_row * g.n_total + k) * g.ndim;
-                for (int i = 0; i < g.ndim; ++i) c[i] = accept ? prop[i] : g.pos[(size_t)k * g.ndim + i];
+                for (int i = 0; i < g.ndim; ++i) c[i] = accept ? park[i] : g.pos[(size_t)k * g.ndim + i];
                 g.chain_lnp[(size_t)g.chain_row * g.n_total + k] = accept ? lnp : lnp_old;
             }
             if (g.bad_log && (status == MP_STATUS_FLAG || status == MP_STATUS_NONFINITE)) {
                 // the reference appends such parameter sets to its `fbad` file (code/synthetic_datasets/mcmc_eqns.py:72-79)
                 const unsigned slot_b = atomicAdd(g.bad_count, 1u);
                 if (slot_b < g.bad_cap)
-                    for (int i = 0; i < g.ndim; ++i) g.bad_log[(size_t)slot_b * g.ndim + i] = prop[i];
+                    for (int i = 0; i < g.ndim; ++i) g.bad_log[(size_t)slot_b * g.ndim + i] = park[i];
             }
         }
     }
@@ -278,39 +287,46 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPL >= 4 ? 1
         }
         skip = outside;   // a proposal outside the prior box is never accepted: this candidate cannot be the one
     }
-    double par[MP_MAX_NDIM], prop[MP_MAX_NDIM];
+    double par[MP_MAX_NDIM];
 #pragma unroll
     for (int i = 0; i < MP_MAX_NDIM; ++i) {
         const double xk = i < g.ndim ? g.pos[(size_t)k * g.ndim + i] : 0.0;
         par[i] = sub_rn(xj[i], mul_rn(sub_rn(xj[i], xk), zz));
-        prop[i] = par[i];
     }
-    LaunchArgs a{};
-    a.ds_id = g.ds_id;
-    a.ndim = g.ndim;
-    a.physical = 0;
-    a.want_chi2 = 1;
     double lnp = -INFINITY;
     int status = MP_STATUS_PRIOR, sweeps, tiles;
-    if (!skip) {
-        if (g.target == 1) {   // isotropic unit Gaussian: exercises the move itself (tests)
-            lnp = 0.0;
-            status = MP_STATUS_OK;
+    if (!skip && g.target == 1) {   // isotropic unit Gaussian: exercises the move itself (tests)
+        lnp = 0.0;
+        status = MP_STATUS_OK;
 #pragma unroll
-            for (int i = 0; i < MP_MAX_NDIM; ++i) lnp = i < g.ndim ? sub_rn(lnp, mul_rn(mul_rn(0.5, prop[i]), prop[i])) : lnp;
-        } else {
-            walker_eval<false, SPL, LONG>(sh, a, k, par, im, tt, lds, lnp, status, sweeps, tiles, (int)blockIdx.x);
-        }
+        for (int i = 0; i < MP_MAX_NDIM; ++i) lnp = i < g.ndim ? sub_rn(lnp, mul_rn(mul_rn(0.5, par[i]), par[i])) : lnp;
     }
-    if ((threadIdx.x & 63) == 0) {
+    // Everything of the outcome row that does not depend on the evaluation is written NOW: nothing of the draw stays live
+    // across walker_eval, which needs every register (round 3 held the proposal, the partner and the thresholds in registers
+    // there: 180 B of scratch per lane, 16 MB of spill traffic per launch).
+    const bool lane0 = (threadIdx.x & 63) == 0;
+    if (lane0) {
         double *u = g.spec + (size_t)blockIdx.x * (g.ndim + kSpecExtra);
-        for (int i = 0; i < g.ndim; ++i) u[i] = prop[i];
+        for (int i = 0; i < g.ndim; ++i) u[i] = par[i];
         u[g.ndim] = lnp;
         u[g.ndim + 1] = (double)status;
         u[g.ndim + 2] = mul_rn(g.ndim - 1.0, log(zz));
         u[g.ndim + 3] = logu;
         u[g.ndim + 4] = g.lnprob[k];
         u[g.ndim + 5] = (double)jc;
+    }
+    if (!skip && g.target != 1) {
+        LaunchArgs a{};
+        a.ds_id = g.ds_id;
+        a.ndim = g.ndim;
+        a.physical = 0;
+        a.want_chi2 = 1;
+        walker_eval<false, SPL, LONG>(sh, a, k, par, im, tt, lds, lnp, status, sweeps, tiles);
+        if (lane0) {
+            double *u = g.spec + (size_t)blockIdx.x * (g.ndim + kSpecExtra);
+            u[g.ndim] = lnp;
+            u[g.ndim + 1] = (double)status;
+        }
     }
 }
 
@@ -397,7 +413,7 @@ int launch_lnprob(const DevShared &sh, const LaunchArgs &a, void *stream) {
     //  - beyond: two steps per lane, which keeps two waves resident per SIMD (they fill each other's issue gaps);
     //  - a handle that holds a light curve of more than 64 points runs the LONG builds of the same kernels.
     const bool wide = (sh.force_spl ? sh.force_spl : kernel_spl(sh, a.n)) == 4;
-    const bool lng = sh.scratch_stride > 0;
+    const bool lng = sh.has_long != 0;
     hipStream_t st = (hipStream_t)stream;
     if (curves) {
         if (wide) hipLaunchKernelGGL((lnprob_kernel<true, 4, false>), grid, block, 0, st, sh, a);
@@ -417,7 +433,7 @@ int launch_stretch(const DevShared &sh, const StretchArgs &g, int n_blocks, void
     if (n_blocks <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)n_blocks);
-    const bool lng = sh.scratch_stride > 0;
+    const bool lng = sh.has_long != 0;
     if ((sh.force_spl ? sh.force_spl : kernel_spl(sh, n_blocks)) == 4) {
         if (lng) hipLaunchKernelGGL((stretch_kernel<4, true>), grid, dim3(64), 0, st, sh, g);
         else hipLaunchKernelGGL((stretch_kernel<4, false>), grid, dim3(64), 0, st, sh, g);
@@ -432,7 +448,7 @@ int launch_stretch_step(const DevShared &sh, const StretchArgs &g, int n_blocks,
     if (n_blocks <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)n_blocks);
-    const bool lng = sh.scratch_stride > 0;
+    const bool lng = sh.has_long != 0;
     if ((sh.force_spl ? sh.force_spl : kernel_spl(sh, n_blocks)) == 4) {
         if (lng) hipLaunchKernelGGL((stretch_step_kernel<4, true>), grid, dim3(64), 0, st, sh, g);
         else hipLaunchKernelGGL((stretch_step_kernel<4, false>), grid, dim3(64), 0, st, sh, g);
