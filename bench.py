@@ -39,7 +39,10 @@ Prints one JSON line on rank 0 (contract in the task description) with extra obj
                    N > 1: walker-sharded half-steps with one all-gather each — dependent launches, nothing overlapped).
   cpu_baseline     oracle/lsoda_port.py in its reference_cost mode (scipy odeint + Python RHS that re-derives the constants
                    in every call + element-wise torque loop: within +5 % of the real reference per evaluation, identical
-                   values) timed on this box's host cores over a bounded sample of the same walkers (rank 0, N = 1 only).
+                   values) timed on this box's host cores over a bounded sample of the same walkers (rank 0, at every N,
+                   before that rank touches the GPU; the other ranks wait for it in the rendezvous).
+`value` (the contract's K timed steps) is the authoritative figure; `sustained` is its >= 2 s cross-check and
+`ensemble_sampler` the same metric through the dependent half-steps of ONE ensemble (SURVEY.md 8(d) names both).
 """
 import argparse
 import glob
@@ -236,6 +239,41 @@ def config5_datasets(g):
     return sets
 
 
+def config5_sampler_sets(g):
+    """Four light curves of different lengths, one per GRB type, for the four ensembles of BASELINE config 5 through the
+    sampler: the seeded 50-point Humped set, and 410 / 8 / 1 944 points drawn around the Classic / Sloped / Stuttering model
+    curves (20 % errors), as tests/test_gpu_batched.py::test_config5_through_the_ensemble_sampler does."""
+    from magprop_amd import model_lum
+    tarr = np.logspace(0.0, 6.0, 10001)
+    sets = [(g["Humped_x"], g["Humped_y"], g["Humped_yerr"])]
+    for t, m, seed in (("Classic", 410, 1), ("Sloped", 8, 3), ("Stuttering", 1944, 2)):
+        rng = np.random.default_rng(seed)
+        x = np.sort(10.0 ** rng.uniform(0.0, 6.0, m))
+        x[0], x[-1] = tarr[0], tarr[-1]
+        y0 = np.interp(x, tarr, model_lum(CANON[t])[1])
+        sets.append((x, y0 + rng.normal(0, 0.2 * y0), 0.2 * y0))
+    return sets
+
+
+def sampler_leg(c, n_walk, datasets, p0, steps, seed, **kw):
+    """walkers x steps / s of the device-resident stretch move over `datasets` (one ensemble of n_walk walkers per entry),
+    single GPU: 5 untimed steps, then `steps` timed ones, nothing copied back."""
+    from magprop_amd import EnsembleSampler
+    es = EnsembleSampler(n_walk, 6, datasets=datasets, seed=seed, device=c.dev_index, **kw)
+    es.run_mcmc(p0, 5, store=False)
+    t = time.perf_counter()
+    es.run_mcmc(None, steps, store=False)
+    t = time.perf_counter() - t
+    n = es.ntotal
+    whole = kw.get("whole_step", True) and 3 * (n // 2) <= 2 * es.handle.n_simd
+    out = {"walkers": n, "ensembles": es.nensembles, "n_obs": [int(len(d[0])) for d in datasets], "steps": steps,
+           "walker_steps_per_sec": n * steps / t, "ms_per_step": 1e3 * t / steps,
+           "acceptance_fraction": float(es.acceptance_fraction.mean()),
+           "launches": "one per step (3/2 x walkers evaluations) + commit" if whole else "one fused launch per half-step"}
+    es.close()
+    return out
+
+
 class Ctx:
     """What every leg of one rank shares: device, process group, golden data, command-line switches."""
 
@@ -364,6 +402,18 @@ def run_passes(c, config, scaling, steps, warmup, curve=False, nwalk=None, grb=N
                     f"({n_global} walkers total), walkers at truth+{a.spread:g}*randn")
     workload += f", 10001-point grid, mode {'B (lnprob + model light curve written to HBM)' if curve else 'A (lnprob only)'}"
     kavg = float(kern_ms.mean()) * 1e-3
+    # the slowest walker of a rank decides its pass, and the slowest rank decides the job: the spread over the ranks
+    k_ranks = torch.tensor([kavg * 1e3 if n_local > 0 else float("nan")], dtype=torch.float64, device=dev)
+    if world > 1:
+        k_all = [torch.empty_like(k_ranks) for _ in range(world)]
+        if a.backend == "gloo":
+            k_cpu = [t.cpu() for t in k_all]
+            dist.all_gather(k_cpu, k_ranks.cpu())
+            k_all = k_cpu
+        else:
+            dist.all_gather(k_all, k_ranks)
+        k_ranks = torch.cat([t.cpu() for t in k_all])
+    k_ranks = k_ranks.cpu().numpy()
     bytes_eval = BYTES_PER_EVAL_A + (BYTES_LTOT if curve else 0)
     achieved = bytes_eval * n_local / kavg / 1e9
     fig = c.pmc.get("curve" if curve else ("config5" if config == 5 else "lnprob"), {}).get(str(n_local), {})
@@ -371,11 +421,12 @@ def run_passes(c, config, scaling, steps, warmup, curve=False, nwalk=None, grb=N
     res = {
         "value": n_global * steps / dt, "ms_per_step": 1e3 * dt / steps, "steps": steps, "warmup": warmup, "scaling": scaling,
         "workload": workload, "baseline_config": config, "n_walk_per_gpu": n_local, "n_walk_total": n_global,
-        "n_obs": n_obs_desc, "kernel_variant": variant, "sweep_tol": lp.handle.sweep_tol,
+        "n_obs": n_obs_desc, "kernel_variant": variant, "sweep_tol": lp.handle.sweep_tol, "policy": lp.handle.policy,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel": "mp::lnprob_kernel",
                      "kernel_ms_avg": 1e3 * kavg, "kernel_ms_min": float(kern_ms.min()),
+                     "kernel_ms_max_over_ranks": float(np.nanmax(k_ranks)), "kernel_ms_min_over_ranks": float(np.nanmin(k_ranks)),
                      "algorithmic_bytes_per_eval": bytes_eval, "evals_per_launch": n_local,
                      "note": "latency-bound fp64 VALU recurrence: neither HBM nor MFMA binds; see valu"},
         "valu": {"bound": "fp64 VALU issue", "unit": "TFLOP/s", "fp64_flops_per_launch_pmc": flops,
@@ -395,7 +446,7 @@ def brief(r):
     """A sub-leg as it appears under `configs`."""
     return {k: r[k] for k in ("value", "ms_per_step", "steps", "scaling", "workload", "n_walk_per_gpu", "n_walk_total",
                               "kernel_variant", "kernel_evals_per_sec_per_gpu")} | {
-        "kernel_ms_avg": r["roofline"]["kernel_ms_avg"],
+        "kernel_ms_avg": r["roofline"]["kernel_ms_avg"], "kernel_ms_max_over_ranks": r["roofline"]["kernel_ms_max_over_ranks"],
         "roofline": {k: r["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel",
                                                    "algorithmic_bytes_per_eval")},
         "valu": {k: r["valu"][k] for k in ("achieved", "peak", "frac", "fp64_flops_per_launch_pmc")},
@@ -471,9 +522,10 @@ def main():
     grb = a.grb or {2: "Humped", 3: "Classic", 4: "Humped", 5: "Humped"}[a.config]
     headline = a.config == 2 and not a.curve and a.nwalk is None and a.scaling is None   # the driver's invocation
     cpu = c1 = p0_c1 = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        cpu = cpu_baseline(grb, a.cpu_seconds, a.seed)          # before any GPU initialisation (forks)
-        if headline and not a.no_extra:
+    if rank == 0 and not a.no_cpu_baseline:
+        # before this rank initialises the GPU (the leg forks); at N > 1 the other ranks wait in the rendezvous meanwhile
+        cpu = cpu_baseline(grb, a.cpu_seconds, a.seed)
+        if world == 1 and headline and not a.no_extra:
             p0_c1, c1 = config1_cpu(a.seed)
 
     import torch
@@ -524,7 +576,14 @@ def main():
 
     # ---- the same metric through the device-resident ensemble sampler: walkers x steps / s
     mcmc = None
-    if not a.no_mcmc and a.config != 5 and n_global % 2 == 0:
+    if not a.no_mcmc and a.config == 5 and world == 1:
+        # four ensembles (one per GRB type, light curves of 50 / 410 / 8 / 1 944 points) advanced together
+        nw5 = n_global // 4
+        rng5 = np.random.default_rng(a.seed + 5)
+        p05 = np.concatenate([np.array(TRUTH[t]) + 1.0e-4 * rng5.standard_normal((nw5, 6)) for t in TYPES])
+        mcmc = sampler_leg(c, nw5, config5_sampler_sets(g), p05, a.mcmc_steps, a.seed)
+        mcmc["note"] = "emcee-style stretch move, four ensembles on light curves of different lengths advanced together"
+    elif not a.no_mcmc and a.config != 5 and n_global % 2 == 0:
         p0 = (truth + 1.0e-4 * torch.randn(n_global, 6, dtype=torch.float64, device=dev, generator=gen)).cpu().numpy()
         es = EnsembleSampler(n_global, 6, x, y, yerr, seed=a.seed, device=c.dev_index)
         half_step_launches = None
@@ -677,14 +736,26 @@ def main():
     if headline and not a.no_extra:
         ss, sw, su = min(a.steps, 40), min(a.warmup, 5), min(a.spin_up, 60)
 
-        def sub(config, scal, **kw):
+        def sub(config, scal, sampler=False, **kw):
             r = brief(run_passes(c, config, scal, ss, sw, spin_up=su, **kw))
-            c.last["lp"].handle.close()                         # the leg's handle (stream, grid, datasets) is not needed again
+            Lx = c.last
+            if sampler and not a.no_mcmc:
+                # SURVEY.md 8(d)'s metric for this workload too: the ensemble loop (walkers x steps / s), not only raw passes
+                rngs = np.random.default_rng(a.seed + 10 * config)
+                ms = max(10, min(a.mcmc_steps, 60))
+                if config == 5:
+                    nw5 = Lx["n_global"] // 4
+                    p0s = np.concatenate([np.array(TRUTH[t]) + 1.0e-4 * rngs.standard_normal((nw5, 6)) for t in TYPES])
+                    r["ensemble_sampler"] = sampler_leg(c, nw5, config5_sampler_sets(g), p0s, ms, a.seed)
+                else:
+                    p0s = np.array(TRUTH[Lx["grb"]]) + 1.0e-4 * rngs.standard_normal((Lx["n_global"], 6))
+                    r["ensemble_sampler"] = sampler_leg(c, Lx["n_global"], [(Lx["x"], Lx["y"], Lx["yerr"])], p0s, ms, a.seed)
+            Lx["lp"].handle.close()                             # the leg's handle (stream, grid, datasets) is not needed again
             c.last = None
             return r
         if world == 1:
-            configs = {"3": sub(3, "weak"), "4_one_gpu": sub(4, "strong"), "5": sub(5, "strong"),
-                       "curve": sub(2, "weak", curve=True)}
+            configs = {"3": sub(3, "weak", sampler=True), "4_one_gpu": sub(4, "strong", sampler=True),
+                       "5": sub(5, "strong", sampler=True), "curve": sub(2, "weak", curve=True)}
         else:
             configs = {"4_strong": sub(4, "strong"), "5_strong": sub(5, "strong")}
 
@@ -704,7 +775,9 @@ def main():
             "config": {"workload": r["workload"], "baseline_config": a.config,
                        "n_walk_per_gpu": r["n_walk_per_gpu"], "n_walk_total": r["n_walk_total"], "n_grid": 10001,
                        "n_obs": r["n_obs"], "variant": "synth", "kernel_variant": r["kernel_variant"],
-                       "sweep_tol": r["sweep_tol"], "parallelism": par},
+                       "sweep_tol": r["sweep_tol"], "policy": r["policy"], "parallelism": par},
+            "authoritative": "value = the contract's K timed steps (raw, independent passes); sustained = its >= 2 s cross-check; "
+                             "ensemble_sampler.walker_steps_per_sec = the same metric through one ensemble's dependent half-steps",
             "roofline": r["roofline"], "valu": r["valu"],
             "kernel_evals_per_sec_per_gpu": r["kernel_evals_per_sec_per_gpu"], "spin_up_launches": a.spin_up,
             "host_enqueue_ms_per_step": r["host_enqueue_ms_per_step"], "ranks_seen": ranks_seen,

@@ -53,7 +53,7 @@
 extern "C" {
 #endif
 
-#define MP_ABI_VERSION 3
+#define MP_ABI_VERSION 4
 
 /* return codes */
 #define MP_OK 0
@@ -111,6 +111,10 @@ typedef struct mp_model_cfg {
  * per walker (9 near the truths). */
 #define MP_MAX_STRIDE_DEFAULT 8
 #define MP_STRIDE_TOL_DEFAULT 1.0e-7
+/* Coarse tiles that START before this time (seconds; the spin-up transients of heavy discs around strongly magnetised
+ * stars live here) are held to a tenth of stride_tol.  A physical time, not a grid index: the reference's "L" grid
+ * reaches it at index 1 003, its "S" grid (t0 = 1 ms) at index 4 003. */
+#define MP_EARLY_HOLD_SECONDS 4.0
 
 /* The sweeps contract by 1e-2..1e-3 per pass, so a tile whose last correction was <= 1e-7 relative is converged to
  * <= 4.5e-9 relative in lnprob (measured over the golden clouds and the prior-wide scans, tools/tol_scan.py) — 10x below
@@ -300,6 +304,26 @@ int mp_last_tile_log(const mp_handle *h, int walker, int32_t *out, int n);
 /* tiles solved (kept or redone) by every walker of that batch; returns the count copied */
 int mp_last_tiles(const mp_handle *h, int32_t *out, int n);
 double mp_sweep_tol(const mp_handle *h); /* the tolerance in force (cfg.sweep_tol or the default) */
+/* The solver settings in force for this handle, out[i] for i < min(n, MP_POLICY_COUNT); returns how many were written.
+ * The shipped library takes them from cfg and the constants above only; the developer build
+ * (`make -C magprop_amd/csrc experiments`) also reads MAGPROP_AMD_* environment overrides and says so in
+ * out[MP_POLICY_EXPERIMENTS] (bench.py copies the whole vector into its JSON line). */
+enum {
+    MP_POLICY_MAX_STRIDE = 0,        /* grid intervals a step may span                                         */
+    MP_POLICY_STRIDE_TOL,            /* smoothness bound of coarse tiles                                       */
+    MP_POLICY_SWEEP_TOL,             /* end of the Newton sweeps                                               */
+    MP_POLICY_EARLY_HOLD_SECONDS,    /* MP_EARLY_HOLD_SECONDS                                                  */
+    MP_POLICY_K4_TOL_FACTOR,         /* stride_tol of tiles over 8 intervals, relative to stride_tol           */
+    MP_POLICY_COARSE_TOL_FACTOR,     /* sweep_tol of tiles over 2, 4, 8 intervals, relative to sweep_tol       */
+    MP_POLICY_COARSE_MAX_SWEEPS,     /* sweeps after which a coarse tile keeps its converged lanes             */
+    MP_POLICY_FINE_MAX_SWEEPS,       /* the same for tiles over single intervals                               */
+    MP_POLICY_TROUBLE_LIMIT,         /* failed coarse attempts after which stride 8 is no longer tried         */
+    MP_POLICY_ULTRA_TOL,             /* correction below which a sweep linearises omega_dot                    */
+    MP_POLICY_FORCED_STEPS_PER_LANE, /* 0 = by batch size                                                      */
+    MP_POLICY_EXPERIMENTS,           /* 1: developer build that honours MAGPROP_AMD_* environment overrides    */
+    MP_POLICY_COUNT
+};
+int mp_get_policy(const mp_handle *h, double *out, int n);
 int mp_n_simd(const mp_handle *h);       /* SIMDs of the handle's device: batch-size thresholds of the kernel variants */
 
 #ifdef __cplusplus

@@ -27,8 +27,12 @@ EXPORTS = (
     "mp_sampler_get_bad", "mp_sampler_n_slots", "mp_sampler_row_doubles", "mp_sampler_halfstep_shard",
     "mp_sampler_halfstep_apply", "mp_sampler_step_blocks", "mp_sampler_step_row_doubles", "mp_sampler_step_shard",
     "mp_sampler_step_apply", "mp_sampler_state_ptrs", "mp_sweep_tol", "mp_n_simd", "mp_last_sweeps", "mp_last_tiles", "mp_tile_log", "mp_last_tile_log",
+    "mp_get_policy",
 )
-ABI_VERSION = 3
+ABI_VERSION = 4
+# order of mp_get_policy()'s vector (include/magprop_amd.h MP_POLICY_*)
+POLICY_FIELDS = ("max_stride", "stride_tol", "sweep_tol", "early_hold_seconds", "k4_tol_factor", "coarse_tol_factor",
+                 "coarse_max_sweeps", "fine_max_sweeps", "trouble_limit", "ultra_tol", "forced_steps_per_lane", "experiments_build")
 
 
 class MagpropAmdError(RuntimeError):
@@ -141,6 +145,8 @@ def lib():
     L.mp_sweep_tol.argtypes = [vp]
     L.mp_sweep_tol.restype = C.c_double
     L.mp_n_simd.argtypes = [vp]
+    L.mp_get_policy.argtypes = [vp, dp, C.c_int]
+    L.mp_get_policy.restype = C.c_int
     L.mp_last_sweeps.argtypes = [vp, ip, C.c_int]
     L.mp_last_sweeps.restype = C.c_int
     L.mp_last_tiles.argtypes = [vp, ip, C.c_int]
@@ -361,6 +367,16 @@ class Handle:
     @property
     def sweep_tol(self):
         return self._L.mp_sweep_tol(self._h)
+
+    @property
+    def policy(self):
+        """The solver settings in force (mp_get_policy): a dict keyed by POLICY_FIELDS.  experiments_build = 1.0 marks the
+        developer build that honours MAGPROP_AMD_* environment overrides; the shipped library reports 0."""
+        buf = np.zeros(len(POLICY_FIELDS))
+        m = self._L.mp_get_policy(self._h, _dptr(buf), int(buf.size))
+        if m < 0:
+            check(m, "mp_get_policy")
+        return dict(zip(POLICY_FIELDS[:m], (float(v) for v in buf[:m])))
 
     @property
     def n_simd(self):

@@ -321,55 +321,48 @@ mp_handle *mp_create(const mp_model_cfg *cfg, const double *tgrid, int n_grid, i
     s.sweep_tol = cfg->sweep_tol > 0.0 ? cfg->sweep_tol : MP_SWEEP_TOL_DEFAULT;
     s.stride_tol = cfg->stride_tol > 0.0 ? cfg->stride_tol : MP_STRIDE_TOL_DEFAULT;
     {
-        int ms = cfg->max_stride > 0 ? cfg->max_stride : MP_MAX_STRIDE_DEFAULT;
-        if (const char *e = std::getenv("MAGPROP_AMD_MAX_STRIDE")) {   // experiments only
-            const int v = std::atoi(e);
-            if (v == 1 || v == 2 || v == 4 || v == 8) ms = v;
-        }
+        const int ms = cfg->max_stride > 0 ? cfg->max_stride : MP_MAX_STRIDE_DEFAULT;
         s.max_kind = ms == 1 ? 1 : (ms == 2 ? 2 : (ms == 4 ? 3 : 4));
     }
     s.n_simd = std::max(1, prop.multiProcessorCount) * 4;         // 4 SIMDs per CU (1 024 on MI355X)
     s.force_spl = 0;
-    if (const char *e = std::getenv("MAGPROP_AMD_SPL")) {          // experiments only
-        const int v = std::atoi(e);
-        if (v == 2 || v == 4) s.force_spl = v;
-    }
-    if (const char *e = std::getenv("MAGPROP_AMD_SWEEP_TOL")) {   // experiments only
-        const double v = std::atof(e);
-        if (v > 0.0 && v < 1.0) s.sweep_tol = v;
-    }
-    if (const char *e = std::getenv("MAGPROP_AMD_STRIDE_TOL")) {  // experiments only
-        const double v = std::atof(e);
-        if (v > 0.0 && v < 1.0e-3) s.stride_tol = v;
-    }
+    // The constants of the stride policy (oracle/mp_oracle.c carries the same ones).  They are not
+    // settings: the shipped library takes them from here only, mp_get_policy() reports them.
     s.coarse_max_sweeps = 5;
-    s.trouble_limit = 2;
-    s.early_hold = 1024; s.pad2 = 0;                               // oracle/mp_oracle.c MPO_EARLY_HOLD
-    if (const char *e = std::getenv("MAGPROP_AMD_EARLY_HOLD")) { const int v = std::atoi(e); if (v >= 0) s.early_hold = v; }   // experiments only
-    if (const char *e = std::getenv("MAGPROP_AMD_TROUBLE_LIMIT")) { const int v = std::atoi(e); if (v >= 0 && v <= 1000) s.trouble_limit = v; }   // experiments only
     s.fine_max_sweeps = 8;
-    if (const char *e = std::getenv("MAGPROP_AMD_COARSE_MAX_SWEEPS")) { const int v = std::atoi(e); if (v >= 2 && v <= 64) s.coarse_max_sweeps = v; }   // experiments only
-    if (const char *e = std::getenv("MAGPROP_AMD_FINE_MAX_SWEEPS")) { const int v = std::atoi(e); if (v >= 2 && v <= 272) s.fine_max_sweeps = v; }
+    s.trouble_limit = 2;
+    s.early_hold_t = MP_EARLY_HOLD_SECONDS;                       // oracle/mp_oracle.c MPO_EARLY_HOLD_SECONDS
     s.coarse_tol_factor = 0.1;
-    if (const char *e = std::getenv("MAGPROP_AMD_COARSE_TOL_FACTOR")) {   // experiments only
-        const double v = std::atof(e);
-        if (v > 0.0 && v <= 1.0) s.coarse_tol_factor = v;
-    }
     s.coarse_ultra_factor = s.coarse_tol_factor;
-    if (const char *e = std::getenv("MAGPROP_AMD_COARSE_ULTRA_FACTOR")) {   // experiments only
-        const double v = std::atof(e);
-        if (v >= 0.0 && v <= 1.0) s.coarse_ultra_factor = v;
-    }
     s.k4_tol_factor = 0.1;
-    if (const char *e = std::getenv("MAGPROP_AMD_K4_TOL_FACTOR")) {   // experiments only
-        const double v = std::atof(e);
-        if (v > 0.0 && v <= 1.0) s.k4_tol_factor = v;
-    }
     s.ultra_tol = std::min(1.0e-5, 100.0 * s.sweep_tol);
-    if (const char *e = std::getenv("MAGPROP_AMD_ULTRA_TOL")) {   // experiments only (0 disables); kept inside [0, 1e-4]
-        const double v = std::atof(e);
-        if (v >= 0.0 && v <= 1.0e-4) s.ultra_tol = v;
+#ifdef MP_EXPERIMENTS
+    // Developer build only (`make -C magprop_amd/csrc experiments` -> libmagprop_amd_exp.so, selected with MAGPROP_AMD_LIB):
+    // environment overrides of the policy constants for A/B runs (tools/).  The shipped library does not read the
+    // environment, so no benchmark or soak artefact can be produced with loosened settings and leave no trace
+    // (mp_get_policy()[MP_POLICY_EXPERIMENTS] tells the two builds apart; bench.py prints it).
+    {
+        auto env_i = [](const char *name, int lo, int hi, int32_t &dst) { if (const char *e = std::getenv(name)) { const int v = std::atoi(e); if (v >= lo && v <= hi) dst = v; } };
+        auto env_d = [](const char *name, double lo, double hi, double &dst) { if (const char *e = std::getenv(name)) { const double v = std::atof(e); if (v >= lo && v <= hi) dst = v; } };
+        if (const char *e = std::getenv("MAGPROP_AMD_MAX_STRIDE")) {
+            const int v = std::atoi(e);
+            if (v == 1 || v == 2 || v == 4 || v == 8) s.max_kind = v == 1 ? 1 : (v == 2 ? 2 : (v == 4 ? 3 : 4));
+        }
+        if (const char *e = std::getenv("MAGPROP_AMD_SPL")) { const int v = std::atoi(e); if (v == 2 || v == 4) s.force_spl = v; }
+        env_d("MAGPROP_AMD_SWEEP_TOL", 1.0e-14, 1.0e-3, s.sweep_tol);       // (the cfg validation range)
+        env_d("MAGPROP_AMD_STRIDE_TOL", 1.0e-14, 1.0e-3, s.stride_tol);
+        env_d("MAGPROP_AMD_EARLY_HOLD_SECONDS", 0.0, 1.0e6, s.early_hold_t);
+        env_i("MAGPROP_AMD_TROUBLE_LIMIT", 0, 1000, s.trouble_limit);
+        env_i("MAGPROP_AMD_COARSE_MAX_SWEEPS", 2, 64, s.coarse_max_sweeps);
+        env_i("MAGPROP_AMD_FINE_MAX_SWEEPS", 2, 272, s.fine_max_sweeps);
+        env_d("MAGPROP_AMD_COARSE_TOL_FACTOR", 1.0e-3, 1.0, s.coarse_tol_factor);
+        s.coarse_ultra_factor = s.coarse_tol_factor;
+        env_d("MAGPROP_AMD_COARSE_ULTRA_FACTOR", 0.0, 1.0, s.coarse_ultra_factor);
+        env_d("MAGPROP_AMD_K4_TOL_FACTOR", 1.0e-3, 1.0, s.k4_tol_factor);
+        s.ultra_tol = std::min(1.0e-5, 100.0 * s.sweep_tol);
+        env_d("MAGPROP_AMD_ULTRA_TOL", 0.0, 1.0e-4, s.ultra_tol);
     }
+#endif
     // Constants of the tile kinds: steps over 1/8, 1, 2, 4, 8 grid intervals (mp_device.h StrideK).
     // Quadrature matrices of the exponential Adams-Moulton formulas on nodes t_{j+1}, t_j, t_{j-1}, ... of a geometric
     // grid of ratio Q (in units of the step, origin t_j: 1, 0, -1/Q, -(1/Q + 1/Q^2), ...):
@@ -1132,6 +1125,30 @@ int mp_last_tiles(const mp_handle *h, int32_t *out, int n) {
     return m;
 }
 double mp_sweep_tol(const mp_handle *h) { return h ? h->sh.sweep_tol : 0.0; }
+int mp_get_policy(const mp_handle *h, double *out, int n) {
+    if (!h || !out || n < 0) return fail(MP_EINVAL, "mp_get_policy: bad argument");
+    const mp::DevShared &s = h->sh;
+    double v[MP_POLICY_COUNT];
+    v[MP_POLICY_MAX_STRIDE] = (double)(s.max_kind <= 1 ? 1 : (1 << (s.max_kind - 1)));
+    v[MP_POLICY_STRIDE_TOL] = s.stride_tol;
+    v[MP_POLICY_SWEEP_TOL] = s.sweep_tol;
+    v[MP_POLICY_EARLY_HOLD_SECONDS] = s.early_hold_t;
+    v[MP_POLICY_K4_TOL_FACTOR] = s.k4_tol_factor;
+    v[MP_POLICY_COARSE_TOL_FACTOR] = s.coarse_tol_factor;
+    v[MP_POLICY_COARSE_MAX_SWEEPS] = (double)s.coarse_max_sweeps;
+    v[MP_POLICY_FINE_MAX_SWEEPS] = (double)s.fine_max_sweeps;
+    v[MP_POLICY_TROUBLE_LIMIT] = (double)s.trouble_limit;
+    v[MP_POLICY_ULTRA_TOL] = s.ultra_tol;
+    v[MP_POLICY_FORCED_STEPS_PER_LANE] = (double)s.force_spl;
+#ifdef MP_EXPERIMENTS
+    v[MP_POLICY_EXPERIMENTS] = 1.0;
+#else
+    v[MP_POLICY_EXPERIMENTS] = 0.0;
+#endif
+    const int m = std::min(n, (int)MP_POLICY_COUNT);
+    std::copy(v, v + m, out);
+    return m;
+}
 int mp_n_simd(const mp_handle *h) { return h ? h->sh.n_simd : 0; }
 
 }  // extern "C"

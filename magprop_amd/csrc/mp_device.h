@@ -86,8 +86,9 @@ struct DevShared {
     int32_t force_spl;    // experiments: 0 = automatic, else steps per lane (2, 4)
     int32_t max_kind;     // coarsest tile kind allowed: 1, 2, 3, 4 for cfg.max_stride 1, 2, 4, 8
     int32_t coarse_max_sweeps, fine_max_sweeps, trouble_limit;   // sweeps after which a slowly converging tile keeps its converged lanes
-    int32_t early_hold, pad2;   // coarse tiles that start before this grid index (1 024: the first decade or so, where the spin-up
-                                // transients live) are held to a tenth of stride_tol, like the tile behind the sub-steps
+    double early_hold_t;  // coarse tiles that start before this TIME (MP_EARLY_HOLD_SECONDS = 4 s: where the spin-up transients
+                          // live; a physical time, so the "S" grid, whose index 1 024 is at 8 ms, gets the same protection) are
+                          // held to a tenth of stride_tol, like the tile behind the sub-steps
     StrideK sk[kKinds];
     const double *wtab;   // [kWtabSize] quadrature matrices, skipped-point positions and dense-output weights of the tile kinds
     mp_model_cfg cfg;

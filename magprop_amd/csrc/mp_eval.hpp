@@ -622,9 +622,9 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
             const double tol_k = kind >= 2 ? sh.coarse_tol_factor * sh.sweep_tol : sh.sweep_tol;
             const double ultra_k = kind >= 2 ? sh.coarse_ultra_factor * sh.ultra_tol : sh.ultra_tol;
             // (the tile tried at a coarse stride right behind the sub-steps has no calm predecessor to vouch for it: a tenth;
-            // likewise every coarse tile that starts within the first early_hold grid intervals, and steps over 8 intervals:
+            // likewise every coarse tile that starts before t = early_hold_t (4 s), and steps over 8 intervals:
             // oracle/mp_oracle.c)
-            const double tile_tol = (kind >= 2 && (rec_kind == 0 || pos8 < 8 * sh.early_hold)) ? 0.1 * sh.stride_tol : (kind >= 4 ? sh.k4_tol_factor * sh.stride_tol : sh.stride_tol);
+            const double tile_tol = (kind >= 2 && (rec_kind == 0 || t_s < sh.early_hold_t)) ? 0.1 * sh.stride_tol : (kind >= 4 ? sh.k4_tol_factor * sh.stride_tol : sh.stride_tol);
             bool abort_tile = false;
             while (true) {
                 ++sweep;
@@ -881,17 +881,36 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
 
             // ---------------- commit: the tile's image goes to LDS (record for the next tile's history, source of the
             // observations' states)
+            // (curve kernels: in a tile whose kept steps are all longer than tvisc the dense output of Mdisc never uses the
+            // second derivative; the D2 array then carries the node values of Mdisc / Mdotfb its quasi-steady form
+            // interpolates: one reciprocal per step here instead of four per skipped grid point there)
+            bool all_qs = false;
+            Vd<kSPL> ratio;
+            if constexpr (CURVES) {
+                bool lane_qs = true;
+#pragma unroll
+                for (int s = 0; s < kSPL; ++s) lane_qs = lane_qs && (lane * kSPL + s >= keep || h[s] * w.inv_tau >= 1.0);
+                all_qs = kind >= 2 && keep >= 3 && __all(lane_qs);
+                if (all_qs) {
+                    const Vd<kSPL> iS = rcp_fast(S1);
+#pragma unroll
+                    for (int s = 0; s < kSPL; ++s) ratio[s] = M1[s] * iS[s];
+                }
+            }
             __syncthreads();                                                    // earlier readers of the image are done
 #pragma unroll
             for (int s = 0; s < kSPL; ++s) {
                 const int e = lane * kSPL + s + 1;
                 const double dM = fma(-M1[s], w.inv_tau, S1[s]);               // dM/dt = Mdotfb - M/tvisc, and its derivative
-                im.W[e] = wg[s]; im.F[e] = Ef[4 + s]; im.M[e] = M1[s]; im.D[e] = dM; im.D2[e] = fma(-dM, w.inv_tau, dS1[s]);
+                im.W[e] = wg[s]; im.F[e] = Ef[4 + s]; im.M[e] = M1[s]; im.D[e] = dM;
+                im.D2[e] = (CURVES && all_qs) ? ratio[s] : fma(-dM, w.inv_tau, dS1[s]);
                 im.R[e] = d1.rmu[s];
             }
             if (lane == 0) {
                 const double dM = fma(-M_s, w.inv_tau, cS0);
-                im.W[0] = om_s; im.F[0] = cf0; im.M[0] = M_s; im.D[0] = dM; im.D2[0] = fma(-dM, w.inv_tau, cdS0);
+                im.W[0] = om_s; im.F[0] = cf0; im.M[0] = M_s; im.D[0] = dM;
+                if (CURVES && all_qs) { const Vd<1> s0{{cS0}}; im.D2[0] = M_s * rcp_fast(s0)[0]; }
+                else im.D2[0] = fma(-dM, w.inv_tau, cdS0);
             }
             __syncthreads();
 
@@ -949,21 +968,76 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 const int g0 = pos8 >> 3;                                       // grid index of the tile's start
                 const int n_here = pre ? keep >> 3 : keep * ns;                 // grid points this tile adds
                 const size_t o0 = row + (size_t)g0 + 1;
-                // which: 0 Ltot, 1 Lprop, 2 Ldip, 3 Mdisc, 4 omega -> stage[m], m = 1..n_here
+                // Staging index: lanes write their steps' points ns * SPL doubles apart (a 32- or 64-way bank conflict as it
+                // stands); XOR-ing the low five bits with the index of the 32-double block spreads them over the banks and
+                // keeps the coalesced read-out (64 consecutive points) conflict-free.  Stays inside the block: no extra LDS.
+                auto sw = [](int m) { return m ^ ((m >> 5) & 31); };
+                // Dense output (round 4: the Hermite forms were evaluated from scratch at every skipped point before, ~220 VALU
+                // instructions each; now the basis values, which depend on the wave-uniform position theta of the skipped point
+                // only, are formed once per position):
+                //   omega(theta)  = W0 + cD dW + c0 h F0 + c1 h F1                               (cubic Hermite)
+                //   Mdisc(theta)  = M0 + s5 dM + b1 h D0 + b4 h D1 + b2 h^2 E0 + b5 h^2 E1       (quintic, steps shorter than tvisc)
+                // which: 0 Ltot, 1 Lprop, 2 Ldip, 3 Mdisc, 4 omega -> stage[sw(m)], m = 1..n_here
                 auto stage_curve = [&](int which, double *stage) {
                     for (int i = 1; i <= ns; ++i) {
                         Vd<kSPL> Mv = M1, Wv = wg;                              // i == ns: the step ends themselves
                         if (i < ns) {
-                            const double th = wtab_theta(kind, i);
+                            const double th = wtab_theta(kind, i), t2 = th * th, t3 = t2 * th;
+                            const double cD = fma(-2.0, t3, 3.0 * t2), c0 = fma(-2.0, t2, th) + t3, c1 = t3 - t2;
 #pragma unroll
                             for (int s = 0; s < kSPL; ++s) {
                                 const int J = lane * kSPL + s;                 // nodes J (step start) and J + 1 of the image
-                                const double z = h[s] * w.inv_tau;
-                                if (z < 1.0 || keep < 3 || J >= keep)
-                                    Mv[s] = hermite_mdisc(th, h[s], z, im.M[J], im.D[J], im.D2[J], im.M[J + 1], im.D[J + 1], im.D2[J + 1]);
-                                else
-                                    Mv[s] = dense_mdisc_qs(w, im, kind, i, J, keep, fma(th - 1.0, h[s], t_s * tt.E[kind - 1][J + 1]));
-                                Wv[s] = hermite(th, h[s], im.W[J], im.F[J], wg[s], Ef[4 + s]);
+                                const double W0 = im.W[J];
+                                Wv[s] = fma(cD, wg[s] - W0, fma(c0, h[s] * im.F[J], fma(c1, h[s] * Ef[4 + s], W0)));
+                            }
+                            if (all_qs) {
+                                // every kept step of the tile is longer than tvisc: Mdisc = [cubic Lagrange of Mdisc/Mdotfb through the
+                                // four nodes around the step; node values in the image's D2 array] x Mdotfb(t), the fallback rate
+                                // from its binomial series about the step end: (1 + y)^(-5/3), |y| <= 1 - 1/Q <= 0.011, 6 terms: 1e-13
+                                const double thm1 = th - 1.0;
+#pragma unroll
+                                for (int s = 0; s < kSPL; ++s) {
+                                    const int J = lane * kSPL + s;
+                                    const int l0 = max(min(J - 1, keep - 3), 0), variant = min(J - l0, 2);
+                                    const int base = kWtabDense + ((kind - 2) * 7 + (i - 1)) * 12 + variant * 4;
+                                    double r = 0.0;
+#pragma unroll
+                                    for (int k = 0; k < 4; ++k) r = fma(g_wtab[base + k], im.D2[l0 + k], r);
+                                    const double y = thm1 * (h[s] * w.inv_tfb * iu1[s]);   // (theta - 1) h / (t_{J+1} + tfb)
+                                    double P = fma(y, 26180.0 / 6561.0, -2618.0 / 729.0);
+                                    P = fma(y, P, 770.0 / 243.0);
+                                    P = fma(y, P, -220.0 / 81.0);
+                                    P = fma(y, P, 20.0 / 9.0);
+                                    P = fma(y, P, -5.0 / 3.0);
+                                    P = fma(y, P, 1.0);
+                                    Mv[s] = r * (S1[s] * P);
+                                }
+                            } else {
+                                const double s5 = t3 * fma(th, fma(th, 6.0, -15.0), 10.0);          // the quintic's basis (hermite5)
+                                const double b1 = fma(t3, fma(th, fma(th, -3.0, 8.0), -6.0), th);
+                                const double b4 = t3 * fma(th, fma(th, -3.0, 7.0), -4.0);
+                                const double b2 = 0.5 * t2 * fma(th, fma(th, fma(th, -1.0, 3.0), -3.0), 1.0);
+                                const double b5 = 0.5 * t3 * fma(th, fma(th, 1.0, -2.0), 1.0);
+                                bool any_qs = false;
+#pragma unroll
+                                for (int s = 0; s < kSPL; ++s) {
+                                    const int J = lane * kSPL + s;
+                                    const double hs = h[s], hh = hs * hs, M0 = im.M[J], dMs = M1[s] - M0;
+                                    const double hD0 = hs * im.D[J], hD1 = hs * im.D[J + 1];
+                                    const bool shortstep = hs * w.inv_tau < 1.0;
+                                    const double quint = fma(s5, dMs, M0) + fma(b1, hD0, b4 * hD1) + hh * fma(b2, im.D2[J], b5 * im.D2[J + 1]);
+                                    const double cub = fma(cD, dMs, fma(c0, hD0, fma(c1, hD1, M0)));
+                                    Mv[s] = shortstep ? quint : cub;
+                                    any_qs = any_qs || !(shortstep || keep < 3 || J >= keep);
+                                }
+                                if (__any(any_qs)) {   // the one tile in which the steps outgrow tvisc: node ratios formed on the spot
+#pragma unroll
+                                    for (int s = 0; s < kSPL; ++s) {
+                                        const int J = lane * kSPL + s;
+                                        if (!(h[s] * w.inv_tau < 1.0 || keep < 3 || J >= keep))
+                                            Mv[s] = dense_mdisc_qs(w, im, kind, i, J, keep, fma(th - 1.0, h[s], t_s * tt.E[kind - 1][J + 1]));
+                                    }
+                                }
                             }
                         }
                         Vd<kSPL> val;
@@ -978,26 +1052,33 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
 #pragma unroll
                         for (int s = 0; s < kSPL; ++s) {
                             const int e = lane * kSPL + s;                     // step index in the tile
-                            if (pre) { if ((e & 7) == 7) stage[(e >> 3) + 1] = val[s]; }
-                            else stage[e * ns + i] = val[s];
+                            if (pre) { if ((e & 7) == 7) stage[sw((e >> 3) + 1)] = val[s]; }
+                            else stage[sw(e * ns + i)] = val[s];
                         }
                     }
                 };
-                auto store_curve = [&](double *dst, const double *stage, double div) {
+                // x / 1e50 correctly rounded without the division sequence (one per stored grid point): q = x r, then one
+                // Newton correction with the exact remainder (r = fl(1e-50)); div == 1: the value itself
+                auto store_curve = [&](double *dst, const double *stage, bool scale) {
                     for (int c = 0; c * 64 < n_here; ++c) {
                         const int m = c * 64 + lane;
-                        if (m < n_here) dst[o0 + m] = stage[m + 1] / div;
+                        if (m < n_here) {
+                            const double v = stage[sw(m + 1)];
+                            double q = v;
+                            if (scale) { const double q0 = v * 1.0e-50; q = fma(fma(-q0, 1.0e50, v), 1.0e-50, q0); }
+                            dst[o0 + m] = q;
+                        }
                     }
                 };
                 stage_curve(0, Lbuf);
-                if (lane == 0) Lbuf[0] = L_s;
+                if (lane == 0) Lbuf[sw(0)] = L_s;
                 __syncthreads();
-                if (a.ltot) store_curve(a.ltot, Lbuf, 1.0e50);
+                if (a.ltot) store_curve(a.ltot, Lbuf, true);
                 if (a.want_chi2) {
                     const int g_hi = end_kept8 >> 3;
                     if (ob_g >= g0 && ob_g < g_hi) {
                         const int m = ob_g - g0;
-                        const double La = Lbuf[m], Lb = Lbuf[m + 1];
+                        const double La = Lbuf[sw(m)], Lb = Lbuf[sw(m + 1)];
                         const double mod = fma((Lb - La) * ob_idt, ob_dx, La) / 1.0e50;   // np.interp, then /1e50
                         const double res = (ob_y - mod) / ob_ye;
                         chi = fma(res, res, chi);
@@ -1010,27 +1091,27 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                             const int g = sh.obs_g[jj];
                             if (g < g0 || g >= g_hi) continue;
                             const int m = g - g0;
-                            const double La = Lbuf[m], Lb = Lbuf[m + 1];
+                            const double La = Lbuf[sw(m)], Lb = Lbuf[sw(m + 1)];
                             const double mod = fma((Lb - La) * sh.obs_idt[jj], sh.obs_dx[jj], La) / 1.0e50;
                             const double res = (sh.obs_y[jj] - mod) / sh.obs_yerr[jj];
                             chi = fma(res, res, chi);
                         }
                     }
                 }
-                L_s = Lbuf[n_here];
+                L_s = Lbuf[sw(n_here)];
                 __syncthreads();                                                // the staging area is reused below / by the next tile
                 // the other curves (mp_model_lc only) go through the same staging area, one at a time
-                auto put = [&](double *dst, int which, double div) {
+                auto put = [&](double *dst, int which, bool scale) {
                     if (!dst) return;                                           // wave-uniform
                     stage_curve(which, Lbuf);
                     __syncthreads();
-                    store_curve(dst, Lbuf, div);
+                    store_curve(dst, Lbuf, scale);
                     __syncthreads();
                 };
-                put(a.lprop, 1, 1.0e50);
-                put(a.ldip, 2, 1.0e50);
-                put(a.mdisc, 3, 1.0);
-                put(a.omega, 4, 1.0);
+                put(a.lprop, 1, true);
+                put(a.ldip, 2, true);
+                put(a.mdisc, 3, false);
+                put(a.omega, 4, false);
             }
 
             // ---------------- carry the end of the kept steps to the next tile

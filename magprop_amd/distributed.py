@@ -142,6 +142,12 @@ class HipShardEngine:
         """(pos, lnprob, n_accepted) as numpy arrays (synchronises)."""
         return self.s.get_last_sample()
 
+    def drain_bad(self):
+        """Move the device window of failed proposals into the library's host log (synchronises the device) and append
+        the new rows to the sampler's fbad file, if it has one."""
+        self.s.get_bad(first_row=0, max_rows=0)
+        self.s._flush_fbad()
+
 
 class DistributedEnsembleSampler:
     """emcee's stretch move on an ensemble whose walkers are sharded over the process group, one fused kernel and ONE
@@ -169,7 +175,19 @@ class DistributedEnsembleSampler:
         self.always_gather = always_gather   # run the collective even in a group of one (exercises RCCL on a 1-GPU box)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        self.whole_step = (hasattr(engine, "step_shard") and engine.whole_step_ok(self.world)) if whole_step is None else bool(whole_step)
+        if whole_step is None:
+            ok = bool(hasattr(engine, "step_shard") and engine.whole_step_ok(self.world))
+            # The protocol fixes the row width and the number of rows of the all-gather, so every rank must choose the same
+            # one: the local verdict depends on the local device (its SIMD count), and ranks on different devices or
+            # partitions could disagree.  ONE all-reduce(MIN) at construction settles it.
+            if self.world > 1:
+                v = torch.tensor([1 if ok else 0], dtype=torch.int32,
+                                 device=engine.device if dist.get_backend(group) == "nccl" else "cpu")
+                dist.all_reduce(v, op=dist.ReduceOp.MIN, group=group)
+                ok = bool(int(v.item()))
+            self.whole_step = ok
+        else:
+            self.whole_step = bool(whole_step)
         n_units = engine.step_blocks if self.whole_step else engine.n_slots        # what is sharded: blocks of a step / slots of a half
         self.lo, self.hi, self.per = shard_range(n_units, self.rank, self.world)
         R = engine.step_row_doubles if self.whole_step else engine.row_doubles
@@ -178,6 +196,15 @@ class DistributedEnsembleSampler:
         alone = self.world == 1 and not always_gather
         self.rows = self.send if alone else torch.zeros(self.per * self.world, R, dtype=torch.float64, device=dev)
         self.iteration = 0
+        self.drain_every = 256         # steps between drains of the device window of failed proposals (fbad)
+
+    def _drain_bad(self):
+        """The sharded entry points never drain the 65 536-row device window of failed proposals themselves (they only
+        enqueue work); a long run started prior-wide would overflow it and lose fbad rows.  Draining synchronises the
+        device, so it happens every `drain_every` steps and at the end of run_mcmc, not per step."""
+        drain = getattr(self.engine, "drain_bad", None)
+        if drain is not None:
+            drain()
 
     def _gather(self):
         if self.rows is self.send:
@@ -205,12 +232,18 @@ class DistributedEnsembleSampler:
                 self._gather()     # row index == block index
                 e.step_apply(self.rows, chain[step] if store else None, lnp[step] if store else None)
                 self.iteration += 1
+                if self.iteration % self.drain_every == 0:
+                    self._drain_bad()
                 continue
             for half in (0, 1):
                 e.halfstep_shard(half, self.lo, self.hi, self.send)
                 self._gather()     # rank r's block lands at rows [r*per, (r+1)*per): row index == slot index (shard_range)
                 e.halfstep_apply(half, self.rows, chain[step] if store else None, lnp[step] if store else None)
             self.iteration += 1
+            if self.iteration % self.drain_every == 0:
+                self._drain_bad()
+        if nsteps > 0:
+            self._drain_bad()
         return chain, lnp
 
     @property

@@ -102,7 +102,14 @@ def use(cfg, GRBtype=None, device=-1):
 
 
 def clear():
+    """Close every cached engine.  An engine that a thread is using (inside `with use(...)`) is closed only after that
+    thread has left its block: the cache forgets all engines at once, under the module lock, and then each one's own lock is
+    taken before its handle is destroyed (use() holds that lock for the whole block; mp_destroy on a handle in use would be a
+    use-after-free on the native side).  A thread that was still waiting for the engine's lock finds it closed and looks up a
+    fresh one (use() above)."""
     with _lock:
-        for e in _handles.values():
-            e.handle.close()
+        engines = list(_handles.values())
         _handles.clear()
+    for e in engines:
+        with e.lock:
+            e.handle.close()

@@ -16,7 +16,7 @@ class LogProb:
                  device=-1, fbad=None, sweep_tol=None, max_stride=None):
         """sweep_tol: Newton-sweep tolerance of the time-parallel solver (0 = the library default,
         include/magprop_amd.h MP_SWEEP_TOL_DEFAULT).  max_stride: grid intervals one step of the solver may span (1, 2, 4, 8;
-        0 = the library default 4; 1 = every grid interval is a step)."""
+        0 = the library default 8, MP_MAX_STRIDE_DEFAULT; 1 = every grid interval is a step)."""
         tol_kw = {} if sweep_tol is None else {"sweep_tol": float(sweep_tol)}   # None: _capi.DEFAULT_SWEEP_TOL
         if max_stride is not None:                                              # None: _capi.DEFAULT_MAX_STRIDE
             tol_kw["max_stride"] = int(max_stride)

@@ -411,7 +411,7 @@ typedef struct {
 
 #define MPO_PRE_FINE 32   /* grid intervals covered by the sub-stepped tiles */
 #define MPO_PRE_SUB 8     /* sub-steps per grid interval there */
-#define MPO_EARLY_HOLD 1024   /* coarse tiles starting before this grid index are held to a tenth of stride_tol */
+#define MPO_EARLY_HOLD_SECONDS 4.0   /* coarse tiles starting before this time are held to a tenth of stride_tol */
 #define MPO_MIN_KEEP 8    /* a coarse tile is kept if at least this many lanes precede the first offending one */
 
 /* omega, f, Mdisc, dMdisc/dt at time t <= the last accepted node (Hermite on the accepted steps; exact at nodes) */
@@ -564,10 +564,12 @@ int mpo_trajectory_mode(const mpo_cfg *c, const double *pars, int ndim, const do
             /* the tile tried at a coarse stride right behind the sub-steps has no calm predecessor to vouch for it: a tenth;
                steps over 8 intervals: likewise (with the plain bound the prior-wide golden points come out up to 1.0e-7 off
                the reference's tight values instead of 0.5e-7; with 0.3 one soak walker in 32 768 is 1.01e-7 off the fixed steps) */
-            /* coarse tiles that start within the first MPO_EARLY_HOLD grid intervals (where the spin-up transients live) too:
+            /* coarse tiles that start before t = MPO_EARLY_HOLD_SECONDS (where the spin-up transients live) too:
                of 262 144 soak walkers one, a model far above its data whose Lprop cancels to 1e-2, came out 1.45e-7 off the
-               fixed steps through stride-4 tiles at t < 16 s that pass the plain bound; held to the tenth: 7.3e-8, no cost */
-            const double tile_tol = (after_pre || s >= 8 || i0 < MPO_EARLY_HOLD) ? 0.1 * stride_tol : stride_tol;
+               fixed steps through stride-4 tiles at t < 16 s that pass the plain bound; held to the tenth: 7.3e-8, no cost.
+               (Round 3 expressed this as grid index 1 024 = 4.1 s on the reference's "L" grid; on its "S" grid that index is
+               at 8 ms.  A time protects both.) */
+            const double tile_tol = (after_pre || s >= 8 || t0 < MPO_EARLY_HOLD_SECONDS) ? 0.1 * stride_tol : stride_tol;
             int first = (nsolved < nc) ? nsolved / spl : 64;
             for (int l = 0; l < first && l * spl < nc; ++l)
                 for (int e = l * spl; e < (l + 1) * spl && e < nsolved; ++e)

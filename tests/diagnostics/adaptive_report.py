@@ -1,6 +1,6 @@
 """Report (GPU box): the product's default stride-adaptive solver and the fixed-step mode against the reference's
 tight-integrator values and the serial C restatement, over every golden point; tiles per walker and sweeps per tile.
-    python tests/adaptive_report.py [--quick]"""
+    python tests/diagnostics/adaptive_report.py [--quick]"""
 import json
 import os
 import sys
@@ -8,7 +8,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from conftest import TYPES  # noqa: E402

@@ -2,7 +2,7 @@
 next to the serial restatement's adaptive mode on the same point."""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from conftest import TYPES
 from magprop_amd import LogProb

@@ -5,6 +5,8 @@
   * config 5 — the four GRB types, 1 024 walkers each, light curves of mixed lengths, ONE launch, plain
     and through the fused ensemble sampler.
 """
+import time
+
 import numpy as np
 import pytest
 
@@ -268,7 +270,7 @@ def test_config5_through_the_ensemble_sampler(gsynth, glonglc, tarr):
 
 # ---------------------------------------------------------------- threads and streams (include/magprop_amd.h contract)
 def test_one_handle_from_several_threads_and_streams(gsynth, tarr):
-    """A handle that holds a long light curve owns per-walker scratch rows: host calls from several Python threads
+    """A handle that holds a long light curve used to own per-walker scratch rows (rounds 1-3; none since round 4): host calls from several Python threads
     (ctypes drops the GIL) and device calls on two torch streams must give the results of the same calls made one
     after the other."""
     import threading
@@ -295,7 +297,7 @@ def test_one_handle_from_several_threads_and_streams(gsynth, tarr):
         t.join()
     for w, g_ in zip(want, got):
         assert np.array_equal(w, g_)
-    # device entry on two streams, interleaved: the library orders the launches that share the scratch rows
+    # device entry on two streams, interleaved: the launches share nothing writable and may overlap
     dev = torch.device("cuda", lp_.handle.device)
     s1, s2 = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
     tb = [torch.from_numpy(b).to(dev) for b in batches]
@@ -309,6 +311,23 @@ def test_one_handle_from_several_threads_and_streams(gsynth, tarr):
     torch.cuda.synchronize(dev)
     for w, o in zip(want, outs):
         assert np.array_equal(w, o.cpu().numpy())
+    # ... and they DO overlap (round 4: no scratch rows, no event between launches of one handle): two 300-walker launches of
+    # the long-light-curve kernel fit the device side by side, so alternating two streams must finish clearly sooner than
+    # the same launches on one stream
+    k = 2                                                      # the 300-walker batch
+    o2 = torch.empty_like(outs[k])
+
+    def timed(streams, reps=40):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for r in range(reps):
+            with torch.cuda.stream(streams[r % len(streams)]):
+                lp_.lnprob_device(tb[k], out=outs[k] if r % 2 == 0 else o2, ds_id=ti[k])
+        torch.cuda.synchronize(dev)
+        return time.perf_counter() - t0
+    timed([s1, s2], 10)
+    one, two = min(timed([s1]) for _ in range(3)), min(timed([s1, s2]) for _ in range(3))
+    assert two < 0.85 * one, (one, two)
 
 
 # ---------------------------------------------------------------- datasets: bad ids, incremental registration
@@ -358,7 +377,7 @@ def test_registering_64_datasets_is_incremental(gsynth, tarr):
     rng = np.random.default_rng(64)
     base = mpa.model_lum(CANON["Humped"])[1]
     sets = [_long_set(rng, tarr, base, int(m)) for m in rng.integers(8, 400, 64)]
-    sets[40] = _long_set(rng, tarr, base, 1944)                 # forces the arena (and the scratch rows) to grow midway
+    sets[40] = _long_set(rng, tarr, base, 1944)                 # forces the arena to grow midway
     lp = LogProb(*sets[0])
     t0 = time.perf_counter()
     for s in sets[1:]:
@@ -370,7 +389,7 @@ def test_registering_64_datasets_is_incremental(gsynth, tarr):
     got = lp(P, ds_id=np.arange(64, dtype=np.int32))
     for k in (0, 1, 17, 39, 40, 41, 63):
         alone = LogProb(*sets[k])
-        assert np.isclose(alone(P[k:k + 1])[0], got[k], rtol=1e-9, atol=0.0), k     # (kernel builds with / without scratch rows)
+        assert np.isclose(alone(P[k:k + 1])[0], got[k], rtol=1e-9, atol=0.0), k     # (kernel builds with / without the long-light-curve path)
     # replace slot 17 by another light curve: slot 17 changes, the others do not
     lp.handle.set_dataset(17, *sets[3])
     again = lp(P, ds_id=np.arange(64, dtype=np.int32))

@@ -13,14 +13,15 @@ from conftest import (CANON, LC_REF_RTOL, LC_TIGHT_RTOL, REF_ATOL, REF_RTOL, TIG
 pytestmark = pytest.mark.gpu
 
 GPU_VS_C_RTOL = 1e-10   # HIP kernel (strict sweep tolerance) vs serial C oracle: same scheme, different evaluation order / algebra
-DEFAULT_VS_STRICT_RTOL = 1e-7   # lnprob at the product defaults (sweep tolerance 1e-7, steps over 1/2/4 grid intervals) vs strict
+DEFAULT_VS_STRICT_RTOL = 1e-7   # lnprob at the product defaults (sweep tolerance 1e-7, steps over 1/2/4/8 grid intervals) vs strict
                                 # (1e-9, every grid interval a step); observed <= 5e-8 (soak: tests/test_gpu_soak.py)
 CROSS_VARIANT_RTOL = 1e-7       # kernel variants (tile lengths: the adaptive tiles fall differently) against each other
 
 
 def kernel_variant(n):
-    """(wavefronts per walker, steps per lane) the library picks for a batch of n (mp_device.h): batches of different
-    variants agree to CROSS_VARIANT_RTOL, batches of the same variant bit for bit."""
+    """(wavefronts per walker, steps per lane) the library picks for a batch of n (mp_device.h; always ONE wavefront per walker
+    since round 3, four steps per lane up to one wave per SIMD, two beyond): batches of different variants agree to
+    CROSS_VARIANT_RTOL, batches of the same variant bit for bit."""
     return (1, 4) if n <= 1024 else (1, 2)
 LOG_MASK = 0b111100
 
@@ -351,9 +352,10 @@ def test_mixed_datasets_and_lengths(mpa, co, gsynth, tarr, strict):
 
 @pytest.mark.parametrize("nw", [40, 400, 700, 1700])
 def test_long_light_curves_every_kernel_variant(mpa, co, gsynth, tarr, nw, strict):
-    """Real GRB light curves have up to 1 944 points (data/real_data/): observations beyond the register-resident
-    ones go through the per-walker scratch rows.  40 / 400 walkers run on the producer/consumer pair of wavefronts,
-    700 on the 4-steps-per-lane and 1 700 on the 2-steps-per-lane kernel; a few walkers are checked against the C oracle, all against each other."""
+    """Real GRB light curves have up to 1 944 points (data/real_data/): observations beyond the 64 register-resident
+    ones are scored from the tile image as their tile is committed (the LONG kernel builds).  40 / 400 / 700 walkers run
+    on the 4-steps-per-lane kernel, 1 700 on the 2-steps-per-lane one; a few walkers are checked against the C oracle,
+    all against each other."""
     from magprop_amd import LogProb
     rng = np.random.default_rng(19)
     base = mpa.model_lum(CANON["Classic"])
@@ -382,17 +384,17 @@ def test_long_light_curves_every_kernel_variant(mpa, co, gsynth, tarr, nw, stric
         ref, _ = co.lnprob_batch(co.cfg_synth(), P[i], tarr, x, y, yerr, gsynth["prior_lower"],
                                  gsynth["prior_upper"], LOG_MASK)
         assert abs(out[i] - ref[0]) <= GPU_VS_C_RTOL * abs(ref[0]) * 10 + 1e-9, (i, ids[i], out[i], ref[0])
-    # the same walkers in a batch of 8 (producer/consumer pair) agree to rounding
+    # the same walkers in a batch of 8 agree to rounding
     sub = np.r_[0:3, 4:9]
     small = lp_(P[sub], ds_id=ids[sub])
     assert np.allclose(small, out[sub], rtol=1e-10, atol=1e-9)
-    # repeatable bit for bit (the scratch rows carry nothing over from one launch to the next)
+    # repeatable bit for bit (a launch carries nothing over from the one before)
     assert np.array_equal(lp_(P, ds_id=ids), out)
 
 
 @pytest.mark.parametrize("n", [112, 410, 1944])
 def test_long_light_curves_vs_reference(mpa, gsynth, glonglc, n):
-    """The scratch-row path against the reference itself (golden_longlc.npz: reference model_lum + chi-square over
+    """The long-light-curve path against the reference itself (golden_longlc.npz: reference model_lum + chi-square over
     112 / 410 / 1944 observed times, a quarter of them clustered in ten grid intervals)."""
     from magprop_amd import LogProb
     x, y, yerr = glonglc[f"synth{n}_ds"]
@@ -650,7 +652,7 @@ def test_light_curves_with_real_swift_time_stamps(mpa, gswift, gsynth, name):
     """Observation times of real Swift bursts (1 921 / 74 inside the synth grid, most of them in the first hundred seconds:
     up to 40 per grid interval early, none for thousands of intervals late; every row from 1e-3 s on for the library
     variant's short-GRB grid): the reference's values, default and tight integrator, through both front ends; the long one
-    also inside a 1 300-walker batch (the 2-steps-per-lane kernel with scratch rows)."""
+    also inside a 1 300-walker batch (the 2-steps-per-lane LONG kernel)."""
     import pandas as pd
     from magprop_amd import LogProb
     x, y, yerr = gswift[f"swift_{name}_ds"]

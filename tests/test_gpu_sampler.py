@@ -115,7 +115,7 @@ def test_whole_step_launch_equals_half_step_launches(gsynth):
             ref_chain, ref_lnp, ref_acc = so.run(q0, 50, 23)
             assert np.array_equal(s.get_chain(), ref_chain) and np.array_equal(s.acceptance_fraction, ref_acc / 50), (nwalk, w)
     # posterior: one ensemble near the truth; four ensembles, each on its own dataset; walkers all over the prior box
-    # (failed proposals); a 600-point light curve (scratch rows: the two candidates of a walker must not share one)
+    # (failed proposals); a 600-point light curve (the LONG kernel builds)
     sets = [(gsynth[n + "_x"], gsynth[n + "_y"], gsynth[n + "_yerr"]) for n in TYPES]
     lo, hi = gsynth["prior_lower"], gsynth["prior_upper"]
     xl = np.sort(10.0 ** rng.uniform(0.0, 6.0, 600))
@@ -353,7 +353,7 @@ def test_sharded_sampler_gaussian_two_ranks_equal_the_fused_chain_and_the_oracle
 
 
 def test_sharded_sampler_posterior_two_ranks_equal_the_fused_chain(gsynth):
-    """The magnetar posterior, two ensembles (a 50-point and a 300-point light curve: scratch rows in play), 2 x 48
+    """The magnetar posterior, two ensembles (a 50-point and a 300-point light curve: the LONG kernel builds in play), 2 x 48
     walkers over two ranks: bit-identical to the single-GPU fused sampler, failed proposals logged on both ranks."""
     from magprop_amd import EnsembleSampler, engine, model_lum
     rng = np.random.default_rng(31)

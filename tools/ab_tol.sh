@@ -1,5 +1,7 @@
 #!/bin/bash
 # Newton-sweep tolerance A/B on one box: kernel time near the truth / prior-wide / burnt-in, per batch size.
+# the MAGPROP_AMD_* overrides are honoured by the developer build only: make -C magprop_amd/csrc experiments
+export MAGPROP_AMD_LIB=${MAGPROP_AMD_LIB:-$PWD/magprop_amd/libmagprop_amd_exp.so}
 for rep in 1 2; do
 for n in 1024 4096 8192 512; do
   for tol in 1e-9 1e-7; do

@@ -1,5 +1,5 @@
 """Diagnostic (GPU box): one golden point under several solver settings, with its tile sequence.
-    python tests/adaptive_one.py <set> <index> [batch]      set: flagscan | flagscan2_<type>"""
+    python tools/adaptive_one.py <set> <index> [batch]      set: flagscan | flagscan2_<type>"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

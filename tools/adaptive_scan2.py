@@ -1,4 +1,6 @@
-"""Scan (GPU box): launch time of near-truth / burnt-in / prior-wide ensembles of 1 024 walkers under the solver's experiment
+"""(MAGPROP_AMD_* overrides: developer build only -- make -C magprop_amd/csrc experiments and
+MAGPROP_AMD_LIB=$PWD/magprop_amd/libmagprop_amd_exp.so.)
+Scan (GPU box): launch time of near-truth / burnt-in / prior-wide ensembles of 1 024 walkers under the solver's experiment
 knobs (environment of the process: MAGPROP_AMD_COARSE_MAX_SWEEPS, MAGPROP_AMD_FINE_MAX_SWEEPS, MAGPROP_AMD_TROUBLE_LIMIT ...)."""
 import os, sys, time
 import numpy as np

@@ -1,5 +1,5 @@
 """Diagnostic (GPU box): the soak's walkers (tests/test_gpu_soak.py, any N) at the product's defaults against the fixed-step
-strict kernel; the worst walkers with their tile sequences.   python tests/adaptive_soak_worst.py [N]"""
+strict kernel; the worst walkers with their tile sequences.   python tools/adaptive_soak_worst.py [N]"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,4 +1,6 @@
-"""Timing (GPU box): kernel time at several batch sizes / steps per lane / max_stride, with tiles and sweeps."""
+"""(MAGPROP_AMD_* overrides: developer build only -- make -C magprop_amd/csrc experiments and
+MAGPROP_AMD_LIB=$PWD/magprop_amd/libmagprop_amd_exp.so.)
+Timing (GPU box): kernel time at several batch sizes / steps per lane / max_stride, with tiles and sweeps."""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

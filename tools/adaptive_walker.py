@@ -1,6 +1,6 @@
 """Diagnostic (GPU box): ONE walker (sampler coordinates on the command line, dataset index) under several solver settings,
 in a batch of 4 096 copies (2 steps per lane) and of 64 (4 steps per lane).
-    python tests/adaptive_walker.py <ds> p0 p1 p2 p3 p4 p5"""
+    python tools/adaptive_walker.py <ds> p0 p1 p2 p3 p4 p5"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,5 +1,7 @@
 #!/bin/bash
 # Steps per lane (tile length) against batch size on one box: MAGPROP_AMD_SPL=2|4 forces the one-wavefront kernels.
+# the MAGPROP_AMD_* overrides are honoured by the developer build only: make -C magprop_amd/csrc experiments
+export MAGPROP_AMD_LIB=${MAGPROP_AMD_LIB:-$PWD/magprop_amd/libmagprop_amd_exp.so}
 for n in 256 512 768 1024 1536 2048 4096; do
   for spl in 4 2; do
     MAGPROP_AMD_SPL=$spl python bench.py --no-cpu-baseline --no-mcmc --no-extra --nwalk $n --steps 100 --warmup 5 2>/dev/null | \

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Experiment: accuracy and speed against the Newton-sweep tolerance (MAGPROP_AMD_SWEEP_TOL), per kernel variant.
+"""(MAGPROP_AMD_* overrides: developer build only -- make -C magprop_amd/csrc experiments and
+MAGPROP_AMD_LIB=$PWD/magprop_amd/libmagprop_amd_exp.so.)
+Experiment: accuracy and speed against the Newton-sweep tolerance (MAGPROP_AMD_SWEEP_TOL), per kernel variant.
 Accuracy is measured against the kernel's own result at tolerance 1e-13 on the golden parameter clouds and the
 1 500-point prior-wide scan; speed on a near-truth batch.  python tools/tol_scan.py   (GPU box)"""
 import json
