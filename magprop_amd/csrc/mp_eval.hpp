@@ -311,6 +311,7 @@ struct TileImage {
     double D[kN];   // dMdisc/dt
     double D2[kN];  // d2Mdisc/dt2
     double R[kN];   // uncapped Alfven radius (the branch of the right-hand side at the start of the next tile)
+    double C[4];    // the fallback rate, its time derivative and tfb / (t + tfb) at the last kept node: the next tile's start
 };
 
 // Mdisc at the i-th skipped grid point of step J (time t) of a tile of `keep` kept steps where the step is longer than the
@@ -355,13 +356,16 @@ MP_DEV void image_state(const DevShared &sh, const Walker &w, const TileImage<SP
 // Phase profile (developer build, `make -C magprop_amd/csrc phase-profile`, tools/phase_profile.py): the shader clock is read
 // between the sections of a tile and the per-section sums of one walker replace its tile log.  Compiles to nothing otherwise.
 #ifdef MP_PHASE_PROFILE
-#define MP_PHASE_DECL unsigned long long ph_t = __builtin_amdgcn_s_memtime(), ph_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define MP_PHASE_N 18
+#define MP_PHASE_DECL unsigned long long ph_t = __builtin_amdgcn_s_memtime(), ph_acc[MP_PHASE_N] = {0};
 #define MP_PHASE(i) { const unsigned long long ph_n = __builtin_amdgcn_s_memtime(); ph_acc[i] += ph_n - ph_t; ph_t = ph_n; }
-#define MP_PHASE_DUMP if (a.tile_log && lane == 0) { for (int i = 0; i < 10; ++i) a.tile_log[(size_t)walker * MP_TILE_LOG + i] = (int32_t)min(ph_acc[i], 0x7FFFFFFFull); }
+#define MP_PHASE_DUMP if (a.tile_log && lane == 0) { for (int i = 0; i < MP_PHASE_N; ++i) a.tile_log[(size_t)walker * MP_TILE_LOG + i] = (int32_t)min(ph_acc[i], 0x7FFFFFFFull); }
+#define MP_TILE_LOG_ON false   // (the per-tile words would be overwritten by the dump, and their stores would be waited for inside the timed sections)
 #else
 #define MP_PHASE_DECL
 #define MP_PHASE(i)
 #define MP_PHASE_DUMP
+#define MP_TILE_LOG_ON true
 #endif
 
 // ---------------------------------------------------------------- the kernel
@@ -383,6 +387,15 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
 
     Walker w;
     int status = walker_setup(sh, a, par, w);
+    if constexpr (SPL == 2) {
+        // two waves per SIMD: 256 vector registers per wave.  The walker's constants are wave-uniform; in scalar registers
+        // (spilled, if at all, to lanes of a vector register, not to memory) they free 30 vector registers and the kernel
+        // no longer reloads spilled values from scratch memory inside the tile loop.
+        w.inv_tau = uniform(w.inv_tau); w.S_amp = uniform(w.S_amp); w.inv_tfb = uniform(w.inv_tfb); w.Crm = uniform(w.Crm);
+        w.sqrtCrm = uniform(w.sqrtCrm); w.Crm15 = uniform(w.Crm15); w.DI = uniform(w.DI); w.D = uniform(w.D);
+        w.armI = uniform(w.armI); w.kc = uniform(w.kc); w.sqrt_kc = uniform(w.sqrt_kc); w.Kc = uniform(w.Kc);
+        w.dipeff = uniform(w.dipeff); w.propeff = uniform(w.propeff); w.f_beam = uniform(w.f_beam);
+    }
 
     // ---- state carried from tile to tile (all wave-uniform)
     double t_s = sh.t0;
@@ -419,15 +432,20 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
     // The first 64 observations of the walker's light curve live in registers, one per lane (time-sorted;
     // every synthetic set has 50).  The further observations of a longer light curve are scored tile by tile, when the
     // tile that brackets them is committed (below).
+    // (mode A needs only the grid interval while the tiles go by; the other four values of the observation are fetched
+    // behind the last tile, where they are used: eight registers less across the tile loop, which the 2-steps-per-lane
+    // kernels, two waves per SIMD, were spilling to scratch memory)
     int ob_g = -1;
     double ob_dx = 0.0, ob_idt = 0.0, ob_y = 0.0, ob_ye = 1.0;
     if (a.want_chi2 && lane < dsd.n_obs) {
         const int jj = dsd.obs_off + lane;
         ob_g = sh.obs_g[jj];
-        ob_dx = sh.obs_dx[jj];
-        ob_idt = sh.obs_idt[jj];
-        ob_y = sh.obs_y[jj];
-        ob_ye = sh.obs_yerr[jj];
+        if constexpr (CURVES) {
+            ob_dx = sh.obs_dx[jj];
+            ob_idt = sh.obs_idt[jj];
+            ob_y = sh.obs_y[jj];
+            ob_ye = sh.obs_yerr[jj];
+        }
     }
     // LONG: compiled with the path for light curves of more than 64 points (the launcher picks this variant when the
     // handle holds such a dataset; the short variant keeps that code out of the register budget)
@@ -460,6 +478,14 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                                                  // when the indicator of a full tile over 4 intervals promotes it
         int opt_kind = max_kind;                 // the kind that is tried after a calm tile over single intervals: lowered when
                                                  // such an attempt fails outright, raised when the indicator promotes a tile
+        double cS0, cdS0, ciu0;                  // the fallback rate at the tile's start, its time derivative, tfb / (t_s + tfb)
+        {
+            const Vd<1> tsv{{t_s}};
+            Vd<1> dS0, iu0;
+            cS0 = mdot_fb_d(w, tsv, dS0, iu0)[0];
+            cdS0 = dS0[0];
+            ciu0 = iu0[0];
+        }
         // Each lane owns kSPL consecutive steps of the tile: steps lane*kSPL + s, s = 0..kSPL-1.
         MP_PHASE(0)
         while (pos8 < end8) {
@@ -488,15 +514,9 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 S1 = mdot_fb_d(w, tb, dS1, iu1);
             }
 
-            // ---------------- the fallback rate at the tile's start (its derivative: d2Mdisc/dt2 of the image's node 0)
-            double cS0, cdS0, ciu0;
-            {
-                const Vd<1> tsv{{t_s}};
-                Vd<1> dS0, iu0;
-                cS0 = mdot_fb_d(w, tsv, dS0, iu0)[0];
-                cdS0 = dS0[0];
-                ciu0 = iu0[0];
-            }
+            MP_PHASE(10)
+            // (the fallback rate at the tile's start, its derivative and tfb / (t + tfb) -- cS0, cdS0, ciu0 -- are the values the
+            // previous tile computed at its last kept step end, carried through the image; the first tile's: before the loop)
             // ---------------- history at this tile's spacing: (omega_dot, omega) at the three (predictor: four) previous
             // points come from the record of the last kept tile
             double cf1 = cf0, cf2 = cf0, cf3 = cf0, cw1 = om_s, cw2 = om_s, cw3 = om_s, cw4 = om_s;
@@ -638,6 +658,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                             if (!(wg[s] > 0.0)) wg[s] = Ew[3] > 0.0 ? Ew[3] : om_s;
                     }
                 }
+                MP_PHASE(4)
                 Vd<kSPL> rot, f1;
                 const bool full = !light;                 // lambda, e^{h lambda} and the weights are renewed in this sweep
                 if (ultra) {
@@ -657,6 +678,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                     Ef[4 + s] = f1[s];
                     Ew[4 + s] = wg[s];
                 }
+                MP_PHASE(13)
                 // largest rotation parameter among this lane's step ends (the padding steps of a short tile repeat its
                 // last point once the first sweep has run; before that nothing is decided on them: `settled` is false)
                 const double rot_max = lane_max(rot.v);
@@ -685,6 +707,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                     n3[s] = fma(-lam[s], Ew[1 + s], Ef[1 + s]);
                     n4[s] = fma(-lam[s], Ew[s], Ef[s]);
                 }
+                MP_PHASE(14)
                 if (!light) {
                     Vd<kSPL> zw;
 #pragma unroll
@@ -694,6 +717,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                     p5 = pw_.p5;
                     cw = eam5_node_weights(wbase, pw_);
                 }
+                MP_PHASE(15)
                 const Vd<kSPL> inc = eam5_increment_nodes(cw, h, n0, n1, n2, n3, n4);
                 Vd<kSPL> aw, bw;
                 double A = 1.0, B = 0.0;
@@ -717,6 +741,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                     dsum += fabs(wc - wg[s]);
                     wg[s] = wc;
                 }
+                MP_PHASE(16)
                 const double mag = (double)kSPL * fabs(wc);
                 const bool all_settled = dsum <= 1.0e-6 * mag;                       // false for NaN
                 const bool all_small = dsum <= 1.0e-4 * mag;
@@ -759,9 +784,9 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 if (over_sweeps >= kChatterSweeps) { flagged |= over_now ? over_now : pending; break; }
             }
             sweeps_total += sweep;
-            MP_PHASE(4)
+            MP_PHASE(17)
             if (abort_tile) {                                                   // redo at stride 1 (as after a tile that keeps nothing)
-                if (a.tile_log && lane == 0 && tiles_total <= MP_TILE_LOG)
+                if (MP_TILE_LOG_ON && a.tile_log && lane == 0 && tiles_total <= MP_TILE_LOG)
                     a.tile_log[(size_t)walker * MP_TILE_LOG + tiles_total - 1] = kind | (sweep << 4) | (64 << 24);
                 cool = 3;
                 ++trouble;
@@ -786,6 +811,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 mf = flagged | __ballot(over) | ((flagged || early_stop) ? 0ull : pending);
                 if (early_stop) { mb &= ~pending_tight; mf &= ~pending_tight; }   // nothing is decided on lanes that are not kept
             }
+            MP_PHASE(11)
             // At a coarse stride nothing of this is a verdict: the lanes before the first one that failed, or whose sweeps
             // had not converged when they were stopped, hold converged steps (a step depends on earlier ones only) and
             // are kept like the steps before a kink; the rest is redone finer.
@@ -832,7 +858,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                         if (first < kMinKeepLanes) {                            // nothing worth keeping: redo at stride 1
                             opt_kind = max(2, kind - 1);
                             ++trouble;
-                            if (a.tile_log && lane == 0 && tiles_total <= MP_TILE_LOG)
+                            if (MP_TILE_LOG_ON && a.tile_log && lane == 0 && tiles_total <= MP_TILE_LOG)
                                 a.tile_log[(size_t)walker * MP_TILE_LOG + tiles_total - 1] = kind | (sweep << 4) | (why << 24);
                             // a kink in those lanes: single intervals; else the next finer stride is tried at once
                             kind = (kind > 2 && (B & ((1ull << kMinKeepLanes) - 1ull)) == 0ull) ? kind - 1 : 1;
@@ -875,7 +901,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
             }
             MP_PHASE(5)
             const int keep = min(keep_lanes * kSPL, nc);                       // steps kept
-            if (a.tile_log && lane == 0 && tiles_total <= MP_TILE_LOG)
+            if (MP_TILE_LOG_ON && a.tile_log && lane == 0 && tiles_total <= MP_TILE_LOG)
                 a.tile_log[(size_t)walker * MP_TILE_LOG + tiles_total - 1] = kind | (sweep << 4) | (keep_lanes << 16) | (why << 24);
             const int end_kept8 = pos8 + keep * d8;
 
@@ -905,6 +931,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 im.W[e] = wg[s]; im.F[e] = Ef[4 + s]; im.M[e] = M1[s]; im.D[e] = dM;
                 im.D2[e] = (CURVES && all_qs) ? ratio[s] : fma(-dM, w.inv_tau, dS1[s]);
                 im.R[e] = d1.rmu[s];
+                if (e == keep) { im.C[0] = S1[s]; im.C[1] = dS1[s]; im.C[2] = iu1[s]; }
             }
             if (lane == 0) {
                 const double dM = fma(-M_s, w.inv_tau, cS0);
@@ -1114,19 +1141,21 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 put(a.omega, 4, false);
             }
 
+            MP_PHASE(7)
             // ---------------- carry the end of the kept steps to the next tile
             t_s = t_s * time_factor(sh, tt, kind, keep);
             M_s = im.M[keep];
             om_s = im.W[keep];
             cf0 = im.F[keep];
             flags_s = branch_flags(w, im.R[keep], om_s);
+            cS0 = im.C[0]; cdS0 = im.C[1]; ciu0 = im.C[2];
             rec_valid = true;
             rec_kind = kind;
             rec_sh8 = sh8;
             rec_J = keep;
             pos8 = end_kept8;
             kind = next_kind;
-            MP_PHASE(7)
+            MP_PHASE(12)
         }
         if (deferred && status == MP_STATUS_OK) {   // the luminosity evaluations of this walker: one per 64 observations
             const Vd<2> Mv{{obM[0], obM[1]}}, Wv{{obW[0], obW[1]}};
@@ -1134,6 +1163,8 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
             Vd<2> Lt, Lp, Ld;
             luminosity(sh, w, dp, Wv, Lt, Lp, Ld);
             if (ob_g >= 0) {
+                const int jj = dsd.obs_off + lane;
+                ob_dx = sh.obs_dx[jj]; ob_idt = sh.obs_idt[jj]; ob_y = sh.obs_y[jj]; ob_ye = sh.obs_yerr[jj];
                 const double mod = fma((Lt[1] - Lt[0]) * ob_idt, ob_dx, Lt[0]) / 1.0e50;   // np.interp, then /1e50
                 const double res = (ob_y - mod) / ob_ye;
                 chi = res * res;

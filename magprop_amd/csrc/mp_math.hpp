@@ -44,6 +44,14 @@ MP_DEV double lane_bcast(double v, int src) {
     return __hiloint2double(hi, lo);
 }
 
+// A value that is the same in every lane, moved to scalar registers (the compiler cannot prove uniformity of fp64 results,
+// which only the vector ALU computes, and keeps them in vector registers otherwise)
+MP_DEV double uniform(double v) {
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+    const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
 // Inclusive scan of affine maps x -> a*x + b over the 64 lanes: afterwards lane l holds
 // m_l o m_{l-1} o ... o m_0.  Lanes without a DPP source combine with the identity (1, 0).
 // Within-row shifts (all rows enabled) let the hardware supply the zero dwords of the identity (bound_ctrl: a lane

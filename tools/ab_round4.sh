@@ -1,0 +1,14 @@
+#!/bin/bash
+# Same-box A/B of kernel builds over the legs round 4 works on (headline, sampler, 4 096 Classic, mode B, config 5):
+#   bash tools/ab_round4.sh ab/libA.so ab/libB.so ...        (GPU box; boxes differ by several per cent, builds must share one)
+REPS=${REPS:-2}
+for rep in $(seq $REPS); do
+  for lib in "$@"; do
+    MAGPROP_AMD_LIB=$PWD/$lib python bench.py --no-cpu-baseline --no-extra --steps 200 --mcmc-steps 200 2>/dev/null | \
+      python3 -c "import json,sys; d=json.loads(sys.stdin.read()); s=d['ensemble_sampler']; print('$lib', 'n1024 kernel_ms %.4f value %.3f M | sampler %.3f M w-steps/s (%.4f ms/step; half-step launches %.3f M)' % (d['roofline']['kernel_ms_avg'], d['value']/1e6, s['walker_steps_per_sec']/1e6, s['ms_per_step'], s.get('walker_steps_per_sec_one_launch_per_half_step',0)/1e6))"
+    for args in "--nwalk 4096 --grb Classic" "--curve" "--config 5"; do
+      MAGPROP_AMD_LIB=$PWD/$lib python bench.py --no-cpu-baseline --no-mcmc --no-extra --steps 100 $args 2>/dev/null | \
+        python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('$lib', '[$args]', 'kernel_ms %.4f value %.3f M' % (d['roofline']['kernel_ms_avg'], d['value']/1e6))"
+    done
+  done
+done

@@ -8,9 +8,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from magprop_amd import LogProb, _capi
 
-NAMES = ["walker setup (prior, constants, initial state, observations into registers)", "step times, fallback rate, history lookup", "Mdisc step + scan + disc quantities",
-         "predictor", "Newton sweeps", "failure detection + acceptance policy", "image to LDS", "observations / curves + carry",
-         "tile control", "luminosity at the observations + chi^2"]
+NAMES = ["walker setup (prior, constants, initial state, observations into registers)", "history lookup", "Mdisc step + scan + disc quantities",
+         "predictor", "sweep: entry (wild-guess check), loop control", "acceptance policy", "image to LDS", "observations / curves",
+         "tile control", "luminosity at the observations + chi^2", "step times + fallback rate", "failure detection", "carry to the next tile",
+         "sweep: omega_dot (+ Jacobian)", "sweep: flags, neighbour fetch, node values", "sweep: phi functions + weights",
+         "sweep: increment, scan, update", "sweep: convergence tests, early give-up"]
+NPH = len(NAMES)
 gs = np.load(os.path.join(ROOT, "tests", "golden", "golden_synth.npz"))
 lo, hi = gs["prior_lower"], gs["prior_upper"]
 rng = np.random.default_rng(1)
@@ -22,14 +25,15 @@ lp.handle.tile_log(True)
 for name, P in sets.items():
     out, st = lp.handle.lnprob_batch(P, want_status=True)
     tiles, sweeps = lp.handle.last_tiles(n), lp.handle.last_sweeps(n)
-    acc = np.zeros((n, 10))
+    acc = np.zeros((n, NPH))
     buf = np.zeros(96, dtype=np.int32)
     for i in range(n):
         lp.handle._L.mp_last_tile_log(lp.handle._h, i, _capi._iptr(buf), 96)
-        acc[i] = buf[:10]
+        acc[i] = buf[:NPH]
     ok = st == 0
     tot = acc[ok].sum(axis=1)
     print(f"{name}: {ok.sum()} walkers, {tiles[ok].mean():.1f} tiles, {sweeps[ok].mean():.1f} sweeps per walker; clock ticks per walker mean {tot.mean():.0f} max {tot.max():.0f}")
-    for k in range(10):
+    for k in range(NPH):
         print(f"   {NAMES[k]:80s} {100 * acc[ok, k].sum() / tot.sum():5.1f} %   per tile {acc[ok, k].sum() / tiles[ok].sum():8.1f} ticks")
-    print(f"   per sweep {acc[ok, 4].sum() / sweeps[ok].sum():.1f} ticks")
+    sw = acc[ok][:, [4, 13, 14, 15, 16, 17]].sum()
+    print(f"   all of the sweeps: {100 * sw / tot.sum():.1f} %, per sweep {sw / sweeps[ok].sum():.1f} ticks")
