@@ -329,7 +329,12 @@ mp_handle *mp_create(const mp_model_cfg *cfg, const double *tgrid, int n_grid, i
     // The constants of the stride policy (oracle/mp_oracle.c carries the same ones).  They are not
     // settings: the shipped library takes them from here only, mp_get_policy() reports them.
     s.coarse_max_sweeps = 5;
-    s.fine_max_sweeps = 8;
+    s.fine_max_sweeps = 12;                                        // (round 3: 8.  A tile over single intervals that is cut after 8 sweeps
+                                                                   // restarts with a fresh extrapolation inside the slow zone -- where the
+                                                                   // Jacobian changes from step to step and the converged region grows by
+                                                                   // about one lane per sweep -- and the restart can be far worse than going
+                                                                   // on: 1 walker in 1 000 prior-wide ones then needed 120 - 160 sweeps in one
+                                                                   // tile.  12: worst walker 83 sweeps, means unchanged; profiles/r04_tail.log)
     s.trouble_limit = 2;
     s.early_hold_t = MP_EARLY_HOLD_SECONDS;                       // oracle/mp_oracle.c MPO_EARLY_HOLD_SECONDS
     s.coarse_tol_factor = 0.1;

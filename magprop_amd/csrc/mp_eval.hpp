@@ -238,7 +238,7 @@ constexpr int kMinKeepLanes = 8;
 // Sweeps a tile at a coarse stride may take: of one that has not converged by then (a poor extrapolated guess across a fast
 // feature) the converged leading lanes are kept and the rest is redone at the next finer stride.
 constexpr int kCoarseMaxSweeps = 5;
-constexpr int kFineMaxSweeps = 8;     // the same for tiles over single intervals or sub-steps, if enough lanes have converged
+constexpr int kFineMaxSweeps = 12;    // the same for tiles over single intervals or sub-steps, if enough lanes have converged (mp_capi.cpp: fine_max_sweeps)
 
 // cubic Hermite on a step of length h (theta in [0, 1]): value, and its time derivative
 MP_DEV double hermite(double th, double h, double y0, double d0, double y1, double d1) {
@@ -365,7 +365,11 @@ MP_DEV void image_state(const DevShared &sh, const Walker &w, const TileImage<SP
 #define MP_PHASE_DECL
 #define MP_PHASE(i)
 #define MP_PHASE_DUMP
+#ifdef MP_SWEEP_TRACE
+#define MP_TILE_LOG_ON false
+#else
 #define MP_TILE_LOG_ON true
+#endif
 #endif
 
 // ---------------------------------------------------------------- the kernel
@@ -454,6 +458,9 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
     double obM[2] = {1.0e30, 1.0e30}, obW[2] = {1.0e3, 1.0e3};  // (Mdisc, omega) at the observation's bracketing grid points
     double chi = 0.0, chi_long = 0.0;
     int sweeps_total = 0, tiles_total = 0;
+#ifdef MP_SWEEP_TRACE
+    int tr_tile = -1;
+#endif
 
     if (status == MP_STATUS_OK) {
         if (CURVES && lane == 0) {
@@ -753,6 +760,15 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 // discontinuity of the accretion torque, so tiles that come near it keep evaluating omega_dot)
                 ultra = full && __all(all_tiny && !near_limit);
                 pending = __ballot(!all_ok);
+#ifdef MP_SWEEP_TRACE
+                // developer build (make sweep-trace): how the converged region of a slowly converging tile over single intervals grows,
+                // one word per sweep in the walker's tile-log row: first pending lane | pending lanes << 8 | lanes beyond the break-up limit << 16
+                if (a.tile_log && lane == 0 && kind <= 1 && sweep <= MP_TILE_LOG && (tr_tile < 0 || tr_tile == tiles_total)) {
+                    if (sweep > 12) tr_tile = tiles_total;
+                    if (tr_tile < 0 || tr_tile == tiles_total)
+                        a.tile_log[(size_t)walker * MP_TILE_LOG + sweep - 1] = (pending ? __ffsll(pending) - 1 : 64) | (__popcll(pending) << 8) | (__popcll(over_now) << 16) | (tiles_total << 24);
+                }
+#endif
                 // (lanes of a tile that is stopped before all of it has converged are kept only if their own last
                 // correction was a hundred times below the tolerance: slow sweeps contract by 0.3-0.5 per pass, so a
                 // correction just below the tolerance leaves an error of the same size)

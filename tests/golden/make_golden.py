@@ -348,6 +348,52 @@ def make_flagscan2(n_each=1500):
     print("flagscan2 flag rate", (st == 1).mean(), "n", len(P))
 
 
+HOLDOUT_SEED = 41020261   # drawn after the round-4 policy constants (include/magprop_amd.h, mp_capi.cpp) were frozen; never used for tuning
+
+
+def make_holdout(n_synth=900, n_lib=600):
+    """HOLD-OUT set: points no constant of the solver's stride policy was ever tuned on.  4 x n_synth prior-wide points,
+    one block per synthetic dataset (seeds as in make_synth), and 2 x n_lib library-variant points (grids "L" and "S") over
+    the library's prior box; at every point the reference at its default LSODA tolerance AND at rtol = atol = 1e-12, plus
+    the enumerated LSODA-noise points.  tests/test_gpu_holdout.py holds the product defaults to both bounds and to exact
+    status; tests/test_oracle.py does the same for the serial restatement."""
+    import multiprocessing as mp
+    import pandas as pd
+    rng = np.random.default_rng(HOLDOUT_SEED)
+    P = LOWER + (UPPER - LOWER) * rng.random((4 * n_synth, 6))
+    ds = np.repeat(np.arange(4), n_synth).astype(np.int32)
+    sets = [synth_dataset(nm, SEED0 + i)[1:] for i, nm in enumerate(TYPES)]
+    jobs = [(P[i], *sets[ds[i]]) for i in range(len(P))]
+    with mp.Pool(8) as pool:
+        res = pool.map(_scan_one, jobs, chunksize=20)
+        lnp = np.array([r[0] for r in res]); st = np.array([r[1] for r in res], dtype=np.int32)
+        tight = np.full(len(P), np.nan)
+        ok = np.nonzero(st == 0)[0]
+        tight[ok] = pool.map(_tight_synth_one, [jobs[i] for i in ok], chunksize=20)
+    out = {"synth_pars": P, "synth_ds": ds, "synth_ds_names": np.array(TYPES), "synth_lnprob": lnp, "synth_status": st,
+           "synth_lnprob_tight": tight, "synth_lsoda_noise_idx": noise_idx(lnp, tight), "seed": np.array([HOLDOUT_SEED])}
+    print("holdout synth: flags", int((st == 1).sum()), "noise points", len(out["synth_lsoda_noise_idx"]), "of", len(P), flush=True)
+    os.chdir(REF)
+    lims = pd.read_csv(os.path.join(REF, "magnetar/mcmc_limits.csv"), index_col="pars")
+    lo, hi = lims["lower"].values[:6], lims["upper"].values[:6]
+    gl = np.load(os.path.join(HERE, "golden_lib.npz"))
+    for kind in ("L", "S"):
+        x, y, yerr = gl["ds_" + kind]
+        Pl = lo + (hi - lo) * rng.random((n_lib, 6))
+        phys = Pl.copy(); phys[:, 2:] = 10.0 ** phys[:, 2:]
+        jobs = [(p, x, y, yerr, kind) for p in phys]
+        with mp.Pool(8) as pool:
+            res = pool.map(_libscan_one, jobs, chunksize=10)
+            lnl = np.array([r[0] for r in res]); stl = np.array([r[1] for r in res], dtype=np.int32)
+            tl = np.full(n_lib, np.nan)
+            okl = np.nonzero(stl == 0)[0]
+            tl[okl] = pool.map(_tight_lib_one, [jobs[i] for i in okl], chunksize=10)
+        out.update({f"lib{kind}_pars_sampler": Pl, f"lib{kind}_pars_physical": phys, f"lib{kind}_lnlike": lnl, f"lib{kind}_status": stl,
+                    f"lib{kind}_lnlike_tight": tl, f"lib{kind}_lsoda_noise_idx": noise_idx(lnl, tl)})
+        print(f"holdout lib {kind}: flags", int((stl == 1).sum()), "noise points", len(out[f"lib{kind}_lsoda_noise_idx"]), "of", n_lib, flush=True)
+    np.savez_compressed(os.path.join(HERE, "golden_holdout.npz"), **out)
+
+
 def make_corners():
     """All 64 corners of the synth prior box on the Humped dataset, plus the largest rotation parameter the
     reference's own trajectory reaches (so tests can tell 'rode the break-up limit but LSODA survived')."""
@@ -666,7 +712,7 @@ def make_swift():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--flag-scan", type=int, default=1500)
-    ap.add_argument("--only", choices=["all", "lib", "libkw", "corners", "libscan", "longlc", "flagscan2", "libscan2", "rhs", "tight", "swift"], default="all", help="regenerate only one file")
+    ap.add_argument("--only", choices=["all", "lib", "libkw", "corners", "libscan", "longlc", "flagscan2", "libscan2", "rhs", "tight", "swift", "holdout"], default="all", help="regenerate only one file")
     a = ap.parse_args()
     import scipy, pandas
     if a.only == "all":
@@ -689,6 +735,8 @@ def main():
     if a.only in ("all", "rhs"):
         make_rhs()
     noise_report = make_tight() if a.only in ("all", "tight") else None
+    if a.only == "holdout":          # (not part of "all": the hold-out set is generated once, after a policy freeze)
+        make_holdout()
     if a.only in ("all", "swift"):
         make_swift()
     manifest = {
@@ -697,7 +745,7 @@ def main():
         if hasattr(lib, "__version__") else "sgibson91/magprop mounted at /root/reference",
         "versions": {"python": sys.version.split()[0], "numpy": np.__version__, "scipy": scipy.__version__,
                      "pandas": pandas.__version__},
-        "seed0": SEED0, "decimation": DECIM, "flag_scan_n": a.flag_scan,
+        "seed0": SEED0, "holdout_seed": HOLDOUT_SEED, "decimation": DECIM, "flag_scan_n": a.flag_scan,
     }
     old = {}
     if os.path.exists(os.path.join(HERE, "MANIFEST.json")):

@@ -13,6 +13,16 @@ pytestmark = pytest.mark.gpu
 LOG_MASK = 0b111100
 N_SOAK = int(os.environ.get("MAGPROP_SOAK_N", "32768"))
 STRICT = 1.0e-9   # MP_SWEEP_TOL_STRICT: the kernels against the serial restatement of the scheme
+# Two sets of walkers: seed 20261003 is the one every constant of the stride policy was tuned on in round 3 (kept: a
+# regression guard); the second seed was drawn after the round-4 constants were frozen (MAGPROP_SOAK_SEED overrides it, so
+# the points can be changed without touching the file).
+TUNING_SEED = 20261003
+FRESH_SEED = int(os.environ.get("MAGPROP_SOAK_SEED", "77120264"))
+# Product defaults (adaptive stride, sweep tolerance 1e-7) against the fixed-step scheme (C oracle mode 0).  Round 4, both
+# seeds, 32 768 walkers: max 4.5e-8 / 4.8e-8, 99.9 % below 8e-9 (profiles/r04_soak_parity.json) -- asserted at 1e-7, a
+# margin of 2.  The maximum of a sample grows with its size (round 3, 262 144 walkers: 7.3e-8): larger runs
+# (MAGPROP_SOAK_N) are held to the documented bound of 2e-7.
+DEFAULTS_VS_FIXED_MAX, DEFAULTS_VS_FIXED_P999 = (1.0e-7 if N_SOAK <= 65536 else 2.0e-7), 2.0e-8
 
 
 def _walkers(rng, n, lo, hi):
@@ -38,9 +48,10 @@ def _walkers(rng, n, lo, hi):
     return P
 
 
-def test_every_kernel_variant_against_the_c_oracle(gsynth, tarr):
+@pytest.mark.parametrize("seed", [TUNING_SEED, FRESH_SEED], ids=["tuning-seed", "fresh-seed"])
+def test_every_kernel_variant_against_the_c_oracle(gsynth, tarr, seed):
     from magprop_amd import LogProb
-    rng = np.random.default_rng(20261003)
+    rng = np.random.default_rng(seed)
     lo, hi = gsynth["prior_lower"], gsynth["prior_upper"]
     P = _walkers(rng, N_SOAK, lo, hi)
     ids = rng.integers(0, 4, N_SOAK).astype(np.int32)
@@ -62,7 +73,7 @@ def test_every_kernel_variant_against_the_c_oracle(gsynth, tarr):
     for part, (v, s) in zip(where, res):
         ref[part], rst[part] = v, s
 
-    summary = {"n": N_SOAK, "oracle_status_counts": np.bincount(rst, minlength=4).tolist(), "variants": {}}
+    summary = {"n": N_SOAK, "seed": int(seed), "oracle_status_counts": np.bincount(rst, minlength=4).tolist(), "variants": {}}
     # strict: sweep tolerance 1e-9 and every grid interval a step, i.e. the scheme the serial C restatement integrates
     # (mode 0); product defaults: sweep tolerance 1e-7, steps over 1, 2, 4 or 8 grid intervals (include/magprop_amd.h)
     for batch, label, env in ((256, "4 steps per lane, small batches", {}),
@@ -95,33 +106,36 @@ def test_every_kernel_variant_against_the_c_oracle(gsynth, tarr):
         assert np.sum(rst != st) == 0, summary["variants"][label]      # ok / flag / prior verdicts identical to the oracle's
         # product defaults against the fixed-step restatement: the adaptive steps add up to ~5e-8 (same size as the
         # scheme's own deviation from the reference's tight-integrator values), 99.9 % of the walkers below 2e-8
-        assert rel.max() <= (1e-7 if loose else 1e-9), summary["variants"][label]
-        assert np.quantile(rel, 0.999) <= (2e-8 if loose else 1e-10), summary["variants"][label]
+        assert rel.max() <= (DEFAULTS_VS_FIXED_MAX if loose else 1e-9), summary["variants"][label]
+        assert np.quantile(rel, 0.999) <= (DEFAULTS_VS_FIXED_P999 if loose else 1e-10), summary["variants"][label]
     out_dir = os.path.join(os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(__file__))), "gpurun_out")
     if os.path.isdir(out_dir):
-        with open(os.path.join(out_dir, "soak_parity.json"), "w") as f:
+        with open(os.path.join(out_dir, f"soak_parity_seed{seed}.json"), "w") as f:
             json.dump(summary, f, indent=1)
     print(json.dumps(summary))
 
 
-def test_library_variant_against_the_c_oracle(glib, tarr):
+@pytest.mark.parametrize("grid,seed", [("L", 77), ("S", FRESH_SEED + 1)], ids=["L-grid", "S-grid-fresh-seed"])
+def test_library_variant_against_the_c_oracle(glib, grid, seed):
     """Same soak for the `magnetar` package variant (I = 0.8 M R^2, n = 1 in the ODE, Lprop == 0; 7-parameter
-    likelihood with f_beam) over its own prior box (magnetar/mcmc_limits.csv)."""
-    from magprop_amd import LogProb, mcmc_eqns
+    likelihood with f_beam) over its own prior box (magnetar/mcmc_limits.csv), on both grids of the reference
+    (magnetar/funcs.py:132-137; the "S" grid starts at 1 ms: the early hold of the stride policy is a physical time)."""
+    from magprop_amd import LogProb, engine, mcmc_eqns
     from _soak_worker import oracle_slice
+    tarr = engine.grid(grid)
     n = N_SOAK // 4
-    rng = np.random.default_rng(77)
+    rng = np.random.default_rng(seed)
     lo, hi = mcmc_eqns._bounds(7)
     P = lo + (hi - lo) * rng.random((n, 7))
     P[: n // 50, 6] = np.nextafter(hi[6], np.inf)                               # f_beam one ulp above its bound
-    ds = tuple(glib["ds_L"])
+    ds = tuple(glib["ds_" + grid])
     parts = np.array_split(np.arange(n), 16)
     ncpu = max(1, min(16, len(os.sched_getaffinity(0))))
     with mp.get_context("spawn").Pool(ncpu) as pool:
         res = pool.map(oracle_slice, [("lib", P[p], ds, tarr, lo, hi, mcmc_eqns.LIB_LOG_MASK) for p in parts], chunksize=1)
     ref = np.concatenate([r[0] for r in res])
     rst = np.concatenate([r[1] for r in res])
-    lp_ = LogProb(*ds, variant="lib", lower=lo, upper=hi, sweep_tol=STRICT, max_stride=1)
+    lp_ = LogProb(*ds, variant="lib", GRBtype=grid, lower=lo, upper=hi, sweep_tol=STRICT, max_stride=1)
     for batch in (256, 1024, 4096):
         out = np.empty(n)
         st = np.empty(n, dtype=np.int32)
@@ -133,7 +147,8 @@ def test_library_variant_against_the_c_oracle(glib, tarr):
         assert both.sum() > 0.9 * n and rel.max() <= 1e-9 and np.quantile(rel, 0.999) <= 1e-10, (batch, rel.max())
         assert np.all(out[~both] == -np.inf)
     # the product defaults (adaptive stride) on the same walkers: identical verdicts, values within the documented bound
-    lpd = LogProb(*ds, variant="lib", lower=lo, upper=hi)
+    lpd = LogProb(*ds, variant="lib", GRBtype=grid, lower=lo, upper=hi)
+    worst = {}
     for batch in (1024, 4096):
         out = np.empty(n)
         st = np.empty(n, dtype=np.int32)
@@ -141,4 +156,10 @@ def test_library_variant_against_the_c_oracle(glib, tarr):
             out[a:a + batch], st[a:a + batch] = lpd.handle.lnprob_batch(P[a:a + batch], want_status=True)
         assert np.array_equal(st, rst), (batch, np.nonzero(st != rst)[0][:5])
         rel = np.abs(out[both] - ref[both]) / np.maximum(np.abs(ref[both]), 1.0)
-        assert rel.max() <= 1e-7 and np.quantile(rel, 0.999) <= 2e-8, (batch, rel.max())
+        worst[batch] = {"max_rel_diff": float(rel.max()), "p999_rel_diff": float(np.quantile(rel, 0.999))}
+        assert rel.max() <= DEFAULTS_VS_FIXED_MAX and np.quantile(rel, 0.999) <= DEFAULTS_VS_FIXED_P999, (batch, rel.max())
+    out_dir = os.path.join(os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(__file__))), "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, f"soak_parity_lib_{grid}_seed{seed}.json"), "w") as f:
+            json.dump({"n": n, "grid": grid, "seed": int(seed), "status_counts": np.bincount(rst, minlength=4).tolist(),
+                       "product_defaults_vs_fixed_steps": worst}, f, indent=1)

@@ -46,7 +46,8 @@ def timed(X, reps=60):
 es = EnsembleSampler(1024, 6, *data, seed=7)
 burnt = es.run_mcmc(truth + 1e-4 * rng.standard_normal((1024, 6)), 500, store=False)
 es.close()
-sets = [("near 1024", truth + 1e-4 * rng.standard_normal((1024, 6))), ("wide 1024", lo + (hi - lo) * rng.random((1024, 6))),
+bench_wide = lo + (hi - lo) * np.random.default_rng(20261003 + 1).random((1024, 6))      # bench.py's kernel_ms.prior_wide set
+sets = [("near 1024", truth + 1e-4 * rng.standard_normal((1024, 6))), ("wide bench", bench_wide), ("wide 1024", lo + (hi - lo) * rng.random((1024, 6))),
         ("wide 1024 b", lo + (hi - lo) * rng.random((1024, 6))), ("burnt 1024", burnt), ("wide 8192", lo + (hi - lo) * rng.random((8192, 6)))]
 for name, X in sets:
     ms, tl, sw = timed(X)
