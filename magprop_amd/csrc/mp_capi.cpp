@@ -130,6 +130,14 @@ struct mp_handle {
     PinnedBuf h_io;
     double last_mean_sweeps = 0.0;
     std::vector<int32_t> last_sweeps, last_tiles;   // per walker, most recent host-buffer batch (diagnostic)
+    // Launch order of mixed-length batches (mp_kernels.hip order_kernel): a ring of index buffers, one per launch in flight.
+    // A slot is written by the launch that takes it and read by that launch's workgroups as they start; the launch that
+    // takes it kOrderRing launches later waits (stream-level, on the event recorded behind the earlier launch) for that
+    // launch to have finished -- launches fewer than kOrderRing apart share nothing.
+    static constexpr int kOrderRing = 8;
+    DevBuf<int32_t> order[kOrderRing];
+    hipEvent_t order_done[kOrderRing] = {};
+    unsigned order_next = 0;
     // Threading / stream contract (include/magprop_amd.h): every entry point that takes a handle or a sampler holds
     // `mu` for its duration.  Launches share nothing writable but their own outputs (round 4: no per-walker scratch rows),
     // so launches of one handle on different streams may overlap freely.
@@ -139,9 +147,28 @@ struct mp_handle {
 namespace {
 using Lock = std::lock_guard<std::recursive_mutex>;
 
-int launch_lnprob_ordered(mp_handle *h, const mp::LaunchArgs &a, hipStream_t st) {
+// Launch the log-posterior kernel over a batch.  A batch that refers to light curves of more than 64 points next to short
+// ones and needs more than one round of the device's wave slots (two per SIMD) is evaluated longest light curves first.
+int launch_lnprob_ordered(mp_handle *h, const mp::LaunchArgs &a_in, hipStream_t st) {
+    mp::LaunchArgs a = a_in;
+    int slot = -1;
+    const bool curves = a.ltot || a.lprop || a.ldip || a.mdisc || a.omega;
+    if (h->sh.has_long && h->sh.n_ds > 1 && a.ds_id && a.want_chi2 && !curves && a.n > 2 * h->sh.n_simd) {
+        slot = (int)(h->order_next++ % mp_handle::kOrderRing);
+        if (h->order[slot].cap < (size_t)a.n) {
+            // (growing frees the old buffer, which waits for the device: nothing in flight reads it any more)
+            const int rc = h->order[slot].ensure((size_t)a.n);
+            if (rc) return rc;
+        }
+        if (!h->order_done[slot]) HIP_TRY(hipEventCreateWithFlags(&h->order_done[slot], hipEventDisableTiming));
+        else HIP_TRY(hipStreamWaitEvent(st, h->order_done[slot], 0));
+        const int eo = mp::launch_order(h->sh, a.ds_id, a.n, h->order[slot].p, (void *)st);
+        if (eo) return fail(MP_EHIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)eo));
+        a.order = h->order[slot].p;
+    }
     const int e = mp::launch_lnprob(h->sh, a, (void *)st);
     if (e) return fail(MP_EHIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+    if (slot >= 0) HIP_TRY(hipEventRecord(h->order_done[slot], st));
     return MP_OK;
 }
 }  // namespace
@@ -451,6 +478,10 @@ int mp_destroy(mp_handle *h) {
     h->w_pars.release(); h->w_lnprob.release(); h->w_curves.release();
     h->w_dsid.release(); h->w_status.release(); h->w_sweeps.release(); h->w_tile_log.release();
     h->w_io.release(); h->h_io.release();
+    for (int i = 0; i < mp_handle::kOrderRing; ++i) {
+        h->order[i].release();
+        if (h->order_done[i]) (void)hipEventDestroy(h->order_done[i]);
+    }
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return MP_OK;

@@ -98,6 +98,8 @@ struct DevShared {
 struct LaunchArgs {
     const double *pars;     // [n][ndim], device
     const int32_t *ds_id;   // [n] or nullptr
+    const int32_t *order;   // [n] or nullptr: workgroup b evaluates walker order[b] (mixed-length batches: the walkers with the
+                            // longest light curves first, see order_kernel); nullptr: walker b
     int32_t n;
     int32_t ndim;
     int32_t physical;       // 1: pars are physical, skip prior + un-logging (model_lc)
@@ -163,6 +165,7 @@ struct RhsArgs {
 // implemented in mp_kernels.hip; returns hipError_t as int
 int launch_rhs(const DevShared &sh, const RhsArgs &r, void *stream);
 int launch_lnprob(const DevShared &sh, const LaunchArgs &a, void *stream);
+int launch_order(const DevShared &sh, const int32_t *ds_id, int n, int32_t *order, void *stream);   // fills order[n] (see order_kernel)
 int launch_stretch(const DevShared &sh, const StretchArgs &g, int n_blocks, void *stream);
 int launch_stretch_apply(const StretchArgs &g, void *stream);
 int launch_stretch_step(const DevShared &sh, const StretchArgs &g, int n_blocks, void *stream);   // blocks [g.slot_lo, + n_blocks) of 3 * n_half * n_ensembles

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPL >= 4 ? 1
     ktab_init();
     wtab_init(sh.wtab);
     time_table_init(sh, tt);
-    const int walker = blockIdx.x;
+    const int walker = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
     double par[MP_MAX_NDIM];
     const double *pw = a.pars + (size_t)walker * a.ndim;
 #pragma unroll
@@ -64,6 +64,40 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPL >= 4 ? 1
         if (a.sweeps) a.sweeps[walker] = sweeps;
         if (a.tiles) a.tiles[walker] = tiles;
     }
+}
+
+// ---------------------------------------------------------------- launch order of a mixed-length batch
+// The hardware starts workgroups in index order, a new one whenever a wave slot frees up.  In a batch whose walkers refer to
+// light curves of very different lengths (BASELINE config 5: 8 ... 1 944 points; a walker on the longest costs twice a walker
+// on a 50-point set) and that needs more than one round of the device's wave slots, a long walker that starts in the last
+// round decides the launch time.  This kernel (one workgroup) sorts the walker indices by the length class of their light
+// curve, longest first (counting sort; the order inside a class is immaterial: every walker writes its own outputs only), and
+// lnprob_kernel evaluates walker order[blockIdx.x].  4 096-walker launch of config 5: 0.391 -> 0.313 ms on one box.
+constexpr int kOrderClasses = 6;
+MP_DEV int order_class(const DevShared &sh, const int32_t *ds_id, int i) {
+    const int d = ds_id[i];
+    const int n_obs = (sh.ds != nullptr && d >= 0 && d < sh.n_ds) ? sh.ds[d].n_obs : 0;
+    return n_obs > 1024 ? 0 : (n_obs > 512 ? 1 : (n_obs > 256 ? 2 : (n_obs > 128 ? 3 : (n_obs > 64 ? 4 : 5))));
+}
+__global__ __launch_bounds__(1024) void order_kernel(const DevShared sh, const int32_t *ds_id, int n, int32_t *order) {
+    __shared__ int cnt[kOrderClasses], fill[kOrderClasses];
+    const int t = threadIdx.x;
+    if (t < kOrderClasses) cnt[t] = 0;
+    __syncthreads();
+    for (int i = t; i < n; i += 1024) atomicAdd(&cnt[order_class(sh, ds_id, i)], 1);
+    __syncthreads();
+    if (t == 0) {
+        int acc = 0;
+        for (int c = 0; c < kOrderClasses; ++c) { fill[c] = acc; acc += cnt[c]; }
+    }
+    __syncthreads();
+    for (int i = t; i < n; i += 1024) order[atomicAdd(&fill[order_class(sh, ds_id, i)], 1)] = i;
+}
+
+int launch_order(const DevShared &sh, const int32_t *ds_id, int n, int32_t *order, void *stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, sh, ds_id, n, order);
+    return (int)hipGetLastError();
 }
 
 // ---------------------------------------------------------------- fused stretch-move half-step kernel

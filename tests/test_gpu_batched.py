@@ -330,6 +330,60 @@ def test_one_handle_from_several_threads_and_streams(gsynth, tarr):
     assert two < 0.85 * one, (one, two)
 
 
+def test_longest_light_curves_first_launch_order(gsynth, tarr):
+    """A batch that mixes long and short light curves and needs more than one round of the device's wave slots is evaluated
+    longest light curves first (mp_kernels.hip order_kernel; index buffers from a ring of 8 per handle, reuse ordered by
+    an event).  The order must not show in the results: every walker equals its value from a small batch (no ordering),
+    bit for bit; 20 launches alternating two streams (more than the ring holds) with different id patterns all come out
+    right; a bad id in an ordered batch is still a bad id."""
+    import torch
+    import magprop_amd as mpa
+    from magprop_amd import LogProb
+    rng = np.random.default_rng(404)
+    base = mpa.model_lum(CANON["Humped"])
+    lp_ = LogProb(gsynth["Humped_x"], gsynth["Humped_y"], gsynth["Humped_yerr"])
+    for m in (1500, 300, 8, 700, 100):
+        lp_.add_dataset(*_long_set(rng, tarr, base[1], m))
+    n = 2 * lp_.handle.n_simd + 1000                                      # more than two waves per SIMD
+    P = np.array(TRUTHS["Humped"]) + 0.01 * rng.standard_normal((n, 6))
+    patterns = [rng.integers(0, 6, n).astype(np.int32) for _ in range(5)]
+    patterns.append(np.zeros(n, np.int32))                                # all short: one class
+    want = []
+    half = n // 2                                                         # two chunks: the same kernel variant (2 steps per lane),
+    assert lp_.handle.n_simd < half <= 2 * lp_.handle.n_simd              # one round of wave slots each: launched in index order
+    for ids in patterns:
+        want.append(np.concatenate([lp_(P[a:a + half], ds_id=ids[a:a + half]) for a in (0, half)]))
+    for ids, w in zip(patterns, want):
+        got = lp_(P, ds_id=ids)
+        assert np.array_equal(got, w)
+        assert np.array_equal(lp_(P[::-1].copy(), ds_id=ids[::-1].copy())[::-1], got)
+    dev = torch.device("cuda", lp_.handle.device)
+    s1, s2 = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    tP = torch.from_numpy(P).to(dev)
+    tids = [torch.from_numpy(i).to(dev) for i in patterns]
+    outs = [torch.empty(n, dtype=torch.float64, device=dev) for _ in range(20)]
+    first = [lp_(P, ds_id=ids) for ids in patterns]
+    torch.cuda.synchronize(dev)
+    for r in range(20):
+        with torch.cuda.stream(s1 if r % 2 == 0 else s2):
+            lp_.lnprob_device(tP, out=outs[r], ds_id=tids[r % len(tids)])
+    torch.cuda.synchronize(dev)
+    for r in range(20):
+        assert np.array_equal(outs[r].cpu().numpy(), first[r % len(tids)])
+    bad = patterns[0].copy()
+    bad[7], bad[n - 3] = 40, -1                                           # out of range / never set
+    st = torch.empty(n, dtype=torch.int32, device=dev)
+    o = torch.empty(n, dtype=torch.float64, device=dev)
+    lp_.handle.lnprob_batch_dev(tP.data_ptr(), n, 6, o.data_ptr(), d_ds_id=torch.from_numpy(bad).to(dev).data_ptr(),
+                                d_status=st.data_ptr(), stream=torch.cuda.current_stream(dev).cuda_stream)
+    torch.cuda.synchronize(dev)
+    st, o = st.cpu().numpy(), o.cpu().numpy()
+    assert st[7] == 4 and st[n - 3] == 4 and o[7] == -np.inf and o[n - 3] == -np.inf
+    keep = np.ones(n, bool)
+    keep[[7, n - 3]] = False
+    assert np.array_equal(o[keep], first[0][keep])
+
+
 # ---------------------------------------------------------------- datasets: bad ids, incremental registration
 def test_bad_dataset_id_is_never_a_perfect_fit(gsynth):
     """Device-pointer entry (the ids live in HBM, the host cannot validate them): a walker whose ds_id is out of range or
