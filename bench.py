@@ -354,22 +354,26 @@ def run_passes(c, config, scaling, steps, warmup, curve=False, nwalk=None, grb=N
         step_idx[0] = i
         return sharded.start(props[i], recv=results[i])        # shard -> kernel -> all-gather (RCCL) of lnprob enqueued
 
+    consumer = torch.cuda.Stream(dev) if a.overlap else None   # the stream that would read the gathered vectors
+
     def loop(first, last):
         # The passes are independent batches (as the ensembles of BASELINE config 5 are): with --overlap 1 (default)
-        # the all-gather of pass i runs on RCCL's stream while the kernel of pass i+1 runs on the compute stream.
+        # the all-gather of pass i runs on RCCL's stream while the kernel of pass i+1 runs on the compute stream, and
+        # the stream that waits for the gathered vector is the consumer's, not the compute stream (a cross-queue wait
+        # costs the waiting queue ~10 us even when the collective is long finished: profiles/r04_rccl_overlap.md).
         # --overlap 0 waits for every gather before the next kernel (what ONE ensemble's dependent half-steps see).
         full, pending = None, None
         for i in range(first, last):
             t = start(i)
             if pending is not None:
-                full = sharded.finish(pending)                 # stream-level wait for the collective, no host sync
+                full = sharded.finish(pending, stream=consumer)   # stream-level wait for the collective, no host sync
                 pending = None
             if a.overlap:
                 pending = t
             else:
                 full = sharded.finish(t)
         if pending is not None:
-            full = sharded.finish(pending)
+            full = sharded.finish(pending, stream=consumer)
         return full
 
     if n_local > 0 and spin_up > 0:                             # bring the clocks up (untimed, before the warmup steps)

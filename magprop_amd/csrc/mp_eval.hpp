@@ -365,7 +365,7 @@ MP_DEV void image_state(const DevShared &sh, const Walker &w, const TileImage<SP
 #define MP_PHASE_DECL
 #define MP_PHASE(i)
 #define MP_PHASE_DUMP
-#ifdef MP_SWEEP_TRACE
+#if defined(MP_SWEEP_TRACE) || defined(MP_CORR_TRACE)
 #define MP_TILE_LOG_ON false
 #else
 #define MP_TILE_LOG_ON true
@@ -460,6 +460,9 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
     int sweeps_total = 0, tiles_total = 0;
 #ifdef MP_SWEEP_TRACE
     int tr_tile = -1;
+#endif
+#ifdef MP_CORR_TRACE
+    int tr_word = 0;
 #endif
 
     if (status == MP_STATUS_OK) {
@@ -668,6 +671,9 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 MP_PHASE(4)
                 Vd<kSPL> rot, f1;
                 const bool full = !light;                 // lambda, e^{h lambda} and the weights are renewed in this sweep
+#ifdef MP_CORR_TRACE
+                const bool f1_lin = ultra;
+#endif
                 if (ultra) {
 #pragma unroll
                     for (int s = 0; s < kSPL; ++s) {
@@ -767,6 +773,18 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                     if (sweep > 12) tr_tile = tiles_total;
                     if (tr_tile < 0 || tr_tile == tiles_total)
                         a.tile_log[(size_t)walker * MP_TILE_LOG + sweep - 1] = (pending ? __ffsll(pending) - 1 : 64) | (__popcll(pending) << 8) | (__popcll(over_now) << 16) | (tiles_total << 24);
+                }
+#endif
+#ifdef MP_CORR_TRACE
+                // developer build (make corr-trace, tools/corr_trace.py): one word per sweep of every tile in the walker's tile-log row:
+                // tile | kind << 8 | (0 full, 1 light, 2 linearised) << 11 | pending lanes << 13 | -10 log10(largest relative correction) << 20
+                {
+                    double rel = dsum / mag;
+                    if (!(rel >= 1.0e-25)) rel = rel == rel ? 1.0e-25 : 1.0;
+                    for (int d = 32; d >= 1; d >>= 1) rel = fmax(rel, __shfl_xor(rel, d, 64));
+                    const int q = min(255, max(0, (int)(-10.0 * log10(rel) + 0.5)));
+                    if (a.tile_log && lane == 0 && tr_word < MP_TILE_LOG)
+                        a.tile_log[(size_t)walker * MP_TILE_LOG + tr_word++] = (tiles_total & 0xFF) | (kind << 8) | ((full ? 0 : (f1_lin ? 2 : 1)) << 11) | (__popcll(pending) << 13) | (q << 20);
                 }
 #endif
                 // (lanes of a tile that is stopped before all of it has converged are kept only if their own last

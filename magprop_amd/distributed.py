@@ -80,10 +80,19 @@ class ShardedLnprob:
         return work, buf, n
 
     @staticmethod
-    def finish(ticket):
+    def finish(ticket, stream=None):
+        """The full lnprob vector of a started batch.  The stream that will consume it (`stream`, default: the current
+        one) waits for the collective; the host does not.  Independent batches should name a consumer stream other than
+        the one their kernels run on: a cross-queue wait costs the waiting queue ~10 us on MI355X whether or not the
+        collective has already finished (measured: profiles/r04_rccl_overlap.md), which would delay the next batch's
+        kernel for nothing."""
         work, buf, n = ticket
         if work is not None:
-            work.wait()               # the current stream waits for the collective; the host does not
+            if stream is None:
+                work.wait()
+            else:
+                with torch.cuda.stream(stream):
+                    work.wait()
         return buf[:n]
 
     def __call__(self, pars):

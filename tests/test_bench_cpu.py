@@ -49,3 +49,14 @@ def test_launcher_path_still_works():
 def test_single_process_needs_no_group():
     r = _run(["--dry-run"])
     assert r.returncode == 0 and json.loads(r.stdout.strip())["ranks_seen"] == 1
+
+
+def test_self_launch_eight_ranks():
+    """The driver's largest form (N = 8; BASELINE configs[3]) through bench.py's own launcher: eight rank processes
+    rendezvous over 127.0.0.1, rank 0 prints the one line.  (On the GPU boxes of this pool at most six processes may share the
+    card, so eight real ranks are only ever run by the driver's 8-GPU node; profiles/r04_bench_gloo6.json is the largest
+    rehearsal with kernels.)"""
+    r = _run(["--gpus", "8", "--dry-run"], timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and json.loads(lines[0]) == {"dry_run": True, "n_gpus": 8, "ranks_seen": 8}
