@@ -226,6 +226,15 @@ MP_DEV int walker_setup(const DevShared &sh, const LaunchArgs &a, double (&par)[
     return status;
 }
 
+// Tile kinds from this one on start their sweeps from the log-space extrapolation (5: none).  Tiles of 256 steps (4 steps
+// per lane) over 2, 4, 8 grid intervals reach 0.6 - 1.2 decades ahead; at 128 steps (2 steps per lane) the quartic in the
+// index is as good and cheaper (same-box A/B, profiles/r04_ab_predictor.log: 4 096 near-truth walkers +3 % slower with it).
+#ifndef MP_LOGPRED_MIN_KIND
+#define MP_LOGPRED_MIN_KIND 2
+#endif
+#ifndef MP_LOGPRED_MIN_KIND_SPL2
+#define MP_LOGPRED_MIN_KIND_SPL2 5
+#endif
 constexpr int kMaxSweepsMargin = 16;  // sweeps allowed beyond the tile length (after which every step is exact)
 // A tile whose iterates keep crossing the break-up limit (rotation parameter 0.27: the accretion torque switches off,
 // code/synthetic_datasets/funcs.py:131-132) is chattering on that discontinuity and ends as a 'flag' anyway; after this
@@ -617,6 +626,32 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 // Newton backward-difference extrapolation (quartic once five values exist).  History values that were
                 // interpolated inside the record's steps (a finer successor) carry the interpolant's ~1e-11 ripple, which
                 // the higher differences would amplify by the cube / fourth power of the tile length: quadratic then.
+                if (!startup && kind >= (kSPL >= 4 ? MP_LOGPRED_MIN_KIND : MP_LOGPRED_MIN_KIND_SPL2)) {
+                    // Coarse tiles (round 4): a tile over 8 grid intervals spans 1.2 decades of time, over which omega follows
+                    // power laws, not polynomials: the quartic in the index was off by 15 % (median) to a factor of 6 (one tile in
+                    // ten) at the tile's end, and its 4th difference amplifies the 1e-10 noise of the history by 2e8.  Instead
+                    // log(omega) is extrapolated with the DERIVATIVE's history: d log(omega)/dk = omega_dot t ln(Q) / omega is known
+                    // at the tile's start and the two points before it (exact right-hand sides, no differencing of values);
+                    // its quadratic Newton polynomial in the index, integrated from 0 to k, gives
+                    //   log(omega_k / omega_s) = a0 k + d1 k^2/2 + d2 (k^3/6 + k^2/4),   d1, d2 = backward differences of a.
+                    // Median error at the end of such a tile 5 %, one tile in ten 60 % (tools/predictor_study.py); the Newton
+                    // sweeps double the number of correct digits per pass, so this saves most coarse tiles a sweep.
+                    const Vd<3> den{{om_s, cw1, cw2}};
+                    const Vd<3> rd = rcp_fast(den);
+                    const double tl = t_s * K.lnQ;
+                    const double a0 = tl * cf0 * rd[0], a1 = (tl * K.inv_Q) * cf1 * rd[1], a2 = (tl * K.inv_Q * K.inv_Q) * cf2 * rd[2];
+                    const double d1 = a0 - a1, d2 = d1 - (a1 - a2);
+                    Vd<kSPL> ex;
+#pragma unroll
+                    for (int s = 0; s < kSPL; ++s) {
+                        const double k = (double)(lane * kSPL + s + 1);
+                        const double e = k * fma(k, fma(fma(k, 1.0 / 6.0, 0.25), d2, 0.5 * d1), a0);
+                        ex[s] = fmin(fmax(e, -4.0), 4.0);     // (a guess only: never further than a factor of 55 from the start value)
+                    }
+                    const Vd<kSPL> ee = exp_fast(ex);
+#pragma unroll
+                    for (int s = 0; s < kSPL; ++s) wg[s] = om_s * ee[s];
+                } else {
                 const double g1 = om_s - cw1, g2 = g1 - (cw1 - cw2);
                 const double d2b = (cw1 - cw2) - (cw2 - cw3);
                 const double g3 = (startup || interp_hist) ? 0.0 : g2 - d2b;
@@ -627,6 +662,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                     const double c2 = 0.5 * k * (k + 1.0);
                     const double c3 = c2 * (k + 2.0) * (1.0 / 3.0);
                     wg[s] = fma(k, g1, fma(c2, g2, fma(c3, g3, fma(c3 * (k + 3.0) * 0.25, g4, om_s))));
+                }
                 }
             }
             MP_PHASE(3)

@@ -395,7 +395,7 @@ def test_bad_dataset_id_is_never_a_perfect_fit(gsynth):
     lp = LogProb(x, y, yerr)
     lp.handle.set_dataset(5, gsynth["Classic_x"], gsynth["Classic_y"], gsynth["Classic_yerr"])   # slots 1-4 stay unset
     rng = np.random.default_rng(5)
-    for n in (96, 1200):                                        # producer/consumer pair; 2-steps-per-lane kernel
+    for n in (96, 1200):                                        # 4-steps-per-lane kernel (one wave per SIMD); 2-steps-per-lane kernel
         P = np.array(TRUTHS["Humped"]) + 1.0e-3 * rng.standard_normal((n, 6))
         ids = np.where(np.arange(n) % 2 == 0, 0, 5).astype(np.int32)
         bad = {3: -1, 10: 40, 11: 64, 20: 1000000, 21: 2, 50: 4, n - 1: -2147483648}

@@ -174,7 +174,7 @@ def test_sampler_on_a_long_light_curve(gsynth):
     y = y0 + rng.normal(0, yerr)
     import os
     for nwalk, env in ((32, {}), (640, {}), (2600, {})):
-        # producer/consumer pair (half-steps of 16 and 320 proposals) and one wavefront per walker (1 300)
+        # small half-steps (16 and 320 proposals: 4 steps per lane) and a large one (1 300: 2 steps per lane); one wavefront per walker throughout
         pos = truth + 1.0e-4 * rng.standard_normal((nwalk, 6))
         os.environ.update(env)
         try:
