@@ -232,6 +232,9 @@ MP_DEV int walker_setup(const DevShared &sh, const LaunchArgs &a, double (&par)[
 #ifndef MP_LOGPRED_MIN_KIND
 #define MP_LOGPRED_MIN_KIND 2
 #endif
+#ifndef MP_ABORT_SKIP_RATIO
+#define MP_ABORT_SKIP_RATIO 32.0   // excess of the indicator over its bound beyond which a given-up coarse tile skips a stride
+#endif
 #ifndef MP_LOGPRED_MIN_KIND_SPL2
 #define MP_LOGPRED_MIN_KIND_SPL2 5
 #endif
@@ -856,12 +859,33 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
             sweeps_total += sweep;
             MP_PHASE(17)
             if (abort_tile) {                                                   // redo at stride 1 (as after a tile that keeps nothing)
+                // by how much the first lanes exceeded the bound they were held to (what decided the abort): wave maximum of
+                // indicator / (margin x bound) over the first kMinKeepLanes lanes
+                double hot_ratio = 0.0;
+                {
+                    const double margin = sweep == 2 ? 4.0 : 1.0;
+#pragma unroll
+                    for (int s = 0; s < kSPL; ++s) {
+                        const double d4 = 120.0 * fabs(p5[s]) * h[s] * fabs((n0[s] + n4[s]) - 4.0 * (n1[s] + n3[s]) + 6.0 * n2[s]);
+                        const double r = d4 / (margin * tile_tol * wg[s]);
+                        hot_ratio = (lane < kMinKeepLanes && r > hot_ratio) ? r : hot_ratio;     // (a NaN ratio is ignored)
+                    }
+#pragma unroll
+                    for (int d = 4; d >= 1; d >>= 1) hot_ratio = fmax(hot_ratio, __shfl_xor(hot_ratio, d, 64));
+                    hot_ratio = lane_bcast(hot_ratio, 0);
+                }
                 if (MP_TILE_LOG_ON && a.tile_log && lane == 0 && tiles_total <= MP_TILE_LOG)
-                    a.tile_log[(size_t)walker * MP_TILE_LOG + tiles_total - 1] = kind | (sweep << 4) | (64 << 24);
+                    a.tile_log[(size_t)walker * MP_TILE_LOG + tiles_total - 1] =
+                        kind | (sweep << 4) | (min(255, max(0, (int)(8.0 * log2(fmax(hot_ratio, 1.0))))) << 16) | (64 << 24);
                 cool = 3;
                 ++trouble;
-                opt_kind = max(2, kind - 1);
-                kind = kind > 2 ? kind - 1 : 1;     // the next finer stride is tried at once
+                // the next finer stride is tried at once -- or the one after it, when the first lanes were beyond the bound by
+                // more than a halving of the step buys (order 5: a factor of 32).  Measured on 1 700 given-up tiles of 4 096
+                // prior-wide walkers (tools/abort_study.py, profiles/r04_abort_study.log): with an excess >= 32 the next finer
+                // stride kept nothing either in 50 % (from 8 intervals) / 95 % (from 4) of the cases and a dozen lanes otherwise.
+                const int drop = hot_ratio >= MP_ABORT_SKIP_RATIO ? 2 : 1;
+                opt_kind = max(2, kind - drop);
+                kind = kind - drop >= 2 ? kind - drop : 1;
                 continue;
             }
 
