@@ -235,6 +235,11 @@ MP_DEV int walker_setup(const DevShared &sh, const LaunchArgs &a, double (&par)[
 #ifndef MP_ABORT_SKIP_RATIO
 #define MP_ABORT_SKIP_RATIO 32.0   // excess of the indicator over its bound beyond which a given-up coarse tile skips a stride
 #endif
+// A coarse tile that is cut at a fast feature of the solution (no kink) is followed by the stride its excess over the bound
+// asks for, judged over this many lanes from the cut on (0: always single intervals, as until round 3)
+#ifndef MP_CUT_BY_RATIO
+#define MP_CUT_BY_RATIO 24
+#endif
 #ifndef MP_LOGPRED_MIN_KIND_SPL2
 #define MP_LOGPRED_MIN_KIND_SPL2 5
 #endif
@@ -923,6 +928,9 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
             int keep_lanes = 64, next_kind = kind, why = 0;   // why: diagnostics (tile log)
             {
                 bool brk = false, ind1 = false, ind64 = false, ind2048 = false, ind65536 = false, indp8 = false;
+#if MP_CUT_BY_RATIO > 0
+                bool ind16x = false, ind512x = false;
+#endif
                 const double prom8 = 64.0 / sh.k4_tol_factor;   // a tile over 8 intervals is held to k4_tol_factor x the bound: its
                                                                 // promotion asks the same of the scaled indicator
 #pragma unroll
@@ -938,6 +946,10 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                     ind2048 = ind2048 || 2048.0 * d4 > lim;
                     ind65536 = ind65536 || 65536.0 * d4 > lim;
                     indp8 = indp8 || prom8 * d4 > lim;
+#if MP_CUT_BY_RATIO > 0
+                    ind16x = ind16x || d4 > 16.0 * lim;
+                    ind512x = ind512x || d4 > 512.0 * lim;
+#endif
                 }
                 const unsigned long long B = __ballot(brk), I1 = __ballot(ind1), I64 = __ballot(ind64), I2048 = __ballot(ind2048),
                                          I65536 = __ballot(ind65536), Ip8 = __ballot(indp8);
@@ -962,6 +974,19 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                         // a kink or a fast feature gets single intervals; slow sweeps alone, the next finer stride, which is
                         // then held for a few tiles
                         next_kind = (((B | I1) >> first) & 1ull) ? 1 : kind - 1;
+#if MP_CUT_BY_RATIO > 0
+                        // round 4: a fast feature (no kink) gets the stride its excess over the bound asks for (order 5: a halving of
+                        // the step buys 32 x; margin 2 as in the promotions), judged over the MP_CUT_BY_RATIO lanes from the cut on:
+                        // near the truths the propeller switch-on exceeds the stride-8 bound by < 16 x and a stride-4 tile takes it
+                        // where single intervals needed a tile of their own (9 -> 8 tiles, 28 -> 25 sweeps per walker; burnt-in
+                        // ensembles 10.2 -> 9.1 tiles; profiles/r04_ab_cut_by_ratio.log).  The tile that follows is cut where IT
+                        // does not hold, like any other.
+                        if (((B >> first) & 1ull) == 0ull && ((I1 >> first) & 1ull) != 0ull) {
+                            const unsigned long long win = (first + MP_CUT_BY_RATIO < 64 ? (1ull << (first + MP_CUT_BY_RATIO)) - 1ull : ~0ull) & ~((1ull << first) - 1ull);
+                            const unsigned long long X16 = __ballot(ind16x), X512 = __ballot(ind512x);
+                            if ((B & win) == 0ull) next_kind = (X16 & win) == 0ull ? kind - 1 : ((X512 & win) == 0ull ? max(kind - 2, 1) : 1);
+                        }
+#endif
                         if (next_kind >= 2) { hold_kind = next_kind; hold = 3; }
                     } else if (kind < max_kind && nc == kTile) {
                         if (hold > 0 && kind == hold_kind) --hold;
