@@ -987,6 +987,8 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                             if ((B & win) == 0ull) next_kind = (X16 & win) == 0ull ? kind - 1 : ((X512 & win) == 0ull ? max(kind - 2, 1) : 1);
                         }
 #endif
+                        // (a coarse successor is held for three tiles either way: releasing the one a feature's excess asked for at
+                        // once, or promoting a calm stride-2 tile straight to 8, changed nothing measurable: profiles/r04_ab_cut_by_ratio.log)
                         if (next_kind >= 2) { hold_kind = next_kind; hold = 3; }
                     } else if (kind < max_kind && nc == kTile) {
                         if (hold > 0 && kind == hold_kind) --hold;

@@ -413,6 +413,7 @@ typedef struct {
 #define MPO_PRE_SUB 8     /* sub-steps per grid interval there */
 #define MPO_EARLY_HOLD_SECONDS 4.0   /* coarse tiles starting before this time are held to a tenth of stride_tol */
 #define MPO_MIN_KEEP 8    /* a coarse tile is kept if at least this many lanes precede the first offending one */
+#define MPO_CUT_WINDOW 24 /* lanes from a cut on over which the excess of the indicator decides the next stride (mp_eval.hpp MP_CUT_BY_RATIO) */
 
 /* omega, f, Mdisc, dMdisc/dt at time t <= the last accepted node (Hermite on the accepted steps; exact at nodes) */
 static int node_lookup(const mpo_node *nd, int nn, double t, double *wv, double *fv) {
@@ -588,7 +589,23 @@ int mpo_trajectory_mode(const mpo_cfg *c, const double *pars, int ndim, const do
                     continue;
                 }
                 keep = first * spl;
-                next_s = 1;                                                  /* the offending region gets single intervals */
+                next_s = 1;                                                  /* the offending region gets single intervals ... */
+                /* ... unless it is a fast feature of the solution, not a kink (round 4, mp_eval.hpp MP_CUT_BY_RATIO): then the
+                   stride its excess over the bound asks for -- order 5: a halving of the step buys 32 x, margin 2 as in the
+                   promotions below -- judged over the MPO_CUT_WINDOW lanes from the cut on; a kink among them: single intervals */
+                {
+                    int kink = 0;
+                    double excess = 0.0;
+                    for (int e = first * spl; e < (first + MPO_CUT_WINDOW) * spl && e < nsolved; ++e) {
+                        kink |= brk[e];
+                        if (ind[e] / tile_tol > excess) excess = ind[e] / tile_tol;
+                    }
+                    int cut_by_ind = 0;
+                    for (int e = first * spl; e < (first + 1) * spl && e < nsolved; ++e) cut_by_ind |= (!brk[e] && ind[e] > tile_tol);
+                    for (int e = first * spl; e < (first + 1) * spl && e < nsolved; ++e) if (brk[e]) cut_by_ind = 0;
+                    if (cut_by_ind && !kink && (first + 1) * spl <= nsolved)
+                        next_s = excess <= 16.0 ? s / 2 : (excess <= 512.0 ? (s / 4 > 1 ? s / 4 : 1) : 1);
+                }
             }
         }
         /* ---- stride of the next tile (mode 1): coarsen when the kept steps were calm (5th-order scaling of the indicator) */
