@@ -240,6 +240,21 @@ MP_DEV int walker_setup(const DevShared &sh, const LaunchArgs &a, double (&par)[
 #ifndef MP_CUT_BY_RATIO
 #define MP_CUT_BY_RATIO 24
 #endif
+#ifndef MP_LOGPRED_AFTER_SUBSTEPS
+#define MP_LOGPRED_AFTER_SUBSTEPS 0   // 1: the coarse tile right behind the sub-stepped start uses the log-space guess in every kernel
+#endif
+#ifndef MP_CUT_NO_HOLD_SPL4
+#define MP_CUT_NO_HOLD_SPL4 0
+#endif
+#ifndef MP_CUT_NO_HOLD_SPL2
+#define MP_CUT_NO_HOLD_SPL2 1
+#endif
+#ifndef MP_DOUBLE_PROMOTION_SPL4
+#define MP_DOUBLE_PROMOTION_SPL4 0
+#endif
+#ifndef MP_DOUBLE_PROMOTION_SPL2
+#define MP_DOUBLE_PROMOTION_SPL2 0
+#endif
 #ifndef MP_LOGPRED_MIN_KIND_SPL2
 #define MP_LOGPRED_MIN_KIND_SPL2 5
 #endif
@@ -634,7 +649,8 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 // Newton backward-difference extrapolation (quartic once five values exist).  History values that were
                 // interpolated inside the record's steps (a finer successor) carry the interpolant's ~1e-11 ripple, which
                 // the higher differences would amplify by the cube / fourth power of the tile length: quadratic then.
-                if (!startup && kind >= (kSPL >= 4 ? MP_LOGPRED_MIN_KIND : MP_LOGPRED_MIN_KIND_SPL2)) {
+                if (!startup && (kind >= (kSPL >= 4 ? MP_LOGPRED_MIN_KIND : MP_LOGPRED_MIN_KIND_SPL2) ||
+                                 (MP_LOGPRED_AFTER_SUBSTEPS && kind >= 2 && rec_kind == 0))) {
                     // Coarse tiles (round 4): a tile over 8 grid intervals spans 1.2 decades of time, over which omega follows
                     // power laws, not polynomials: the quartic in the index was off by 15 % (median) to a factor of 6 (one tile in
                     // ten) at the tile's end, and its 4th difference amplifies the 1e-10 noise of the history by 2e8.  Instead
@@ -974,6 +990,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                         // a kink or a fast feature gets single intervals; slow sweeps alone, the next finer stride, which is
                         // then held for a few tiles
                         next_kind = (((B | I1) >> first) & 1ull) ? 1 : kind - 1;
+                        bool by_ratio = false;
 #if MP_CUT_BY_RATIO > 0
                         // round 4: a fast feature (no kink) gets the stride its excess over the bound asks for (order 5: a halving of
                         // the step buys 32 x; margin 2 as in the promotions), judged over the MP_CUT_BY_RATIO lanes from the cut on:
@@ -984,15 +1001,22 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                         if (((B >> first) & 1ull) == 0ull && ((I1 >> first) & 1ull) != 0ull) {
                             const unsigned long long win = (first + MP_CUT_BY_RATIO < 64 ? (1ull << (first + MP_CUT_BY_RATIO)) - 1ull : ~0ull) & ~((1ull << first) - 1ull);
                             const unsigned long long X16 = __ballot(ind16x), X512 = __ballot(ind512x);
-                            if ((B & win) == 0ull) next_kind = (X16 & win) == 0ull ? kind - 1 : ((X512 & win) == 0ull ? max(kind - 2, 1) : 1);
+                            if ((B & win) == 0ull) {
+                                next_kind = (X16 & win) == 0ull ? kind - 1 : ((X512 & win) == 0ull ? max(kind - 2, 1) : 1);
+                                by_ratio = (kSPL >= 4 ? MP_CUT_NO_HOLD_SPL4 : MP_CUT_NO_HOLD_SPL2) != 0;
+                            }
                         }
 #endif
                         // (a coarse successor is held for three tiles either way: releasing the one a feature's excess asked for at
                         // once, or promoting a calm stride-2 tile straight to 8, changed nothing measurable: profiles/r04_ab_cut_by_ratio.log)
-                        if (next_kind >= 2) { hold_kind = next_kind; hold = 3; }
+                        if (next_kind >= 2 && !by_ratio) { hold_kind = next_kind; hold = 3; }
                     } else if (kind < max_kind && nc == kTile) {
                         if (hold > 0 && kind == hold_kind) --hold;
                         else next_kind = (kind == 3 ? Ip8 : I64) == 0ull ? kind + 1 : kind;
+                        // a calm tile over 2 intervals whose indicator leaves room for 4 x the step (4^5 = 1 024, margin 2, and the
+                        // tenth that steps over 8 intervals are held to: 65 536 covers 20 480) may go to 8 at once
+                        if ((kSPL >= 4 ? MP_DOUBLE_PROMOTION_SPL4 : MP_DOUBLE_PROMOTION_SPL2) && kind == 2 && next_kind == 3 && max_kind >= 4 &&
+                            I65536 == 0ull) next_kind = 4;
                         opt_kind = max(opt_kind, min(next_kind, max_kind));
                     }
                 } else if (unconv != 0ull) {                                    // kinds 0, 1 stopped early: the converged lanes
@@ -1017,7 +1041,12 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                         else if (tail >= 6 + kSPL && (I64 & post) == 0ull) next_kind = 2;
                     }
                 }
-                if (kind == 0) next_kind = 4;   // after the sub-stepped tiles: optimistic (a tile that meets a fast feature is cut)
+                // after the sub-stepped tiles: optimistic (a tile that meets a fast feature is cut) -- as far as the record of the
+                // last of them reaches: the successor's history points lie 1, 2, 3 of ITS steps before its start, and a tile
+                // of 128 sub-steps (2 steps per lane) covers 16 grid intervals, not the 24 a step over 8 asks for.  (Until round 4
+                // that attempt was made, read a default for the third point, failed its indicator test in the first lanes and
+                // was redone over 4 intervals: a tile wasted per walker in every 2-steps-per-lane launch.)
+                if (kind == 0) next_kind = ((keep_lanes * kSPL) >> 3) >= 24 ? 4 : (((keep_lanes * kSPL) >> 3) >= 12 ? 3 : (((keep_lanes * kSPL) >> 3) >= 6 ? 2 : 1));
                 next_kind = min(next_kind, max_kind);
             }
             MP_PHASE(5)
