@@ -406,10 +406,12 @@ MP_DEV void image_state(const DevShared &sh, const Walker &w, const TileImage<SP
 
 // ---------------------------------------------------------------- the kernel
 // Evaluate ONE walker on the calling wavefront (all 64 lanes enter with identical arguments).
+// LOG: compiled with the per-tile diagnostics (mp_tile_log); the production builds are not: the words' bookkeeping (the `why`
+// bits need four ballots nothing else uses) costs scalar registers in kernels that spill them.
 // SPL = consecutive steps owned by one lane; a tile is 64*SPL steps.  par[] holds the sampler coordinates
 // (prior checked and log-masked coordinates un-logged here unless a.physical); walker indexes ds_id and the
 // optional curve outputs; im / Lbuf are the wave's LDS areas (Lbuf: [8*64*SPL + 1], staging of the curve outputs).
-template <bool CURVES, int SPL, bool LONG>
+template <bool CURVES, int SPL, bool LONG, bool LOG = false>
 MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, double (&par)[MP_MAX_NDIM],
                         TileImage<SPL> &im, const TimeTable<SPL> &tt, double *Lbuf, double &lnp_out, int &status_out,
                         int &sweeps_out, int &tiles_out) {
@@ -649,8 +651,13 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 // Newton backward-difference extrapolation (quartic once five values exist).  History values that were
                 // interpolated inside the record's steps (a finer successor) carry the interpolant's ~1e-11 ripple, which
                 // the higher differences would amplify by the cube / fourth power of the tile length: quadratic then.
-                if (!startup && (kind >= (kSPL >= 4 ? MP_LOGPRED_MIN_KIND : MP_LOGPRED_MIN_KIND_SPL2) ||
-                                 (MP_LOGPRED_AFTER_SUBSTEPS && kind >= 2 && rec_kind == 0))) {
+                // (compile-time: the 2-steps-per-lane kernels, two waves per SIMD on 256 registers each, do not carry this code)
+                constexpr int kLogPredMinKind = kSPL >= 4 ? MP_LOGPRED_MIN_KIND : MP_LOGPRED_MIN_KIND_SPL2;
+                constexpr bool kLogPredEver = kLogPredMinKind <= 4 || MP_LOGPRED_AFTER_SUBSTEPS != 0;
+                bool guessed = false;
+                if constexpr (kLogPredEver) {
+                if (!startup && (kind >= kLogPredMinKind || (MP_LOGPRED_AFTER_SUBSTEPS && kind >= 2 && rec_kind == 0))) {
+                    guessed = true;
                     // Coarse tiles (round 4): a tile over 8 grid intervals spans 1.2 decades of time, over which omega follows
                     // power laws, not polynomials: the quartic in the index was off by 15 % (median) to a factor of 6 (one tile in
                     // ten) at the tile's end, and its 4th difference amplifies the 1e-10 noise of the history by 2e8.  Instead
@@ -675,7 +682,9 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                     const Vd<kSPL> ee = exp_fast(ex);
 #pragma unroll
                     for (int s = 0; s < kSPL; ++s) wg[s] = om_s * ee[s];
-                } else {
+                }
+                }
+                if (!guessed) {
                 const double g1 = om_s - cw1, g2 = g1 - (cw1 - cw2);
                 const double d2b = (cw1 - cw2) - (cw2 - cw3);
                 const double g3 = (startup || interp_hist) ? 0.0 : g2 - d2b;
@@ -715,7 +724,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
             // likewise every coarse tile that starts before t = early_hold_t (4 s), and steps over 8 intervals:
             // oracle/mp_oracle.c)
             const double tile_tol = (kind >= 2 && (rec_kind == 0 || t_s < sh.early_hold_t)) ? 0.1 * sh.stride_tol : (kind >= 4 ? sh.k4_tol_factor * sh.stride_tol : sh.stride_tol);
-            bool abort_tile = false;
+            bool abort_tile = false, abort_skip = false;
             while (true) {
                 ++sweep;
                 if (!light) {   // (after a sweep that moved every lane by < 1e-4 the guesses are positive and finite)
@@ -860,13 +869,19 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 // 90 % were beyond it after sweep 2 already.)
                 if (kind >= 2 && sweep >= 2) {
                     const double margin = sweep == 2 ? 4.0 : 1.0;
-                    bool hot = false;
+                    bool hot = false, very_hot = false;
 #pragma unroll
                     for (int s = 0; s < kSPL; ++s) {
                         const double d4 = 120.0 * fabs(p5[s]) * h[s] * fabs((n0[s] + n4[s]) - 4.0 * (n1[s] + n3[s]) + 6.0 * n2[s]);
-                        hot = hot || d4 > margin * tile_tol * wg[s];
+                        const double lim = margin * tile_tol * wg[s];
+                        hot = hot || d4 > lim;
+                        very_hot = very_hot || d4 > MP_ABORT_SKIP_RATIO * lim;
                     }
-                    if ((__ballot(hot) & ((1ull << kMinKeepLanes) - 1ull)) != 0ull) { abort_tile = true; break; }
+                    if ((__ballot(hot) & ((1ull << kMinKeepLanes) - 1ull)) != 0ull) {
+                        abort_tile = true;
+                        abort_skip = (__ballot(very_hot) & ((1ull << kMinKeepLanes) - 1ull)) != 0ull;
+                        break;
+                    }
                 }
                 // Slow sweeps on single intervals (a poor extrapolated guess through a fast spin-up, far from the break-up
                 // limit): the lanes that have converged are final (a step depends on earlier ones only); they are kept
@@ -880,8 +895,9 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
             sweeps_total += sweep;
             MP_PHASE(17)
             if (abort_tile) {                                                   // redo at stride 1 (as after a tile that keeps nothing)
-                // by how much the first lanes exceeded the bound they were held to (what decided the abort): wave maximum of
-                // indicator / (margin x bound) over the first kMinKeepLanes lanes
+#ifdef MP_ABORT_STUDY
+                // developer build (tools/abort_study.py): by how much the first lanes exceeded the bound they were held to, as
+                // 8 log2 of the wave maximum of indicator / (margin x bound) over the first kMinKeepLanes lanes, in the tile log
                 double hot_ratio = 0.0;
                 {
                     const double margin = sweep == 2 ? 4.0 : 1.0;
@@ -895,16 +911,19 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                     for (int d = 4; d >= 1; d >>= 1) hot_ratio = fmax(hot_ratio, __shfl_xor(hot_ratio, d, 64));
                     hot_ratio = lane_bcast(hot_ratio, 0);
                 }
-                if (MP_TILE_LOG_ON && a.tile_log && lane == 0 && tiles_total <= MP_TILE_LOG)
-                    a.tile_log[(size_t)walker * MP_TILE_LOG + tiles_total - 1] =
-                        kind | (sweep << 4) | (min(255, max(0, (int)(8.0 * log2(fmax(hot_ratio, 1.0))))) << 16) | (64 << 24);
+                const int hot_q = min(255, max(0, (int)(8.0 * log2(fmax(hot_ratio, 1.0)))));
+#else
+                const int hot_q = abort_skip ? 255 : 0;
+#endif
+                if (MP_TILE_LOG_ON && LOG && a.tile_log && lane == 0 && tiles_total <= MP_TILE_LOG)
+                    a.tile_log[(size_t)walker * MP_TILE_LOG + tiles_total - 1] = kind | (sweep << 4) | (hot_q << 16) | (64 << 24);
                 cool = 3;
                 ++trouble;
                 // the next finer stride is tried at once -- or the one after it, when the first lanes were beyond the bound by
                 // more than a halving of the step buys (order 5: a factor of 32).  Measured on 1 700 given-up tiles of 4 096
                 // prior-wide walkers (tools/abort_study.py, profiles/r04_abort_study.log): with an excess >= 32 the next finer
                 // stride kept nothing either in 50 % (from 8 intervals) / 95 % (from 4) of the cases and a dozen lanes otherwise.
-                const int drop = hot_ratio >= MP_ABORT_SKIP_RATIO ? 2 : 1;
+                const int drop = abort_skip ? 2 : 1;
                 opt_kind = max(2, kind - drop);
                 kind = kind - drop >= 2 ? kind - drop : 1;
                 continue;
@@ -980,7 +999,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                         if (first < kMinKeepLanes) {                            // nothing worth keeping: redo at stride 1
                             opt_kind = max(2, kind - 1);
                             ++trouble;
-                            if (MP_TILE_LOG_ON && a.tile_log && lane == 0 && tiles_total <= MP_TILE_LOG)
+                            if (MP_TILE_LOG_ON && LOG && a.tile_log && lane == 0 && tiles_total <= MP_TILE_LOG)
                                 a.tile_log[(size_t)walker * MP_TILE_LOG + tiles_total - 1] = kind | (sweep << 4) | (why << 24);
                             // a kink in those lanes: single intervals; else the next finer stride is tried at once
                             kind = (kind > 2 && (B & ((1ull << kMinKeepLanes) - 1ull)) == 0ull) ? kind - 1 : 1;
@@ -1051,7 +1070,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
             }
             MP_PHASE(5)
             const int keep = min(keep_lanes * kSPL, nc);                       // steps kept
-            if (MP_TILE_LOG_ON && a.tile_log && lane == 0 && tiles_total <= MP_TILE_LOG)
+            if (MP_TILE_LOG_ON && LOG && a.tile_log && lane == 0 && tiles_total <= MP_TILE_LOG)
                 a.tile_log[(size_t)walker * MP_TILE_LOG + tiles_total - 1] = kind | (sweep << 4) | (keep_lanes << 16) | (why << 24);
             const int end_kept8 = pos8 + keep * d8;
 

@@ -42,7 +42,13 @@
 namespace mp {
 
 // ---------------------------------------------------------------- batched log-posterior kernel
-template <bool CURVES, int SPL, bool LONG>
+// LOG: the build with the per-tile diagnostics (mp_tile_log(h, 1); developer builds: always), launched only on request
+#if defined(MP_PHASE_PROFILE) || defined(MP_SWEEP_TRACE) || defined(MP_CORR_TRACE) || defined(MP_ABORT_STUDY)
+constexpr bool kAlwaysLog = true;
+#else
+constexpr bool kAlwaysLog = false;
+#endif
+template <bool CURVES, int SPL, bool LONG, bool LOG = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPL >= 4 ? 1 : 2, SPL >= 4 ? 1 : 2))) void lnprob_kernel(const DevShared sh, const LaunchArgs a) {
     __shared__ TileImage<SPL> im;
     __shared__ TimeTable<SPL> tt;
@@ -57,7 +63,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPL >= 4 ? 1
     for (int i = 0; i < MP_MAX_NDIM; ++i) par[i] = i < a.ndim ? pw[i] : 0.0;
     double lnp;
     int status, sweeps, tiles;
-    walker_eval<CURVES, SPL, LONG>(sh, a, walker, par, im, tt, Lbuf, lnp, status, sweeps, tiles);
+    walker_eval<CURVES, SPL, LONG, LOG>(sh, a, walker, par, im, tt, Lbuf, lnp, status, sweeps, tiles);
     if (threadIdx.x == 0) {
         a.lnprob[walker] = lnp;
         if (a.status) a.status[walker] = status;
@@ -452,6 +458,14 @@ int launch_lnprob(const DevShared &sh, const LaunchArgs &a, void *stream) {
     if (curves) {
         if (wide) hipLaunchKernelGGL((lnprob_kernel<true, 4, false>), grid, block, 0, st, sh, a);
         else hipLaunchKernelGGL((lnprob_kernel<true, 2, false>), grid, block, 0, st, sh, a);
+    } else if (a.tile_log != nullptr || kAlwaysLog) {   // diagnostics requested: the builds that record the tile words
+        if (wide) {
+            if (lng) hipLaunchKernelGGL((lnprob_kernel<false, 4, true, true>), grid, block, 0, st, sh, a);
+            else hipLaunchKernelGGL((lnprob_kernel<false, 4, false, true>), grid, block, 0, st, sh, a);
+        } else {
+            if (lng) hipLaunchKernelGGL((lnprob_kernel<false, 2, true, true>), grid, block, 0, st, sh, a);
+            else hipLaunchKernelGGL((lnprob_kernel<false, 2, false, true>), grid, block, 0, st, sh, a);
+        }
     } else if (wide) {
         if (lng) hipLaunchKernelGGL((lnprob_kernel<false, 4, true>), grid, block, 0, st, sh, a);
         else hipLaunchKernelGGL((lnprob_kernel<false, 4, false>), grid, block, 0, st, sh, a);

@@ -94,28 +94,30 @@ if avg:
         lines.append(f"| {k} | {v:.6g} |")
     if meta:
         lines += ["", "dispatch: " + ", ".join(f"{k}={v}" for k, v in meta.items())]
-        # LDS occupancy (BASELINE.json configs[2] asks for it): waves resident per CU as the register allocation allows
-        # (512 VGPRs + AGPRs per SIMD lane, 4 SIMDs per CU, one-wave workgroups) x LDS bytes per workgroup against the
-        # 160 KB of a CU
+        # LDS occupancy (BASELINE.json configs[2] asks for it): resident one-wave workgroups per CU x LDS bytes per workgroup
+        # against the 160 KB of a CU.  Waves per SIMD are fixed by the kernels' amdgpu_waves_per_eu attribute (mp_kernels.hip:
+        # one for the 4-steps-per-lane builds, which take a SIMD's whole register file, two for the 2-steps-per-lane ones);
+        # the register fields of the dispatch record are not used for this.
         try:
-            regs = int(meta.get("VGPR_Count") or 0) + int(meta.get("Accum_VGPR_Count") or 0)
+            import re
             lds = int(meta.get("LDS_Block_Size") or 0)
             wg = int(meta.get("Workgroup_Size") or 64)
-            if regs > 0 and lds > 0 and wg == 64:
-                waves_simd = max(1, min(8, 512 // regs))
-                waves_cu_regs = 4 * waves_simd
-                waves_cu_lds = (160 * 1024) // lds
-                resident = min(waves_cu_regs, waves_cu_lds)
-                occ = {"waves_per_simd_by_registers": waves_simd, "workgroups_per_cu_by_registers": waves_cu_regs,
-                       "workgroups_per_cu_by_lds": waves_cu_lds, "resident_workgroups_per_cu": resident,
-                       "lds_bytes_in_use_per_cu": resident * lds, "lds_occupancy_frac_of_160KB": resident * lds / (160.0 * 1024.0),
-                       "limited_by": "registers" if waves_cu_regs <= waves_cu_lds else "LDS"}
+            m = re.search(r"(?:lnprob_kernel<(?:true|false), (\d)|stretch(?:_step)?_kernel<(\d))", str(summary.get("kernel", "")))
+            spl = int(next(g for g in m.groups() if g)) if m else 0
+            if spl and lds > 0 and wg == 64:
+                waves_simd = 1 if spl >= 4 else 2
+                by_regs = 4 * waves_simd
+                by_lds = (160 * 1024) // lds
+                resident = min(by_regs, by_lds)
+                occ = {"waves_per_simd": waves_simd, "workgroups_per_cu_by_registers": by_regs, "workgroups_per_cu_by_lds": by_lds,
+                       "resident_workgroups_per_cu": resident, "lds_bytes_in_use_per_cu": resident * lds,
+                       "lds_occupancy_frac_of_160KB": resident * lds / (160.0 * 1024.0),
+                       "limited_by": "registers" if by_regs <= by_lds else "LDS"}
                 summary["lds_occupancy"] = occ
-                lines += ["", f"LDS occupancy: {lds} B per one-wave workgroup x {resident} resident workgroups per CU "
-                              f"({waves_simd} per SIMD, limited by {occ['limited_by']}: {regs} registers per lane; LDS alone would allow "
-                              f"{waves_cu_lds}) = {resident * lds / 1024.0:.1f} KB of the CU's 160 KB "
-                              f"({100.0 * occ['lds_occupancy_frac_of_160KB']:.0f} %)"]
-        except (TypeError, ValueError):
+                lines += ["", f"LDS occupancy: {lds} B per one-wave workgroup x {resident} resident workgroups per CU ({waves_simd} "
+                              f"per SIMD, limited by {occ['limited_by']}; LDS alone would allow {by_lds}) = {resident * lds / 1024.0:.1f} KB "
+                              f"of the CU's 160 KB ({100.0 * occ['lds_occupancy_frac_of_160KB']:.0f} %)"]
+        except (TypeError, ValueError, StopIteration):
             pass
 for b in ("bench_trace.json",):
     p = os.path.join(out, b)
