@@ -39,7 +39,10 @@
  *   - mp_lnprob_batch_dev and the mp_sampler_halfstep_* / mp_sampler_step_* calls only enqueue work on the stream
  *     they are given.  Launches of one handle on different streams may overlap on the device: a launch writes nothing
  *     but its own outputs (since ABI 4 also for handles that hold light curves of more than 64 points, which until
- *     ABI 3 owned per-walker scratch rows and were ordered by the library).
+ *     ABI 3 owned per-walker scratch rows and were ordered by the library).  A batch that mixes light curves of more
+ *     than 64 points with short ones and exceeds two wavefronts per SIMD is launched longest light curves first
+ *     (results do not depend on it); its index buffer comes from a ring of eight per handle, so of such launches only
+ *     those eight apart are ordered (by an event, on the device).
  *   - Buffers passed to an asynchronous call must stay valid until the work has completed on that stream;
  *     replacing a dataset (mp_set_dataset) waits for the device first.
  *   - All mp_sampler_halfstep_* calls of one sampler must use one stream.

@@ -665,7 +665,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                     // at the tile's start and the two points before it (exact right-hand sides, no differencing of values);
                     // its quadratic Newton polynomial in the index, integrated from 0 to k, gives
                     //   log(omega_k / omega_s) = a0 k + d1 k^2/2 + d2 (k^3/6 + k^2/4),   d1, d2 = backward differences of a.
-                    // Median error at the end of such a tile 5 %, one tile in ten 60 % (tools/predictor_study.py); the Newton
+                    // Median error at the end of such a tile 5 %, one tile in ten 60 % (tests/diagnostics/predictor_study.py); the Newton
                     // sweeps double the number of correct digits per pass, so this saves most coarse tiles a sweep.
                     const Vd<3> den{{om_s, cw1, cw2}};
                     const Vd<3> rd = rcp_fast(den);

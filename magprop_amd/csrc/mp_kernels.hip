@@ -63,7 +63,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPL >= 4 ? 1
     for (int i = 0; i < MP_MAX_NDIM; ++i) par[i] = i < a.ndim ? pw[i] : 0.0;
     double lnp;
     int status, sweeps, tiles;
-    walker_eval<CURVES, SPL, LONG, LOG>(sh, a, walker, par, im, tt, Lbuf, lnp, status, sweeps, tiles);
+    if constexpr (CURVES) {
+        walker_eval<CURVES, SPL, LONG, LOG>(sh, a, walker, par, im, tt, Lbuf, lnp, status, sweeps, tiles);
+    } else {
+        // (only the curve kernels serve mp_model_lc: here the parameters are the sampler's and chi^2 is wanted, at compile time)
+        LaunchArgs aa = a;
+        aa.physical = 0;
+        aa.want_chi2 = 1;
+        walker_eval<CURVES, SPL, LONG, LOG>(sh, aa, walker, par, im, tt, Lbuf, lnp, status, sweeps, tiles);
+    }
     if (threadIdx.x == 0) {
         a.lnprob[walker] = lnp;
         if (a.status) a.status[walker] = status;

@@ -8,10 +8,10 @@ spacing and compared with the trajectory:
   dlog    round 4: log(omega) from the quadratic Newton polynomial of its DERIVATIVE, d log(omega)/dk = omega_dot t ln(Q) / omega, at
           the tile's start and the two points before it, integrated from 0 to k (no differencing of values)
 Printed: log10 of the largest relative error over the tile: median, 90th percentile, maximum over the tile starts.
-    python tools/predictor_study.py"""
+    python tests/diagnostics/predictor_study.py"""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import c_oracle as co
 g = np.load(os.path.join(ROOT, "tests", "golden", "golden_synth.npz"))
