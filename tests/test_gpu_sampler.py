@@ -296,6 +296,17 @@ def test_sharded_lnprob_pipelined_over_rccl(gsynth):
         for w, g_ in zip(want, got):
             assert torch.equal(w, g_)
         assert torch.equal(sh(batches[0]), want[0])              # blocking form
+        # round 4: the wait for the gathered vector on a CONSUMER stream (what bench.py's independent passes do, so that the
+        # compute stream never waits for a collective): caller-owned receive buffers, results read on that stream
+        consumer = torch.cuda.Stream(dev)
+        recv = torch.empty(len(batches), 1024, dtype=torch.float64, device=dev)
+        tickets = [sh.start(b, recv=recv[i]) for i, b in enumerate(batches)]
+        outs = [sh.finish(t, stream=consumer) for t in tickets]
+        with torch.cuda.stream(consumer):
+            got2 = [o.clone() for o in outs]
+        torch.cuda.synchronize()
+        for w, g_ in zip(want, got2):
+            assert torch.equal(w, g_)
         # the walker-sharded sampler with its real collective (all_gather_into_tensor of the outcome rows over RCCL)
         from magprop_amd import EnsembleSampler
         from magprop_amd.distributed import DistributedEnsembleSampler, HipShardEngine
