@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Developer diagnostic (GPU box): when a coarse tile is given up early (mp_eval.hpp abort_tile), by how much had its first
 lanes exceeded the bound, and what did the next attempt (one stride finer) do?  Basis of the rule that skips strides.
-    python tools/abort_study.py [n]"""
+    make -C magprop_amd/csrc abort-study && MAGPROP_AMD_LIB=$PWD/magprop_amd/libmagprop_amd_abort.so python tools/abort_study.py [n]
+(the shipped library records only WHETHER the excess was beyond the skip threshold: 255 or 0 in the word's lane field)"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
