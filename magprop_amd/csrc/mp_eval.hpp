@@ -240,6 +240,16 @@ MP_DEV int walker_setup(const DevShared &sh, const LaunchArgs &a, double (&par)[
 #ifndef MP_CUT_BY_RATIO
 #define MP_CUT_BY_RATIO 24
 #endif
+// 2-steps-per-lane kernels, adaptive stride: the sub-stepped start ends after its first tile (16 grid intervals) when that tile's
+// indicator, scaled to a step of a whole interval (8^5 with the margin of 2 = 65 536) and held to a tenth like the tile behind
+// the sub-steps, stays below the bound everywhere and no kink lies in it.  (Simply halving the sub-stepped stretch put one
+// golden point -- a spin-up transient at t = 1 s -- at 1.01 of the tight bound in the serial restatement: tests/test_oracle.py.)
+#ifndef MP_PRE_EARLY_END
+#define MP_PRE_EARLY_END 1
+#endif
+#ifndef MP_PRE_EARLY_END_FACTOR
+#define MP_PRE_EARLY_END_FACTOR 6553600.0
+#endif
 #ifndef MP_LOGPRED_AFTER_SUBSTEPS
 #define MP_LOGPRED_AFTER_SUBSTEPS 0   // 1: the coarse tile right behind the sub-stepped start uses the log-space guess in every kernel
 #endif
@@ -509,8 +519,11 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
         }
         // ---- tile control (wave-uniform).  Positions in eighths of a grid interval: the first pre_fine intervals are
         // covered with 1/8-interval sub-steps (kind 0), the rest with steps of 1, 2, 4 or 8 intervals (kinds 1 .. 4).
-        const int end8 = 8 * nsteps, pre_end8 = 8 * sh.pre_fine;
+        // (sub-stepped start: 32 grid intervals = one tile of 256 sub-steps, two of 128 in the 2-steps-per-lane kernels -- which
+        // end it after the first when that tile was calm, see MP_PRE_EARLY_END below)
         const int max_kind = sh.max_kind;
+        const int end8 = 8 * nsteps;
+        int pre_end8 = 8 * sh.pre_fine;
         int pos8 = 0, kind = 1;
         bool rec_valid = false;                  // the image holds a kept tile (the history of the next one)
         int rec_kind = 0, rec_sh8 = 0, rec_J = 0; // its kind, log2 of its step in eighths and the number of steps kept
@@ -962,7 +975,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
             // stride_tol / 64 and / 2048 (what it would be at twice / four times the step: 5th-order scaling, margin 2).
             int keep_lanes = 64, next_kind = kind, why = 0;   // why: diagnostics (tile log)
             {
-                bool brk = false, ind1 = false, ind64 = false, ind2048 = false, ind65536 = false, indp8 = false;
+                bool brk = false, ind1 = false, ind64 = false, ind2048 = false, ind65536 = false, indp8 = false, indpre = false;
 #if MP_CUT_BY_RATIO > 0
                 bool ind16x = false, ind512x = false;
 #endif
@@ -980,6 +993,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                     ind64 = ind64 || 64.0 * d4 > lim;
                     ind2048 = ind2048 || 2048.0 * d4 > lim;
                     ind65536 = ind65536 || 65536.0 * d4 > lim;
+                    if constexpr (kSPL < 4 && MP_PRE_EARLY_END != 0) indpre = indpre || MP_PRE_EARLY_END_FACTOR * d4 > lim;
                     indp8 = indp8 || prom8 * d4 > lim;
 #if MP_CUT_BY_RATIO > 0
                     ind16x = ind16x || d4 > 16.0 * lim;
@@ -1065,6 +1079,10 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 // of 128 sub-steps (2 steps per lane) covers 16 grid intervals, not the 24 a step over 8 asks for.  (Until round 4
                 // that attempt was made, read a default for the third point, failed its indicator test in the first lanes and
                 // was redone over 4 intervals: a tile wasted per walker in every 2-steps-per-lane launch.)
+                if constexpr (kSPL < 4 && MP_PRE_EARLY_END != 0) {
+                    if (pre && max_kind > 1 && keep_lanes == 64 && nc == kTile && pos8 + nc < pre_end8 && B == 0ull && __ballot(indpre) == 0ull)
+                        pre_end8 = pos8 + nc;                                  // the sub-stepped start ends here
+                }
                 if (kind == 0) next_kind = ((keep_lanes * kSPL) >> 3) >= 24 ? 4 : (((keep_lanes * kSPL) >> 3) >= 12 ? 3 : (((keep_lanes * kSPL) >> 3) >= 6 ? 2 : 1));
                 next_kind = min(next_kind, max_kind);
             }

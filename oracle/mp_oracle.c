@@ -456,7 +456,7 @@ int mpo_trajectory_mode(const mpo_cfg *c, const double *pars, int ndim, const do
     }
     if (Mout) Mout[0] = M;
     if (Wout) Wout[0] = om;
-    const int pre_fine = nsteps < MPO_PRE_FINE ? nsteps : MPO_PRE_FINE;
+    int pre_fine = nsteps < MPO_PRE_FINE ? nsteps : MPO_PRE_FINE;
     int i0 = 0;          /* grid index of the tile start */
     int sub_done = 0;    /* sub-steps of the pre-phase done */
     int s = 1;           /* stride of the next grid tile */
@@ -642,7 +642,21 @@ int mpo_trajectory_mode(const mpo_cfg *c, const double *pars, int ndim, const do
             }
             if (next_s > max_stride) next_s = max_stride;
         }
-        if (pre) next_s = (mode == 1 && sub_done + keep >= pre_fine * MPO_PRE_SUB) ? max_stride : 1;   /* optimistic after the sub-steps */
+        /* 128-step tiles (spl < 4), adaptive stride: the sub-stepped start ends after a tile that was calm -- its indicator scaled
+           to a step of a whole interval (8^5, margin 2: 65 536) and held to a tenth stays below the bound everywhere, no kink in
+           it (mp_eval.hpp MP_PRE_EARLY_END) */
+        if (pre && mode == 1 && spl < 4 && max_stride > 1 && keep == nc && nc == TILE && sub_done + keep < pre_fine * MPO_PRE_SUB) {
+            int calm = 1;
+            for (int e = 0; e < keep; ++e) if (brk[e] || 6553600.0 * ind[e] > stride_tol) calm = 0;
+            if (calm) pre_fine = (sub_done + keep) / MPO_PRE_SUB;
+        }
+        if (pre) {
+            next_s = (mode == 1 && sub_done + keep >= pre_fine * MPO_PRE_SUB) ? max_stride : 1;   /* optimistic after the sub-steps ... */
+            /* ... as far as the last sub-stepped tile reaches back (the kernels' history is that tile's record: a successor over s
+               intervals needs points 3 s intervals before its start) */
+            const int reach = keep / MPO_PRE_SUB;
+            while (next_s > 1 && 3 * next_s > reach) next_s /= 2;
+        }
         /* ---- commit the kept steps: nodes, and the grid points they contain */
         mpo_node prev = nd[nn - 1];
         const mpo_node tile_start = prev;
