@@ -247,6 +247,9 @@ MP_DEV int walker_setup(const DevShared &sh, const LaunchArgs &a, double (&par)[
 #ifndef MP_PRE_EARLY_END
 #define MP_PRE_EARLY_END 1
 #endif
+#ifndef MP_REALIGN
+#define MP_REALIGN 1
+#endif
 #ifndef MP_PRE_EARLY_END_FACTOR
 #define MP_PRE_EARLY_END_FACTOR 6553600.0
 #endif
@@ -551,9 +554,23 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
             int d8 = pre ? 1 : (4 << kind);                                 // 8, 16, 32, 64 eighths
             const int left8 = (pre ? pre_end8 : end8) - pos8;
             // (whole steps only; and at least three of them, for the dense output's four nodes)
+            const int want_kind = kind;
             if (!pre) while (kind > 1 && ((left8 & (d8 - 1)) != 0 || left8 < 3 * d8)) { --kind; d8 >>= 1; }
             const int sh8 = pre ? 0 : kind + 2;                             // d8 = 1 << sh8
-            const int nc = min(kTile, left8 >> sh8);                        // steps of this tile that exist
+            int nc = min(kTile, left8 >> sh8);                              // steps of this tile that exist
+#if MP_REALIGN
+            // What is left after a tile must be a whole number of the NEXT tile's steps.  A cut tile can leave a remainder that is
+            // not a multiple of 8 grid intervals (kept lanes x steps per lane x stride), and full tiles of a finer stride
+            // preserve it: until round 4 a walker so placed ran at 4 intervals to the end of the grid (burnt-in Classic walkers
+            // of the 2-steps-per-lane kernels: ten tiles over 4 where five over 8 do).  Now the tile that had to step finer than
+            // the policy asked ends a few steps early, where the asked-for stride fits.
+            if (!pre && kind < want_kind && left8 >= 3 * (4 << want_kind)) {
+                const int D = 4 << want_kind;                               // the asked-for step in eighths
+                const int after = left8 - (nc << sh8);
+                const int m = ((D - (after & (D - 1))) & (D - 1)) >> sh8;   // steps to leave for the next tile
+                if (nc - m >= 3) nc -= m;
+            }
+#endif
             const StrideK &K = sh.sk[kind];
             const int wbase = kind * kWtabStride;                           // this kind's quadrature matrices in the LDS table
             ++tiles_total;
@@ -1043,7 +1060,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                         // (a coarse successor is held for three tiles either way: releasing the one a feature's excess asked for at
                         // once, or promoting a calm stride-2 tile straight to 8, changed nothing measurable: profiles/r04_ab_cut_by_ratio.log)
                         if (next_kind >= 2 && !by_ratio) { hold_kind = next_kind; hold = 3; }
-                    } else if (kind < max_kind && nc == kTile) {
+                    } else if (kind < max_kind && nc + 8 > kTile) {            // (a full tile, or one that ended a few steps early to realign)
                         if (hold > 0 && kind == hold_kind) --hold;
                         else next_kind = (kind == 3 ? Ip8 : I64) == 0ull ? kind + 1 : kind;
                         // a calm tile over 2 intervals whose indicator leaves room for 4 x the step (4^5 = 1 024, margin 2, and the
@@ -1055,7 +1072,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 } else if (unconv != 0ull) {                                    // kinds 0, 1 stopped early: the converged lanes
                     keep_lanes = __ffsll(unconv) - 1;
                     if (pre) keep_lanes &= ~(8 / kSPL - 1);                    // (whole grid intervals of sub-steps)
-                } else if (kind == 1 && nc == kTile) {
+                } else if (kind == 1 && nc + 8 > kTile) {
                     // No kink in this tile: the scaled indicator decides while a recent coarse attempt has failed early
                     // (cool > 0); otherwise the coarsest stride is simply tried (a tile is cut where it does not hold): the
                     // indicator of a tile whose sweeps stopped at the tolerance carries their residual, amplified by the 4th
@@ -1067,7 +1084,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                     else {
                         // a kink inside this tile: the history of a coarse successor must lie behind it
                         const int first_clean = __ffsll(B) - 1 + 2;            // lanes from here on are past the kink
-                        const int tail = kTile - first_clean * kSPL;           // steps in them
+                        const int tail = nc - first_clean * kSPL;              // steps in them
                         const unsigned long long post = first_clean < 64 ? ~0ull << first_clean : 0ull;
                         if (tail >= 24 + kSPL && (I65536 & post) == 0ull) next_kind = 4;
                         else if (tail >= 12 + kSPL && (I2048 & post) == 0ull) next_kind = 3;
