@@ -27,7 +27,9 @@ def aicc(ydata, ymod, yerr, Npars):
         raise ValueError("ydata, ymod and yerr should all be the same length")
     k, n = float(Npars), float(ydata.size)
     chisq = np.sum(np.square((ydata - ymod) / yerr))
-    return 2.0 * k * (1.0 + (k + 1.0) / (n - k - 1.0)) - chisq
+    # (summed in the reference's order, -chi^2, then 2k, then the small-sample term, so that the value agrees with
+    # magnetar/fit_stats.py:58-62 to the last bit and not just to rounding)
+    return (-chisq + 2.0 * k) + (2.0 * k * (k + 1.0)) / (n - k - 1.0)
 
 
 def fit_statistics(pars, x, y, yerr, variant="synth", GRBtype=None, device=-1):
