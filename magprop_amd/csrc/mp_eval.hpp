@@ -247,6 +247,9 @@ MP_DEV int walker_setup(const DevShared &sh, const LaunchArgs &a, double (&par)[
 #ifndef MP_PRE_EARLY_END
 #define MP_PRE_EARLY_END 1
 #endif
+#ifndef MP_HOLD_RELEASE
+#define MP_HOLD_RELEASE 1
+#endif
 #ifndef MP_REALIGN
 #define MP_REALIGN 1
 #endif
@@ -1061,6 +1064,10 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                         // once, or promoting a calm stride-2 tile straight to 8, changed nothing measurable: profiles/r04_ab_cut_by_ratio.log)
                         if (next_kind >= 2 && !by_ratio) { hold_kind = next_kind; hold = 3; }
                     } else if (kind < max_kind && nc + 8 > kTile) {            // (a full tile, or one that ended a few steps early to realign)
+                        // (256-step tiles: the hold ends early when the held tile shows that the slow zone is behind -- sweeps converged
+                        // in three passes, indicator with room for four times the step: burnt-in ensembles 0.107 -> 0.103 ms; with
+                        // 128-step tiles it cost the sampler 1 %: profiles/r04_ab_hold_release.log)
+                        if (kSPL >= 4 && MP_HOLD_RELEASE && hold > 0 && kind == hold_kind && sweep <= 3 && I2048 == 0ull) hold = 0;
                         if (hold > 0 && kind == hold_kind) --hold;
                         else next_kind = (kind == 3 ? Ip8 : I64) == 0ull ? kind + 1 : kind;
                         // a calm tile over 2 intervals whose indicator leaves room for 4 x the step (4^5 = 1 024, margin 2, and the
