@@ -247,6 +247,9 @@ MP_DEV int walker_setup(const DevShared &sh, const LaunchArgs &a, double (&par)[
 #ifndef MP_PRE_EARLY_END
 #define MP_PRE_EARLY_END 1
 #endif
+#ifndef MP_ABORT_KINK
+#define MP_ABORT_KINK 1
+#endif
 #ifndef MP_HOLD_RELEASE
 #define MP_HOLD_RELEASE 1
 #endif
@@ -956,8 +959,19 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 // more than a halving of the step buys (order 5: a factor of 32).  Measured on 1 700 given-up tiles of 4 096
                 // prior-wide walkers (tools/abort_study.py, profiles/r04_abort_study.log): with an excess >= 32 the next finer
                 // stride kept nothing either in 50 % (from 8 intervals) / 95 % (from 4) of the cases and a dozen lanes otherwise.
-                const int drop = abort_skip ? 2 : 1;
-                opt_kind = max(2, kind - drop);
+                int drop = abort_skip ? 2 : 1;
+#if MP_ABORT_KINK
+                // ... or single intervals at once when the first lanes sit on a kink of the right-hand side (it makes the
+                // indicator hot at every coarse stride, and a coarse tile would only be kept up to it: near the Classic and
+                // Sloped truths the 128-step kernels spent a tile over 4 intervals on a dozen lanes there)
+                {
+                    bool brk = false;
+#pragma unroll
+                    for (int s = 0; s < kSPL; ++s) brk = brk || (lane * kSPL + s < nc && branch_flags(w, d1.rmu[s], wg[s]) != flags_s);
+                    if ((__ballot(brk) & ((1ull << kMinKeepLanes) - 1ull)) != 0ull) drop = 4;
+                }
+#endif
+                opt_kind = max(2, kind - (drop > 2 ? 1 : drop));
                 kind = kind - drop >= 2 ? kind - drop : 1;
                 continue;
             }
