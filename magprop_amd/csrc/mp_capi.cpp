@@ -454,6 +454,11 @@ mp_handle *mp_create(const mp_model_cfg *cfg, const double *tgrid, int n_grid, i
             }
         }
     }
+    // behind it: Q^k of the kinds 1 .. 4 (mp_device.h DevShared::ttab)
+    const size_t ttab_off = wtab.size();
+    wtab.resize(ttab_off + (size_t)(mp::kKinds - 1) * mp::kTtabN);
+    for (int kind = 1; kind < mp::kKinds; ++kind)
+        for (int k = 0; k < mp::kTtabN; ++k) wtab[ttab_off + (size_t)(kind - 1) * mp::kTtabN + k] = std::exp((double)k * s.sk[kind].lnQ);
     if (h->d_wtab.ensure(wtab.size()) != MP_OK ||
         hipMemcpy(h->d_wtab.p, wtab.data(), wtab.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
         fail(MP_EHIP, "mp_create: cannot upload the quadrature tables");
@@ -461,6 +466,7 @@ mp_handle *mp_create(const mp_model_cfg *cfg, const double *tgrid, int n_grid, i
         return nullptr;
     }
     s.wtab = h->d_wtab.p;
+    s.ttab = h->d_wtab.p + ttab_off;
     if (rebuild_datasets(h) != MP_OK) {
         mp_destroy(h);
         return nullptr;

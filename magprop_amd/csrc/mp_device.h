@@ -49,6 +49,7 @@ constexpr int kWtabTheta = 32;
 // (0: the first, the step is the first of the tile's kept part; 1: the middle; 2: the last), k = node
 constexpr int kWtabDense = kKinds * kWtabStride;
 constexpr int kWtabSize = kWtabDense + 3 * 7 * 12;
+constexpr int kTtabN = 257;
 
 // Everything the kernel reads that is shared by all walkers (resident in HBM, L2-hot).
 struct DevShared {
@@ -91,6 +92,8 @@ struct DevShared {
                           // held to a tenth of stride_tol, like the tile behind the sub-steps
     StrideK sk[kKinds];
     const double *wtab;   // [kWtabSize] quadrature matrices, skipped-point positions and dense-output weights of the tile kinds
+    const double *ttab;   // [kKinds - 1][kTtabN] Q^k of the kinds 1 .. 4, k = 0 .. 256 (host-computed once per handle: the kernels
+                          // used to spend 16 double-precision exponentials per lane on it at every launch)
     mp_model_cfg cfg;
 };
 

@@ -333,12 +333,8 @@ MP_DEV void time_table_init(const DevShared &sh, TimeTable<SPL> &tt) {   // ever
     const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int kind = 1; kind < kKinds; ++kind) {
-        Vd<SPL> ek;
 #pragma unroll
-        for (int s = 0; s < SPL; ++s) ek[s] = (double)(lane * SPL + s + 1) * sh.sk[kind].lnQ;
-        const Vd<SPL> E = exp_fast(ek);
-#pragma unroll
-        for (int s = 0; s < SPL; ++s) tt.E[kind - 1][lane * SPL + s + 1] = E[s];
+        for (int s = 0; s < SPL; ++s) tt.E[kind - 1][lane * SPL + s + 1] = sh.ttab[(kind - 1) * kTtabN + lane * SPL + s + 1];
         if (lane == 0) tt.E[kind - 1][0] = 1.0;
     }
     __syncthreads();
