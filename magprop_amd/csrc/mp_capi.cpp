@@ -736,6 +736,7 @@ struct mp_sampler {
     uint64_t steps_done = 0;
     bool have_state = false;
     DevBuf<double> d_pos, d_lnprob, d_chain, d_chain_lnp, d_bad, d_spec;
+    std::vector<int32_t> ens_ds;   // dataset of every ensemble
     int whole_step = 1;   // mp_sampler_run: one launch per step where the ensemble is small enough (mp_sampler_set_whole_step)
     DevBuf<int64_t> d_acc;
     DevBuf<int32_t> d_perm, d_dsid, d_status;
@@ -808,6 +809,20 @@ static mp::StretchArgs stretch_args(const mp_sampler *s, const int32_t *d_perm, 
     g.n_total = s->n_total; g.ndim = s->ndim; g.half = half; g.target = s->target;
     g.step = (uint32_t)step; g.seed = s->seed; g.a = s->a;
     g.bad_log = s->d_bad.p; g.bad_count = s->d_bad_count.p; g.bad_cap = (uint32_t)(s->d_bad.cap / (size_t)std::max(s->ndim, 1));
+    // Ensembles on light curves of different lengths (BASELINE config 5: 50 / 410 / 8 / 1 944 points): the half-step launch
+    // starts the ensemble with the longest light curve first, so that its waves do not begin last and finish alone.  The order
+    // is a function of the datasets only, so every rank of a walker-sharded run derives the same one.
+    if (s->target == 0 && s->n_ensembles > 1 && s->n_ensembles <= 16) {
+        int idx[16];
+        std::iota(idx, idx + s->n_ensembles, 0);
+        std::stable_sort(idx, idx + s->n_ensembles, [&](int x, int y) {
+            return s->h->ds[s->ens_ds[(size_t)x]].g.size() > s->h->ds[s->ens_ds[(size_t)y]].g.size();
+        });
+        bool identity = true;
+        for (int e = 0; e < s->n_ensembles; ++e) identity = identity && idx[e] == e;
+        if (!identity)
+            for (int e = 0; e < s->n_ensembles; ++e) g.ens_order |= (uint64_t)idx[e] << (4 * e);
+    }
     return g;
 }
 
@@ -836,6 +851,8 @@ mp_sampler *mp_sampler_create(mp_handle *h, int n_walkers, int n_ensembles, int 
     DeviceScope scope(h->device);
     const size_t nt = (size_t)s->n_total;
     std::vector<int32_t> ds(nt, 0);
+    s->ens_ds.resize((size_t)n_ensembles);
+    for (int e = 0; e < n_ensembles; ++e) s->ens_ds[(size_t)e] = ens_ds_id ? ens_ds_id[e] : 0;
     for (int e = 0; e < n_ensembles; ++e)
         for (int k = 0; k < n_walkers; ++k) ds[(size_t)e * n_walkers + k] = ens_ds_id ? ens_ds_id[e] : 0;
     constexpr size_t kBadRows = MP_BAD_WINDOW;   // device window of failed proposals between two drains (drain_bad)

@@ -148,6 +148,7 @@ struct StretchArgs {
     uint32_t pad;
     uint64_t seed;
     double a;               // stretch scale (emcee default 2)
+    uint64_t ens_order;     // half-step launches: ensemble at position p of the launch = (ens_order >> 4p) & 15; 0 = identity
 };
 
 // Steps per lane of the kernel variant used for a batch of n walkers (tiles are 64*spl steps): see launch_lnprob.

@@ -157,6 +157,12 @@ MP_DEV double u01(uint32_t hi, uint32_t lo) {   // 53-bit uniform in [0, 1)
 // s - slot_lo of g.upd as (proposal[ndim], its lnprob, accepted 0/1) and stretch_apply_kernel commits the rows of all
 // ranks after the all-gather.  The random numbers are keyed by (seed; step, half, walker), so every rank draws what the
 // single-GPU launch would have drawn for the same walker.
+// Half-step launches run the ensembles in the order of StretchArgs::ens_order (mp_capi.cpp: longest light curve first, four
+// bits per position; 0 = the ensembles as they are numbered): the waves that take longest start first, as in order_kernel.
+__device__ __forceinline__ int ens_of_slot(const StretchArgs &g, int e_pos) {
+    return g.ens_order ? (int)((g.ens_order >> (4 * e_pos)) & 15u) : e_pos;
+}
+
 template <int SPL, bool LONG>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPL >= 4 ? 1 : 2, SPL >= 4 ? 1 : 2))) void stretch_kernel(const DevShared sh, const StretchArgs g) {
     __shared__ TileImage<SPL> im;
@@ -167,8 +173,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPL >= 4 ? 1
     wtab_init(sh.wtab);
     time_table_init(sh, tt);
     const int gs = g.slot_lo + (int)blockIdx.x;                    // slot of the active half, all ensembles flattened
-    const int w_ens = gs / g.n_half;                               // which ensemble
-    const int slot = gs - w_ens * g.n_half;                        // which walker of the active half
+    const int w_ens = ens_of_slot(g, gs / g.n_half);               // which ensemble (longest light curve first)
+    const int slot = gs % g.n_half;                                // which walker of the active half
     const int32_t *perm = g.perm + (size_t)w_ens * g.n_walkers;    // this step's random split of the ensemble
     const int base = w_ens * g.n_walkers;
     const int k = base + perm[g.half * g.n_half + slot];           // active walker (global index)
@@ -248,7 +254,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPL >= 4 ? 1
 __global__ __launch_bounds__(256) void stretch_apply_kernel(const StretchArgs g) {
     const int gs = blockIdx.x * 256 + threadIdx.x;
     if (gs >= g.n_half * g.n_ensembles) return;
-    const int w_ens = gs / g.n_half, slot = gs - w_ens * g.n_half;
+    const int w_ens = ens_of_slot(g, gs / g.n_half), slot = gs % g.n_half;
     const int k = w_ens * g.n_walkers + g.perm[(size_t)w_ens * g.n_walkers + g.half * g.n_half + slot];
     const double *u = g.upd + (size_t)gs * (g.ndim + 3);
     const bool accept = u[g.ndim + 1] != 0.0;
