@@ -244,38 +244,8 @@ MP_DEV int walker_setup(const DevShared &sh, const LaunchArgs &a, double (&par)[
 // indicator, scaled to a step of a whole interval (8^5 with the margin of 2 = 65 536) and held to a tenth like the tile behind
 // the sub-steps, stays below the bound everywhere and no kink lies in it.  (Simply halving the sub-stepped stretch put one
 // golden point -- a spin-up transient at t = 1 s -- at 1.01 of the tight bound in the serial restatement: tests/test_oracle.py.)
-#ifndef MP_PRE_EARLY_END
-#define MP_PRE_EARLY_END 1
-#endif
-#ifndef MP_ABORT_KINK
-#define MP_ABORT_KINK 1
-#endif
-#ifndef MP_HOLD_RELEASE
-#define MP_HOLD_RELEASE 1
-#endif
-#ifndef MP_REALIGN
-#define MP_REALIGN 1
-#endif
 #ifndef MP_PRE_EARLY_END_FACTOR
 #define MP_PRE_EARLY_END_FACTOR 6553600.0
-#endif
-#ifndef MP_LOGPRED_AFTER_SUBSTEPS
-#define MP_LOGPRED_AFTER_SUBSTEPS 0   // 1: the coarse tile right behind the sub-stepped start uses the log-space guess in every kernel
-#endif
-#ifndef MP_CUT_NO_HOLD_SPL4
-#define MP_CUT_NO_HOLD_SPL4 0
-#endif
-#ifndef MP_CUT_NO_HOLD_SPL2
-#define MP_CUT_NO_HOLD_SPL2 1
-#endif
-#ifndef MP_DOUBLE_PROMOTION_SPL4
-#define MP_DOUBLE_PROMOTION_SPL4 0
-#endif
-#ifndef MP_DOUBLE_PROMOTION_SPL2
-#define MP_DOUBLE_PROMOTION_SPL2 0
-#endif
-#ifndef MP_LOGPRED_MIN_KIND_SPL2
-#define MP_LOGPRED_MIN_KIND_SPL2 5
 #endif
 constexpr int kMaxSweepsMargin = 16;  // sweeps allowed beyond the tile length (after which every step is exact)
 // A tile whose iterates keep crossing the break-up limit (rotation parameter 0.27: the accretion torque switches off,
@@ -525,7 +495,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
         // ---- tile control (wave-uniform).  Positions in eighths of a grid interval: the first pre_fine intervals are
         // covered with 1/8-interval sub-steps (kind 0), the rest with steps of 1, 2, 4 or 8 intervals (kinds 1 .. 4).
         // (sub-stepped start: 32 grid intervals = one tile of 256 sub-steps, two of 128 in the 2-steps-per-lane kernels -- which
-        // end it after the first when that tile was calm, see MP_PRE_EARLY_END below)
+        // end it after the first when that tile was calm, see MP_PRE_EARLY_END_FACTOR below)
         const int max_kind = sh.max_kind;
         const int end8 = 8 * nsteps;
         int pre_end8 = 8 * sh.pre_fine;
@@ -560,7 +530,6 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
             if (!pre) while (kind > 1 && ((left8 & (d8 - 1)) != 0 || left8 < 3 * d8)) { --kind; d8 >>= 1; }
             const int sh8 = pre ? 0 : kind + 2;                             // d8 = 1 << sh8
             int nc = min(kTile, left8 >> sh8);                              // steps of this tile that exist
-#if MP_REALIGN
             // What is left after a tile must be a whole number of the NEXT tile's steps.  A cut tile can leave a remainder that is
             // not a multiple of 8 grid intervals (kept lanes x steps per lane x stride), and full tiles of a finer stride
             // preserve it: until round 4 a walker so placed ran at 4 intervals to the end of the grid (burnt-in Classic walkers
@@ -572,7 +541,6 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 const int m = ((D - (after & (D - 1))) & (D - 1)) >> sh8;   // steps to leave for the next tile
                 if (nc - m >= 3) nc -= m;
             }
-#endif
             const StrideK &K = sh.sk[kind];
             const int wbase = kind * kWtabStride;                           // this kind's quadrature matrices in the LDS table
             ++tiles_total;
@@ -684,11 +652,10 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 // interpolated inside the record's steps (a finer successor) carry the interpolant's ~1e-11 ripple, which
                 // the higher differences would amplify by the cube / fourth power of the tile length: quadratic then.
                 // (compile-time: the 2-steps-per-lane kernels, two waves per SIMD on 256 registers each, do not carry this code)
-                constexpr int kLogPredMinKind = kSPL >= 4 ? MP_LOGPRED_MIN_KIND : MP_LOGPRED_MIN_KIND_SPL2;
-                constexpr bool kLogPredEver = kLogPredMinKind <= 4 || MP_LOGPRED_AFTER_SUBSTEPS != 0;
+                constexpr bool kLogPredEver = kSPL >= 4;
                 bool guessed = false;
                 if constexpr (kLogPredEver) {
-                if (!startup && (kind >= kLogPredMinKind || (MP_LOGPRED_AFTER_SUBSTEPS && kind >= 2 && rec_kind == 0))) {
+                if (!startup && kind >= MP_LOGPRED_MIN_KIND) {
                     guessed = true;
                     // Coarse tiles (round 4): a tile over 8 grid intervals spans 1.2 decades of time, over which omega follows
                     // power laws, not polynomials: the quartic in the index was off by 15 % (median) to a factor of 6 (one tile in
@@ -956,7 +923,6 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 // prior-wide walkers (tools/abort_study.py, profiles/r04_abort_study.log): with an excess >= 32 the next finer
                 // stride kept nothing either in 50 % (from 8 intervals) / 95 % (from 4) of the cases and a dozen lanes otherwise.
                 int drop = abort_skip ? 2 : 1;
-#if MP_ABORT_KINK
                 // ... or single intervals at once when the first lanes sit on a kink of the right-hand side (it makes the
                 // indicator hot at every coarse stride, and a coarse tile would only be kept up to it: near the Classic and
                 // Sloped truths the 128-step kernels spent a tile over 4 intervals on a dozen lanes there)
@@ -966,7 +932,6 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                     for (int s = 0; s < kSPL; ++s) brk = brk || (lane * kSPL + s < nc && branch_flags(w, d1.rmu[s], wg[s]) != flags_s);
                     if ((__ballot(brk) & ((1ull << kMinKeepLanes) - 1ull)) != 0ull) drop = 4;
                 }
-#endif
                 opt_kind = max(2, kind - (drop > 2 ? 1 : drop));
                 kind = kind - drop >= 2 ? kind - drop : 1;
                 continue;
@@ -1023,7 +988,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                     ind64 = ind64 || 64.0 * d4 > lim;
                     ind2048 = ind2048 || 2048.0 * d4 > lim;
                     ind65536 = ind65536 || 65536.0 * d4 > lim;
-                    if constexpr (kSPL < 4 && MP_PRE_EARLY_END != 0) indpre = indpre || MP_PRE_EARLY_END_FACTOR * d4 > lim;
+                    if constexpr (kSPL < 4) indpre = indpre || MP_PRE_EARLY_END_FACTOR * d4 > lim;
                     indp8 = indp8 || prom8 * d4 > lim;
 #if MP_CUT_BY_RATIO > 0
                     ind16x = ind16x || d4 > 16.0 * lim;
@@ -1066,7 +1031,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                             const unsigned long long X16 = __ballot(ind16x), X512 = __ballot(ind512x);
                             if ((B & win) == 0ull) {
                                 next_kind = (X16 & win) == 0ull ? kind - 1 : ((X512 & win) == 0ull ? max(kind - 2, 1) : 1);
-                                by_ratio = (kSPL >= 4 ? MP_CUT_NO_HOLD_SPL4 : MP_CUT_NO_HOLD_SPL2) != 0;
+                                by_ratio = kSPL < 4;
                             }
                         }
 #endif
@@ -1077,13 +1042,9 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                         // (256-step tiles: the hold ends early when the held tile shows that the slow zone is behind -- sweeps converged
                         // in three passes, indicator with room for four times the step: burnt-in ensembles 0.107 -> 0.103 ms; with
                         // 128-step tiles it cost the sampler 1 %: profiles/r04_ab_hold_release.log)
-                        if (kSPL >= 4 && MP_HOLD_RELEASE && hold > 0 && kind == hold_kind && sweep <= 3 && I2048 == 0ull) hold = 0;
+                        if (kSPL >= 4 && hold > 0 && kind == hold_kind && sweep <= 3 && I2048 == 0ull) hold = 0;
                         if (hold > 0 && kind == hold_kind) --hold;
                         else next_kind = (kind == 3 ? Ip8 : I64) == 0ull ? kind + 1 : kind;
-                        // a calm tile over 2 intervals whose indicator leaves room for 4 x the step (4^5 = 1 024, margin 2, and the
-                        // tenth that steps over 8 intervals are held to: 65 536 covers 20 480) may go to 8 at once
-                        if ((kSPL >= 4 ? MP_DOUBLE_PROMOTION_SPL4 : MP_DOUBLE_PROMOTION_SPL2) && kind == 2 && next_kind == 3 && max_kind >= 4 &&
-                            I65536 == 0ull) next_kind = 4;
                         opt_kind = max(opt_kind, min(next_kind, max_kind));
                     }
                 } else if (unconv != 0ull) {                                    // kinds 0, 1 stopped early: the converged lanes
@@ -1113,7 +1074,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 // of 128 sub-steps (2 steps per lane) covers 16 grid intervals, not the 24 a step over 8 asks for.  (Until round 4
                 // that attempt was made, read a default for the third point, failed its indicator test in the first lanes and
                 // was redone over 4 intervals: a tile wasted per walker in every 2-steps-per-lane launch.)
-                if constexpr (kSPL < 4 && MP_PRE_EARLY_END != 0) {
+                if constexpr (kSPL < 4) {
                     if (pre && max_kind > 1 && keep_lanes == 64 && nc == kTile && pos8 + nc < pre_end8 && B == 0ull && __ballot(indpre) == 0ull)
                         pre_end8 = pos8 + nc;                                  // the sub-stepped start ends here
                 }
