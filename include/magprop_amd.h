@@ -122,10 +122,14 @@ typedef struct mp_model_cfg {
 /* The sweeps contract by 1e-2..1e-3 per pass, so a tile whose last correction was <= 1e-7 relative is converged to
  * <= 4.5e-9 relative in lnprob (measured over the golden clouds and the prior-wide scans, tools/tol_scan.py) — 10x below
  * the 6e-8 by which the scheme itself differs from the reference integrated at rtol = atol = 1e-12, and 3000x below the
- * reference's own LSODA noise (1.4e-5).  MP_SWEEP_TOL_STRICT (1e-9: <= 4e-11) is what the tests use when they compare
- * kernel variants with each other and with the serial restatement of the scheme. */
+ * reference's own LSODA noise (1.4e-5).  The sweeps of a tile also end when every lane's correction fell at least tenfold
+ * from the previous sweep and the next one -- estimated linearly from that factor -- would be below MP_STOP_FACTOR (a hundredth) of the
+ * tolerance: the verification pass of a fast-converging tile is not run (round 4; near the truths 4 of a walker's 25
+ * sweeps), and what is left is <= 0.01 x sweep_tol per tile.  MP_SWEEP_TOL_STRICT (1e-11) is what the tests use when they
+ * compare kernel variants with each other and with the serial restatement of the scheme. */
 #define MP_SWEEP_TOL_DEFAULT 1.0e-7
-#define MP_SWEEP_TOL_STRICT 1.0e-9
+#define MP_SWEEP_TOL_STRICT 1.0e-11
+#define MP_STOP_FACTOR 0.01
 
 typedef struct mp_handle mp_handle;
 
@@ -321,7 +325,7 @@ enum {
     MP_POLICY_COARSE_MAX_SWEEPS,     /* sweeps after which a coarse tile keeps its converged lanes             */
     MP_POLICY_FINE_MAX_SWEEPS,       /* the same for tiles over single intervals                               */
     MP_POLICY_TROUBLE_LIMIT,         /* failed coarse attempts after which stride 8 is no longer tried         */
-    MP_POLICY_ULTRA_TOL,             /* correction below which a sweep linearises omega_dot                    */
+    MP_POLICY_STOP_FACTOR,           /* MP_STOP_FACTOR: estimated next correction / sweep_tol that ends a tile  */
     MP_POLICY_FORCED_STEPS_PER_LANE, /* 0 = by batch size                                                      */
     MP_POLICY_EXPERIMENTS,           /* 1: developer build that honours MAGPROP_AMD_* environment overrides    */
     MP_POLICY_COUNT

@@ -365,9 +365,8 @@ mp_handle *mp_create(const mp_model_cfg *cfg, const double *tgrid, int n_grid, i
     s.trouble_limit = 2;
     s.early_hold_t = MP_EARLY_HOLD_SECONDS;                       // oracle/mp_oracle.c MPO_EARLY_HOLD_SECONDS
     s.coarse_tol_factor = 0.1;
-    s.coarse_ultra_factor = s.coarse_tol_factor;
     s.k4_tol_factor = 0.1;
-    s.ultra_tol = std::min(1.0e-5, 100.0 * s.sweep_tol);
+    s.stop_factor = MP_STOP_FACTOR;                               // (mp_eval.hpp: the end of a tile's sweeps)
 #ifdef MP_EXPERIMENTS
     // Developer build only (`make -C magprop_amd/csrc experiments` -> libmagprop_amd_exp.so, selected with MAGPROP_AMD_LIB):
     // environment overrides of the policy constants for A/B runs (tools/).  The shipped library does not read the
@@ -388,11 +387,8 @@ mp_handle *mp_create(const mp_model_cfg *cfg, const double *tgrid, int n_grid, i
         env_i("MAGPROP_AMD_COARSE_MAX_SWEEPS", 2, 64, s.coarse_max_sweeps);
         env_i("MAGPROP_AMD_FINE_MAX_SWEEPS", 2, 272, s.fine_max_sweeps);
         env_d("MAGPROP_AMD_COARSE_TOL_FACTOR", 1.0e-3, 1.0, s.coarse_tol_factor);
-        s.coarse_ultra_factor = s.coarse_tol_factor;
-        env_d("MAGPROP_AMD_COARSE_ULTRA_FACTOR", 0.0, 1.0, s.coarse_ultra_factor);
         env_d("MAGPROP_AMD_K4_TOL_FACTOR", 1.0e-3, 1.0, s.k4_tol_factor);
-        s.ultra_tol = std::min(1.0e-5, 100.0 * s.sweep_tol);
-        env_d("MAGPROP_AMD_ULTRA_TOL", 0.0, 1.0e-4, s.ultra_tol);
+        env_d("MAGPROP_AMD_STOP_FACTOR", 0.0, 1.0, s.stop_factor);        // (0: every tile runs its verification sweep)
     }
 #endif
     // Constants of the tile kinds: steps over 1/8, 1, 2, 4, 8 grid intervals (mp_device.h StrideK).
@@ -1197,7 +1193,7 @@ int mp_get_policy(const mp_handle *h, double *out, int n) {
     v[MP_POLICY_COARSE_MAX_SWEEPS] = (double)s.coarse_max_sweeps;
     v[MP_POLICY_FINE_MAX_SWEEPS] = (double)s.fine_max_sweeps;
     v[MP_POLICY_TROUBLE_LIMIT] = (double)s.trouble_limit;
-    v[MP_POLICY_ULTRA_TOL] = s.ultra_tol;
+    v[MP_POLICY_STOP_FACTOR] = s.stop_factor;
     v[MP_POLICY_FORCED_STEPS_PER_LANE] = (double)s.force_spl;
 #ifdef MP_EXPERIMENTS
     v[MP_POLICY_EXPERIMENTS] = 1.0;

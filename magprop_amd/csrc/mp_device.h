@@ -78,10 +78,9 @@ struct DevShared {
     // geometric grid t_i = t0 q^i
     double t0, lnq8;      // first grid time; ln(q)/8
     double sweep_tol;     // relative change of the step-end values that ends the Newton sweeps of a tile
-    double ultra_tol;     // corrections below this let the next sweep linearise omega_dot instead of evaluating it
+    double stop_factor;   // the sweeps end when the next correction, estimated from the contraction, is below stop_factor x the tolerance
     double stride_tol;    // smoothness indicator above which a tile at a coarse stride is cut (cfg.stride_tol)
     double coarse_tol_factor;   // sweep tolerance of tiles over 2, 4 or 8 grid intervals, relative to sweep_tol
-    double coarse_ultra_factor; // the same for ultra_tol
     double k4_tol_factor;       // stride_tol of tiles over 8 grid intervals, relative to stride_tol (0.1; oracle/mp_oracle.c)
     int32_t n_simd;       // SIMDs of the device (multiProcessorCount x 4): batch sizes up to this get one wave per SIMD
     int32_t force_spl;    // experiments: 0 = automatic, else steps per lane (2, 4)

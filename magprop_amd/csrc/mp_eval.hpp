@@ -403,6 +403,9 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
     constexpr int kSPL = SPL, kTile = 64 * SPL, kMaxSweeps = kTile + kMaxSweepsMargin;
     const int lane = threadIdx.x & 63;
     MP_PHASE_DECL
+    // every lane's correction in the previous sweep: the 2-steps-per-lane kernels have no register to spare (LDS); the
+    // 4-steps-per-lane ones have no LDS to spare where they stage light curves (four workgroups of 40 KB per CU)
+    __shared__ float s_dsum_prev[SPL >= 4 ? 1 : 64];
 
     const int n_grid = sh.n_grid;
     const int nsteps = n_grid - 1;
@@ -705,20 +708,19 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
             bool settled = false;    // this lane's guesses moved by < 1e-6 in the previous sweep: close enough to its solution
                                      // for an excursion beyond the break-up limit to be the solution's, not the iteration's
             int sweep = 0, over_sweeps = 0;
+            float dsum_prev = 0.0f;   // this lane's correction in the previous sweep (4-steps-per-lane kernels)
             Ew[3] = om_s;
             // A sweep that follows a small correction (every lane moved by < 1e-4) keeps the Jacobian lambda, e^{h lambda}
             // and the quadrature weights of the previous one and only re-evaluates omega_dot ("light" sweep): the scheme
-            // may linearise about any nearby point, the result moves by ~1e-14, and the verification sweep costs a third less.
-            // A sweep that follows a FULL sweep whose correction was below ultra_tol does not evaluate omega_dot at all:
-            // omega_dot at the new point is its linearisation about the previous one, f + lambda*(omega_new - omega_old),
-            // exact to the second order in that correction.  Such a sweep is the cheap verification pass of a tile whose
-            // first guess was good.
+            // may linearise about any nearby point, the result moves by ~1e-14, and the sweep costs a third less.
+            // (Until round 4 a sweep behind a FULL sweep with a correction below 1e-5 did not evaluate omega_dot at all but
+            // linearised it: the cheap verification pass of a tile whose first guess was good.  Those passes are no longer
+            // run -- see the end of the sweep -- and without that path every kernel is 3 - 4 % faster on top.)
             Vd<kSPL> lam, ez, p5, n0, n1, n2, n3, n4;
             EamW5<kSPL> cw;
-            bool light = false, ultra = false, early_stop = false;
+            bool light = false, early_stop = false;
             // (a step over 2, 4 or 8 grid intervals weighs an error of omega_dot that many times as much: tighter sweeps there)
             const double tol_k = kind >= 2 ? sh.coarse_tol_factor * sh.sweep_tol : sh.sweep_tol;
-            const double ultra_k = kind >= 2 ? sh.coarse_ultra_factor * sh.ultra_tol : sh.ultra_tol;
             // (the tile tried at a coarse stride right behind the sub-steps has no calm predecessor to vouch for it: a tenth;
             // likewise every coarse tile that starts before t = early_hold_t (4 s), and steps over 8 intervals:
             // oracle/mp_oracle.c)
@@ -738,17 +740,10 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 }
                 MP_PHASE(4)
                 Vd<kSPL> rot, f1;
-                const bool full = !light;                 // lambda, e^{h lambda} and the weights are renewed in this sweep
 #ifdef MP_CORR_TRACE
-                const bool f1_lin = ultra;
+                const bool full = !light;                 // lambda, e^{h lambda} and the weights are renewed in this sweep
 #endif
-                if (ultra) {
-#pragma unroll
-                    for (int s = 0; s < kSPL; ++s) {
-                        f1[s] = fma(lam[s], wg[s] - Ew[4 + s], Ef[4 + s]);
-                        rot[s] = sh.crot * (wg[s] * wg[s]);
-                    }
-                } else if (light) {
+                if (light) {
                     Vd<kSPL> unused;
                     f1 = omega_rhs<false>(sh, w, d1, wg, rot, unused);
                 } else {
@@ -826,14 +821,36 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 const double mag = (double)kSPL * fabs(wc);
                 const bool all_settled = dsum <= 1.0e-6 * mag;                       // false for NaN
                 const bool all_small = dsum <= 1.0e-4 * mag;
-                const bool all_tiny = dsum <= ultra_k * mag;
                 const bool all_ok = dsum <= tol_k * mag;
                 settled = all_settled;
                 light = __all(all_small);
-                // (lambda is the derivative at the point this sweep evaluated; the linearisation cannot see the break-up
-                // discontinuity of the accretion torque, so tiles that come near it keep evaluating omega_dot)
-                ultra = full && __all(all_tiny && !near_limit);
                 pending = __ballot(!all_ok);
+#ifdef MP_CORR_TRACE
+                bool est_stop = false;
+#endif
+                // The last sweep of a tile used to be a verification pass: its correction is below the tolerance, it changes
+                // nothing that matters, and near the truths it was 7 of a walker's 25 sweeps.  Where the corrections contract fast
+                // it is not needed to know that: a lane whose correction fell by at least a factor of ten from the previous sweep,
+                // and whose next correction -- no larger than this one times that factor (linear estimate; Newton sweeps
+                // contract faster) -- would be below stop_factor (a hundredth, MP_STOP_FACTOR) of the tolerance, is converged.
+                // The tile ends when that holds on every lane, away from the break-up switch of the accretion torque (lambda is
+                // the derivative at the point this sweep evaluated: no linearisation sees that discontinuity); omega_dot at
+                // the step ends follows the last correction through its linearisation, f + lambda (omega_new - omega_old),
+                // exact to the second order in that correction.
+                if (sweep >= 2 && pending != 0ull) {
+                    const double dp = (double)(kSPL >= 4 ? dsum_prev : s_dsum_prev[lane]), lim_c = sh.stop_factor * tol_k * mag;
+                    const bool pass = dsum <= lim_c || (all_small && dsum <= 0.1 * dp && dsum * dsum <= lim_c * dp);
+                    if (__all(pass && !near_limit)) {
+#pragma unroll
+                        for (int s = 0; s < kSPL; ++s) Ef[4 + s] = fma(lam[s], wg[s] - Ew[4 + s], Ef[4 + s]);
+                        pending = 0ull;
+#ifdef MP_CORR_TRACE
+                        est_stop = true;
+#endif
+                    }
+                }
+                if constexpr (kSPL >= 4) dsum_prev = (float)dsum;
+                else s_dsum_prev[lane] = (float)dsum;
 #ifdef MP_SWEEP_TRACE
                 // developer build (make sweep-trace): how the converged region of a slowly converging tile over single intervals grows,
                 // one word per sweep in the walker's tile-log row: first pending lane | pending lanes << 8 | lanes beyond the break-up limit << 16
@@ -845,14 +862,14 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
 #endif
 #ifdef MP_CORR_TRACE
                 // developer build (make corr-trace, tools/corr_trace.py): one word per sweep of every tile in the walker's tile-log row:
-                // tile | kind << 8 | (0 full, 1 light, 2 linearised) << 11 | pending lanes << 13 | -10 log10(largest relative correction) << 20
+                // tile | kind << 8 | (0 full, 1 light) << 11 | (tile ended on the contraction estimate) << 12 | pending lanes << 13 | -10 log10(largest relative correction) << 20
                 {
                     double rel = dsum / mag;
                     if (!(rel >= 1.0e-25)) rel = rel == rel ? 1.0e-25 : 1.0;
                     for (int d = 32; d >= 1; d >>= 1) rel = fmax(rel, __shfl_xor(rel, d, 64));
                     const int q = min(255, max(0, (int)(-10.0 * log10(rel) + 0.5)));
                     if (a.tile_log && lane == 0 && tr_word < MP_TILE_LOG)
-                        a.tile_log[(size_t)walker * MP_TILE_LOG + tr_word++] = (tiles_total & 0xFF) | (kind << 8) | ((full ? 0 : (f1_lin ? 2 : 1)) << 11) | (__popcll(pending) << 13) | (q << 20);
+                        a.tile_log[(size_t)walker * MP_TILE_LOG + tr_word++] = (tiles_total & 0xFF) | (kind << 8) | ((full ? 0 : 1) << 11) | ((est_stop ? 1 : 0) << 12) | (__popcll(pending) << 13) | (q << 20);
                 }
 #endif
                 // (lanes of a tile that is stopped before all of it has converged are kept only if their own last

@@ -102,7 +102,7 @@ def pytest_collection_modifyitems(config, items):
 
 @pytest.fixture
 def strict():
-    """Newton-sweep tolerance 1e-9 (MP_SWEEP_TOL_STRICT) and max_stride 1 (every grid interval a step) for every handle
+    """Newton-sweep tolerance 1e-11 (MP_SWEEP_TOL_STRICT) and max_stride 1 (every grid interval a step) for every handle
     created inside the test: used where the HIP kernels are compared with the serial C restatement of the fixed-step scheme
     or with each other (1e-10).  Everything that is compared with the reference's golden values runs at the product's
     defaults (adaptive stride, sweep tolerance 1e-7)."""

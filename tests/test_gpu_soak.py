@@ -12,7 +12,7 @@ from conftest import TRUTHS, TYPES
 pytestmark = pytest.mark.gpu
 LOG_MASK = 0b111100
 N_SOAK = int(os.environ.get("MAGPROP_SOAK_N", "32768"))
-STRICT = 1.0e-9   # MP_SWEEP_TOL_STRICT: the kernels against the serial restatement of the scheme
+STRICT = 1.0e-11   # MP_SWEEP_TOL_STRICT: the kernels against the serial restatement of the scheme
 # Two sets of walkers: seed 20261003 is the one every constant of the stride policy was tuned on in round 3 (kept: a
 # regression guard); the second seed was drawn after the round-4 constants were frozen (MAGPROP_SOAK_SEED overrides it, so
 # the points can be changed without touching the file).

@@ -28,7 +28,7 @@ def words(i):
 def show(i):
     tiles = {}
     for w in words(i):
-        tiles.setdefault(w & 0xFF, []).append(("P1248"[(w >> 8) & 7], "FLU"[(w >> 11) & 3], (w >> 13) & 0x7F, -0.1 * ((w >> 20) & 0xFF)))
+        tiles.setdefault(w & 0xFF, []).append(("P1248"[(w >> 8) & 7], ("F", "L", "f", "l")[(w >> 11) & 3], (w >> 13) & 0x7F, -0.1 * ((w >> 20) & 0xFF)))
     return " | ".join(f"{v[0][0]}: " + " ".join(f"{m}{q:.1f}/{p}" for _, m, p, q in v) for _, v in sorted(tiles.items()))
 
 
@@ -39,7 +39,7 @@ for name, X in (("near truth", near), ("prior-wide", wide)):
     order = np.argsort(sw)[::-1]
     for i in ([0, 1] if name == "near truth" else list(order[:4]) + list(order[n // 2:n // 2 + 2])):
         print(f"walker {i} status {st[i]} sweeps {sw[i]}: {show(i)}")
-    modes = np.zeros(3)
+    modes = np.zeros(4)
     first_corr, second_corr = {}, {}
     for i in range(min(n, 512)):
         if st[i] != 0:
@@ -53,7 +53,8 @@ for name, X in (("near truth", near), ("prior-wide", wide)):
             first_corr.setdefault(k, []).append(-0.1 * ((v[0] >> 20) & 0xFF))
             if len(v) > 1:
                 second_corr.setdefault(k, []).append(-0.1 * ((v[1] >> 20) & 0xFF))
-    print("   sweeps by mode: full %d, light %d, linearised %d" % tuple(modes))
+    print("   sweeps by mode: full %d, light %d; of these the last of a tile that ended on the contraction estimate "
+          "(lower case above): full %d, light %d" % (modes[0] + modes[2], modes[1] + modes[3], modes[2], modes[3]))
     for k in "P1248":
         if k in first_corr:
             a, b = np.array(first_corr[k]), np.array(second_corr.get(k, [0.0]))
