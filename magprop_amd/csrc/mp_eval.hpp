@@ -244,6 +244,13 @@ MP_DEV int walker_setup(const DevShared &sh, const LaunchArgs &a, double (&par)[
 // indicator, scaled to a step of a whole interval (8^5 with the margin of 2 = 65 536) and held to a tenth like the tile behind
 // the sub-steps, stays below the bound everywhere and no kink lies in it.  (Simply halving the sub-stepped stretch put one
 // golden point -- a spin-up transient at t = 1 s -- at 1.01 of the tight bound in the serial restatement: tests/test_oracle.py.)
+// Corrections below this (relative) let the next sweep keep the Jacobian, e^{h lambda} and the weights ("light" sweep).  1e-4
+// until the tiles ended on the contraction estimate; scanned then on one box (profiles/r04_ab_light_tol.log): 3e-4 / 1e-3 / 3e-3 /
+// 1e-2 speed up the passes near the truths by 0.7 / 1.3 / 1.3 / 2 %, and from 3e-3 on the slowest prior-wide walkers need
+// more sweeps (chord iterations stall where the Jacobian changes from step to step): 0.228 -> 0.220 -> 0.239 ms.
+#ifndef MP_LIGHT_TOL
+#define MP_LIGHT_TOL 1.0e-3
+#endif
 #ifndef MP_PRE_EARLY_END_FACTOR
 #define MP_PRE_EARLY_END_FACTOR 6553600.0
 #endif
@@ -710,7 +717,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
             int sweep = 0, over_sweeps = 0;
             float dsum_prev = 0.0f;   // this lane's correction in the previous sweep (4-steps-per-lane kernels)
             Ew[3] = om_s;
-            // A sweep that follows a small correction (every lane moved by < 1e-4) keeps the Jacobian lambda, e^{h lambda}
+            // A sweep that follows a small correction (every lane moved by < MP_LIGHT_TOL) keeps the Jacobian lambda, e^{h lambda}
             // and the quadrature weights of the previous one and only re-evaluates omega_dot ("light" sweep): the scheme
             // may linearise about any nearby point, the result moves by ~1e-14, and the sweep costs a third less.
             // (Until round 4 a sweep behind a FULL sweep with a correction below 1e-5 did not evaluate omega_dot at all but
@@ -728,7 +735,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
             bool abort_tile = false, abort_skip = false;
             while (true) {
                 ++sweep;
-                if (!light) {   // (after a sweep that moved every lane by < 1e-4 the guesses are positive and finite)
+                if (!light) {   // (after a sweep that moved every lane by < MP_LIGHT_TOL the guesses are positive and finite)
                     bool wild = false;
 #pragma unroll
                     for (int s = 0; s < kSPL; ++s) wild = wild || !(wg[s] > 0.0);
@@ -820,7 +827,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 MP_PHASE(16)
                 const double mag = (double)kSPL * fabs(wc);
                 const bool all_settled = dsum <= 1.0e-6 * mag;                       // false for NaN
-                const bool all_small = dsum <= 1.0e-4 * mag;
+                const bool all_small = dsum <= MP_LIGHT_TOL * mag;
                 const bool all_ok = dsum <= tol_k * mag;
                 settled = all_settled;
                 light = __all(all_small);

@@ -117,19 +117,19 @@ def test_tiles_per_walker_near_the_truths(gsynth):
     """Guard of the stride policy's economy (round 4): walkers in the reference driver's 1e-4 ball around
     the truths cross the 10 000 grid intervals in 8 tiles of 256 steps (one wave per SIMD; 9 until the stride after a fast
     feature came from its excess) and in at most 17 tiles of 128 steps (two waves per SIMD; 18.2 while the tile behind the
-    sub-steps was tried over 8 intervals without the history for it), with fewer than 3.3 / 2.7 Newton sweeps per tile; the
-    values stay inside the cross-variant tolerance."""
+    sub-steps was tried over 8 intervals without the history for it), with fewer than 2.8 / 2.5 Newton sweeps per tile (3.1 /
+    2.6 while every tile ended with a verification sweep); the values stay inside the cross-variant tolerance."""
     from magprop_amd import LogProb
     rng = np.random.default_rng(31)
-    for grb, max4, max2 in (("Humped", 8.05, 17.0), ("Classic", 9.05, 17.0)):
+    for grb, max4, max2 in (("Humped", 8.05, 16.0), ("Classic", 8.05, 15.0)):
         lp = LogProb(gsynth[grb + "_x"], gsynth[grb + "_y"], gsynth[grb + "_yerr"])
         P = np.array(TRUTHS[grb]) + 1.0e-4 * rng.standard_normal((2048, 6))
         o4 = lp(P[:1024])
         t4, s4 = lp.handle.last_mean_tiles, lp.handle.last_mean_sweeps
         o2 = lp(P)
         t2, s2 = lp.handle.last_mean_tiles, lp.handle.last_mean_sweeps
-        assert t4 <= max4 and s4 <= 3.3, (grb, t4, s4)
-        assert t2 <= max2 and s2 <= 2.7, (grb, t2, s2)
+        assert t4 <= max4 and s4 <= 2.8, (grb, t4, s4)
+        assert t2 <= max2 and s2 <= 2.5, (grb, t2, s2)
         assert np.allclose(o2[:1024], o4, rtol=CROSS_VARIANT_RTOL, atol=1e-9)
         lp.handle.close()
 

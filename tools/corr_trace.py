@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Developer diagnostic (GPU box): the Newton sweeps of every tile of a few walkers, sweep by sweep.
     make -C magprop_amd/csrc corr-trace && MAGPROP_AMD_LIB=$PWD/magprop_amd/libmagprop_amd_corr.so python tools/corr_trace.py [n]
-Per sweep: F (full: omega_dot, Jacobian, phi functions, weights), L (light: omega_dot only) or U (linearised omega_dot),
-log10 of the largest relative correction over the wavefront, lanes still pending.  Then, over a near-truth and a prior-wide
-batch, the histogram of sweeps per tile by kind and how many of a tile's sweeps were F / L / U."""
+Per sweep: F (full: omega_dot, Jacobian, phi functions, weights) or L (light: omega_dot only), in lower case when the tile
+ended with it on the contraction estimate (no verification pass); log10 of the largest relative correction over the
+wavefront, lanes still pending.  Then, over a near-truth and a prior-wide batch, the first two corrections per tile kind."""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
