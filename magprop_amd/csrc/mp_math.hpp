@@ -354,12 +354,36 @@ struct Phi5 {
     Vd<N> e, p1, p2, p3, p4, p5;
 };
 
+#ifndef MP_PHI_ALL_BIG
+#define MP_PHI_ALL_BIG 1
+#endif
 template <int N>
 MP_DEV Phi5<N> phi12345(const Vd<N> &z) {
     Vd<N> s;
     const double zmax = lane_maxabs(z.v);          // the lane's largest |z|: one comparison per range instead of one per step
     const bool all_tiny = zmax < 0.03125;
     double inv6 = 1.0 / 6.0, inv24 = 1.0 / 24.0;
+#if MP_PHI_ALL_BIG
+    // Every step of the wave in the stiff range (|z| >= 1/2: the tiles over 8 grid intervals from t ~ 20 s on): the recurrence
+    // from e^z alone, without the series and the selects (the same arithmetic as the mixed path below, bit for bit).
+    // (the 2-steps-per-lane kernels, two waves per SIMD, lose 4 % with this third path: absent there at compile time)
+    if constexpr (N >= 4) if (__all(lane_minabs(z.v) >= 0.5)) {          // (false for a NaN among the z)
+        if constexpr (kUseKtab<N>) { const d2v c = ktab2(12); inv24 = c.x; inv6 = c.y; }
+        Phi5<N> r;
+        Vd<N> zc;
+        FORN zc[i] = fmax(z[i], -750.0);
+        r.e = exp_fast(zc);
+        const Vd<N> rz = rcp_fast(z);
+        FORN {
+            r.p1[i] = (r.e[i] - 1.0) * rz[i];
+            r.p2[i] = (r.p1[i] - 1.0) * rz[i];
+            r.p3[i] = (r.p2[i] - 0.5) * rz[i];
+            r.p4[i] = (r.p3[i] - inv6) * rz[i];
+            r.p5[i] = (r.p4[i] - inv24) * rz[i];
+        }
+        return r;
+    }
+#endif
     if constexpr (kUseKtab<N>) {
         if (__all(all_tiny)) {
             const d2v c4 = ktab2(4), c6 = ktab2(6), c8 = ktab2(8), c10 = ktab2(10), c12 = ktab2(12);
