@@ -357,6 +357,9 @@ struct Phi5 {
 #ifndef MP_PHI_ALL_BIG
 #define MP_PHI_ALL_BIG 1
 #endif
+#ifndef MP_PHI_SKIP_SERIES
+#define MP_PHI_SKIP_SERIES 1
+#endif
 template <int N>
 MP_DEV Phi5<N> phi12345(const Vd<N> &z) {
     Vd<N> s;
@@ -394,6 +397,13 @@ MP_DEV Phi5<N> phi12345(const Vd<N> &z) {
             FORN s[i] = fma3(s[i], z[i], c10.x);      // 1/6!
             FORN s[i] = fma3(s[i], z[i], c10.y);      // 1/5!
             inv24 = c12.x; inv6 = c12.y;
+#if MP_PHI_SKIP_SERIES
+        } else if (__all(lane_minabs(z.v) >= 0.5)) {
+            // every step of the wave in the stiff range: the series' values would all be replaced below
+            const d2v c12 = ktab2(12);
+            inv24 = c12.x; inv6 = c12.y;
+            FORN s[i] = 0.0;
+#endif
         } else {
             {
                 const d2v a = ktab2(18), b = ktab2(0);
