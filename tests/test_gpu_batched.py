@@ -172,7 +172,8 @@ def test_config5_four_types_mixed_lengths_one_launch(gsynth, glonglc, tarr, co):
     sets = _config5_sets(gsynth, glonglc, tarr)
     assert sorted(len(s[0]) for s in sets) == [8, 50, 50, 50, 50, 63, 64, 65, 112, 410, 1944]
     lp_ = LogProb(*sets[0])                                    # product default: against the reference's values
-    lps = LogProb(*sets[0], sweep_tol=1.0e-9, max_stride=1)    # strict, every grid interval a step: against the serial restatement
+    from magprop_amd import _capi as _c
+    lps = LogProb(*sets[0], sweep_tol=_c.SWEEP_TOL_STRICT, max_stride=1)   # strict, every grid interval a step: against the serial restatement
     for s in sets[1:]:
         lp_.add_dataset(*s)
         lps.add_dataset(*s)

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 GPU_VS_C_RTOL = 1e-10   # HIP kernel (strict sweep tolerance) vs serial C oracle: same scheme, different evaluation order / algebra
 DEFAULT_VS_STRICT_RTOL = 1e-7   # lnprob at the product defaults (sweep tolerance 1e-7, steps over 1/2/4/8 grid intervals) vs strict
-                                # (1e-9, every grid interval a step); observed <= 5e-8 (soak: tests/test_gpu_soak.py)
+                                # (MP_SWEEP_TOL_STRICT = 1e-11, every grid interval a step); observed <= 5e-8 (soak: tests/test_gpu_soak.py)
 CROSS_VARIANT_RTOL = 1e-7       # kernel variants (tile lengths: the adaptive tiles fall differently) against each other
 
 
