@@ -26,6 +26,23 @@ def test_library_exports_every_declared_symbol():
     assert L.mp_abi_version() == _capi.ABI_VERSION == 4
 
 
+def test_python_mirror_follows_the_header_constants():
+    """The constants and the order of mp_get_policy()'s vector in magprop_amd/_capi.py are those of include/magprop_amd.h."""
+    hdr = open(os.path.join(ROOT, "include", "magprop_amd.h")).read()
+
+    def define(name):
+        return float(re.search(r"#define\s+%s\s+([0-9.eE+-]+)" % name, hdr).group(1))
+
+    assert define("MP_SWEEP_TOL_DEFAULT") == _capi.SWEEP_TOL_DEFAULT == 1.0e-7
+    assert define("MP_SWEEP_TOL_STRICT") == _capi.SWEEP_TOL_STRICT == 1.0e-11
+    assert define("MP_STOP_FACTOR") == 0.01
+    body = re.search(r"enum\s*\{\s*MP_POLICY_MAX_STRIDE.*?MP_POLICY_COUNT", hdr, flags=re.S).group(0)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = re.findall(r"MP_POLICY_([A-Z0-9_]+)", body)[:-1]
+    alias = {"FORCED_STEPS_PER_LANE": "forced_steps_per_lane", "EXPERIMENTS": "experiments_build"}
+    assert [alias.get(n, n.lower()) for n in names] == list(_capi.POLICY_FIELDS)
+
+
 def test_cfg_struct_layout_and_presets():
     assert ctypes.sizeof(_capi.ModelCfg) == 11 * 8 + 2 * 4 + 2 * 8
     c0 = _capi.cfg_synth()
