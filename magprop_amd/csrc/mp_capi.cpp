@@ -353,6 +353,7 @@ mp_handle *mp_create(const mp_model_cfg *cfg, const double *tgrid, int n_grid, i
     }
     s.n_simd = std::max(1, prop.multiProcessorCount) * 4;         // 4 SIMDs per CU (1 024 on MI355X)
     s.force_spl = 0;
+    s.force_waves = 0;
     // The constants of the stride policy (oracle/mp_oracle.c carries the same ones).  They are not
     // settings: the shipped library takes them from here only, mp_get_policy() reports them.
     s.coarse_max_sweeps = 5;
@@ -380,6 +381,7 @@ mp_handle *mp_create(const mp_model_cfg *cfg, const double *tgrid, int n_grid, i
             if (v == 1 || v == 2 || v == 4 || v == 8) s.max_kind = v == 1 ? 1 : (v == 2 ? 2 : (v == 4 ? 3 : 4));
         }
         if (const char *e = std::getenv("MAGPROP_AMD_SPL")) { const int v = std::atoi(e); if (v == 2 || v == 4) s.force_spl = v; }
+        if (const char *e = std::getenv("MAGPROP_AMD_WAVES")) { const int v = std::atoi(e); if (v == 1 || v == 2 || v == 4) s.force_waves = v; }
         env_d("MAGPROP_AMD_SWEEP_TOL", 1.0e-14, 1.0e-3, s.sweep_tol);       // (the cfg validation range)
         env_d("MAGPROP_AMD_STRIDE_TOL", 1.0e-14, 1.0e-3, s.stride_tol);
         env_d("MAGPROP_AMD_EARLY_HOLD_SECONDS", 0.0, 1.0e6, s.early_hold_t);

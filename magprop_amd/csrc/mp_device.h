@@ -83,7 +83,9 @@ struct DevShared {
     double coarse_tol_factor;   // sweep tolerance of tiles over 2, 4 or 8 grid intervals, relative to sweep_tol
     double k4_tol_factor;       // stride_tol of tiles over 8 grid intervals, relative to stride_tol (0.1; oracle/mp_oracle.c)
     int32_t n_simd;       // SIMDs of the device (multiProcessorCount x 4): batch sizes up to this get one wave per SIMD
-    int32_t force_spl;    // experiments: 0 = automatic, else steps per lane (2, 4)
+    int32_t force_spl;    // experiments: 0 = automatic, else steps per lane (2, 4) of the one-wavefront kernels
+    int32_t force_waves;  // experiments: 0 = automatic, else wavefronts per walker (1, 2, 4)
+    int32_t pad1;
     int32_t max_kind;     // coarsest tile kind allowed: 1, 2, 3, 4 for cfg.max_stride 1, 2, 4, 8
     int32_t coarse_max_sweeps, fine_max_sweeps, trouble_limit;   // sweeps after which a slowly converging tile keeps its converged lanes
     double early_hold_t;  // coarse tiles that start before this TIME (MP_EARLY_HOLD_SECONDS = 4 s: where the spin-up transients
@@ -153,6 +155,17 @@ struct StretchArgs {
 // Steps per lane of the kernel variant used for a batch of n walkers (tiles are 64*spl steps): see launch_lnprob.
 // Up to one wave per SIMD (256 CUs x 4 on MI355X) four steps per lane; beyond, two resident waves win (tools/spl_scan.sh).
 inline int kernel_spl(const DevShared &sh, int n) { return n <= sh.n_simd ? 4 : 2; }
+// Wavefronts per walker: launches that would leave SIMDs idle (n <= n_simd / 2) put a team of 4 wavefronts on every walker
+// (mp_eval.hpp TeamX; mode A, light curves of up to 64 points); see launch_lnprob.  (force_waves = 2: the two-wavefront
+// team, experiments build only.)
+inline int kernel_waves(const DevShared &sh, int n) {
+    if (sh.has_long) return 1;
+#ifdef MP_EXPERIMENTS
+    if (sh.force_waves) return sh.force_waves;
+#endif
+    if (sh.force_spl) return 1;
+    return 2 * n <= sh.n_simd ? 4 : 1;
+}
 
 // Arguments of the batched right-hand-side evaluation (mp_kernels.hip: rhs_kernel), device pointers.
 struct RhsArgs {

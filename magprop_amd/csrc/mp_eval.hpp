@@ -318,6 +318,80 @@ MP_DEV void time_table_init(const DevShared &sh, TimeTable<SPL> &tt) {   // ever
     }
     __syncthreads();
 }
+// All three LDS tables of a kernel (polynomial coefficients, constants of the tile kinds, Q^k) in ONE round trip to global
+// memory: every load is issued before the first store waits for its data, one barrier at the end (the three separate copies
+// cost a walker three global-memory latencies in a row at kernel entry).  NT = threads of the workgroup.
+template <int G, int NT>
+MP_DEV void tables_init(const DevShared &sh, TimeTable<G> &tt) {
+    constexpr int kN = TimeTable<G>::kN, nT = (kKinds - 1) * kN, cW = (kWtabSize + NT - 1) / NT, cT = (nT + NT - 1) / NT;
+    const int tid = threadIdx.x;
+    double vw[cW], vt[cT];
+    const double vk = kKtabInit[tid < kKtabN ? tid : 0];
+#pragma unroll
+    for (int c = 0; c < cW; ++c) { const int i = tid + c * NT; vw[c] = sh.wtab[i < kWtabSize ? i : 0]; }
+#pragma unroll
+    for (int c = 0; c < cT; ++c) {
+        const int i = tid + c * NT, ii = i < nT ? i : 0, kind = ii / kN, k = ii - kind * kN;
+        vt[c] = sh.ttab[kind * kTtabN + k];
+    }
+    if (tid < kKtabN) g_ktab[tid] = vk;
+#pragma unroll
+    for (int c = 0; c < cW; ++c) { const int i = tid + c * NT; if (i < kWtabSize) g_wtab[i] = vw[c]; }
+#pragma unroll
+    for (int c = 0; c < cT; ++c) {
+        const int i = tid + c * NT, kind = i / kN, k = i - kind * kN;
+        if (i < nT) tt.E[kind][k] = vt[c];
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------- a walker on W wavefronts (team kernels)
+// Launches that leave SIMDs idle (n <= n_simd / 2 walkers: what emcee hands over per half-step at the headline
+// configuration) run one walker on a WORKGROUP of W = 2 or 4 wavefronts, each on a SIMD of its own.  The tile stays the
+// 256-step tile of the 4-steps-per-lane kernel and so does its policy: lane g of EVERY wavefront belongs to the group of
+// steps 4 g .. 4 g + 3, of which wavefront v owns steps 4 g + v SPL + s, s = 0 .. SPL - 1 (SPL W = 4).  Everything that is a
+// function of a group -- the composed step maps and their scan, the convergence tests, the ballots of the stride policy -- is
+// formed redundantly and identically in every wavefront from values exchanged through LDS, so the wavefronts take every
+// tile-level decision alike without asking each other; what costs instructions -- the right-hand side, the phi
+// functions, the quadrature -- is evaluated for the own steps only.  Per Newton sweep two exchanges (write, s_barrier, read):
+// (omega_dot, omega) at the own step ends, whose neighbours are the history nodes of the others' steps, and the own step maps
+// with their smoothness indicators; per tile one more for the Mdisc maps and one for the per-step flags of the acceptance.
+// Layout: [j][lane] with j the step's place in its lane's group -- every access of a wavefront is lane-contiguous (the natural
+// [4 lane + j] order puts the lanes 32 bytes apart: a 4-way bank conflict on every exchange, measured as 61 % of the LDS
+// unit's busy cycles and ~2 000 cycles per sweep with the four wavefronts of a CU queueing behind each other).
+template <int G>
+struct TeamX {
+    double F[G][66];     // omega_dot at the step ends: [j][1 + g] = end of step G g + j; [j][0] = the point G - j steps before the
+                         // tile's first step end ([G - 1][0] the tile's start, [G - 2][0] ... the history in front of it)
+    double Wv[G][66];    // omega, same layout
+    double A[G][64], B[G][64];   // step maps x -> A x + B (Mdisc phase, then every sweep)
+    double D4[G][64];    // smoothness indicators of the steps
+    unsigned flags[4][64];
+};
+// entry v SPL + s of a group array: the value of this wavefront's own step s (v is wave-uniform)
+template <int SPL, int W>
+MP_DEV double own_of(const double (&g)[SPL * W], int wave, int s) {
+    double v = g[s];
+#pragma unroll
+    for (int k = 1; k < W; ++k) {
+        v = wave == k ? g[k * SPL + s] : v;
+        asm("" : "+v"(v));   // (keeps the chain of selects: the optimiser otherwise turns it into g[wave], a dynamically indexed private array)
+    }
+    return v;
+}
+
+// OR of a per-lane flag word over the wavefronts of the team, lane by lane (one exchange: every wavefront calls this at
+// the same point of the program)
+template <int W, int G>
+MP_DEV unsigned team_or(TeamX<G> *tx, int wave, int lane, unsigned fl) {
+    tx->flags[wave][lane] = fl;
+    __syncthreads();
+    unsigned r = 0u;
+#pragma unroll
+    for (int k = 0; k < W; ++k) r |= tx->flags[k][lane];
+    return r;
+}
+
 // Q^k of kind `kind` (wave-uniform or per-lane k)
 template <int SPL>
 MP_DEV double time_factor(const DevShared &sh, const TimeTable<SPL> &tt, int kind, int k) {
@@ -385,7 +459,7 @@ MP_DEV void image_state(const DevShared &sh, const Walker &w, const TileImage<SP
 #define MP_PHASE_N 18
 #define MP_PHASE_DECL unsigned long long ph_t = __builtin_amdgcn_s_memtime(), ph_acc[MP_PHASE_N] = {0};
 #define MP_PHASE(i) { const unsigned long long ph_n = __builtin_amdgcn_s_memtime(); ph_acc[i] += ph_n - ph_t; ph_t = ph_n; }
-#define MP_PHASE_DUMP if (a.tile_log && lane == 0) { for (int i = 0; i < MP_PHASE_N; ++i) a.tile_log[(size_t)walker * MP_TILE_LOG + i] = (int32_t)min(ph_acc[i], 0x7FFFFFFFull); }
+#define MP_PHASE_DUMP if (a.tile_log && lead) { for (int i = 0; i < MP_PHASE_N; ++i) a.tile_log[(size_t)walker * MP_TILE_LOG + i] = (int32_t)min(ph_acc[i], 0x7FFFFFFFull); }
 #define MP_TILE_LOG_ON false   // (the per-tile words would be overwritten by the dump, and their stores would be waited for inside the timed sections)
 #else
 #define MP_PHASE_DECL
@@ -405,16 +479,24 @@ MP_DEV void image_state(const DevShared &sh, const Walker &w, const TileImage<SP
 // SPL = consecutive steps owned by one lane; a tile is 64*SPL steps.  par[] holds the sampler coordinates
 // (prior checked and log-masked coordinates un-logged here unless a.physical); walker indexes ds_id and the
 // optional curve outputs; im / Lbuf are the wave's LDS areas (Lbuf: [8*64*SPL + 1], staging of the curve outputs).
-template <bool CURVES, int SPL, bool LONG, bool LOG = false>
+// W = wavefronts per walker (team kernels, see TeamX): the workgroup has 64 W threads, a lane's group of steps is SPL W
+// long, im / tt are dimensioned for it and tx is the team's exchange area (nullptr for W = 1).
+// UNI: the walker's constants live in scalar registers (the builds that keep two wavefronts resident per SIMD).
+template <bool CURVES, int SPL, bool LONG, bool LOG = false, int W = 1, bool UNI = (SPL == 2 && W == 1)>
 MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, double (&par)[MP_MAX_NDIM],
-                        TileImage<SPL> &im, const TimeTable<SPL> &tt, double *Lbuf, double &lnp_out, int &status_out,
-                        int &sweeps_out, int &tiles_out) {
-    constexpr int kSPL = SPL, kTile = 64 * SPL, kMaxSweeps = kTile + kMaxSweepsMargin;
+                        TileImage<SPL * W> &im, const TimeTable<SPL * W> &tt, double *Lbuf, double &lnp_out, int &status_out,
+                        int &sweeps_out, int &tiles_out, TeamX<SPL * W> *tx = nullptr) {
+    static_assert(W == 1 || (SPL * W == 4 && !CURVES && !LONG), "team kernels: 256-step tiles, mode A, light curves of <= 64 points");
+    constexpr int kSPL = SPL, kG = SPL * W, kTile = 64 * kG, kMaxSweeps = kTile + kMaxSweepsMargin;
     const int lane = threadIdx.x & 63;
+    const int wave = W > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;   // which wavefront of the walker's team
+    const int j0 = wave * kSPL;              // its first step inside a lane's group of kG steps
+    const int e0 = lane * kG + j0;           // this lane's first own step in the tile
+    const bool lead = W > 1 ? threadIdx.x == 0 : lane == 0;
     MP_PHASE_DECL
     // every lane's correction in the previous sweep: the 2-steps-per-lane kernels have no register to spare (LDS); the
     // 4-steps-per-lane ones have no LDS to spare where they stage light curves (four workgroups of 40 KB per CU)
-    __shared__ float s_dsum_prev[SPL >= 4 ? 1 : 64];
+    __shared__ float s_dsum_prev[kG >= 4 ? 1 : 64];
 
     const int n_grid = sh.n_grid;
     const int nsteps = n_grid - 1;
@@ -422,7 +504,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
 
     Walker w;
     int status = walker_setup(sh, a, par, w);
-    if constexpr (SPL == 2) {
+    if constexpr (UNI) {
         // two waves per SIMD: 256 vector registers per wave.  The walker's constants are wave-uniform; in scalar registers
         // (spilled, if at all, to lanes of a vector register, not to memory) they free 30 vector registers and the kernel
         // no longer reloads spilled values from scratch memory inside the tile loop.
@@ -499,7 +581,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
 #endif
 
     if (status == MP_STATUS_OK) {
-        if (CURVES && lane == 0) {
+        if (CURVES && lead) {
             if (a.ltot) a.ltot[row] = L_s / 1.0e50;
             if (a.lprop) a.lprop[row] = Lp_s / 1.0e50;
             if (a.ldip) a.ldip[row] = Ld_s / 1.0e50;
@@ -562,14 +644,28 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
 
             // ---------------- step end times (the grid is geometric: t_k = t_s Q^k) and step lengths
             Vd<kSPL> h, S1, dS1, iu1;
-            {
+            double Sp_team = 0.0, iup_team = 0.0;   // team kernels: the fallback rate and tfb / (t + tfb) at the start of this lane's first own step
+            if constexpr (W == 1) {
                 Vd<kSPL> tb;
 #pragma unroll
                 for (int s = 0; s < kSPL; ++s) {
-                    tb[s] = t_s * time_factor(sh, tt, kind, min(lane * kSPL + s + 1, nc));
-                    h[s] = (lane * kSPL + s < nc) ? tb[s] * K.one_m_invQ : 0.0;   // 0 for the padding steps of a short tile
+                    tb[s] = t_s * time_factor(sh, tt, kind, min(e0 + s + 1, nc));
+                    h[s] = (e0 + s < nc) ? tb[s] * K.one_m_invQ : 0.0;   // 0 for the padding steps of a short tile
                 }
                 S1 = mdot_fb_d(w, tb, dS1, iu1);
+            } else {
+                // (the start of a lane's first own step is a step end of ANOTHER wavefront: its fallback rate is evaluated here,
+                // next to the own ones -- the same function of the same time, so the same bits -- instead of being exchanged)
+                Vd<kSPL + 1> tb, Sx, dSx, iux;
+#pragma unroll
+                for (int s = 0; s <= kSPL; ++s) tb[s] = t_s * time_factor(sh, tt, kind, min(e0 + s, nc));
+#pragma unroll
+                for (int s = 0; s < kSPL; ++s) h[s] = (e0 + s < nc) ? tb[s + 1] * K.one_m_invQ : 0.0;
+                Sx = mdot_fb_d(w, tb, dSx, iux);
+#pragma unroll
+                for (int s = 0; s < kSPL; ++s) { S1[s] = Sx[s + 1]; dS1[s] = dSx[s + 1]; iu1[s] = iux[s + 1]; }
+                Sp_team = e0 == 0 ? cS0 : Sx[0];
+                iup_team = e0 == 0 ? ciu0 : iux[0];
             }
 
             MP_PHASE(10)
@@ -620,7 +716,9 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
             DiscPt<kSPL> d1;
             {
                 Vd<kSPL> zm, S0, x;
-                const double Sp = lane_prev(S1[kSPL - 1], cS0), iup = lane_prev(iu1[kSPL - 1], ciu0);   // at this lane's first step start
+                double Sp, iup;                                                         // at this lane's first step start
+                if constexpr (W == 1) { Sp = lane_prev(S1[kSPL - 1], cS0); iup = lane_prev(iu1[kSPL - 1], ciu0); }
+                else { Sp = Sp_team; iup = iup_team; }
 #pragma unroll
                 for (int s = 0; s < kSPL; ++s) {
                     zm[s] = -h[s] * w.inv_tau;
@@ -641,19 +739,40 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 }
                 Vd<kSPL> am, bm;
                 double A = 1.0, B = 0.0;                  // composition of this lane's step maps
+                if constexpr (W == 1) {
 #pragma unroll
-                for (int s = 0; s < kSPL; ++s) {
-                    am[s] = pm.e[s];      // padding steps: h = 0 -> e = 1, inc = 0
-                    bm[s] = inc[s];
-                    B = fma(am[s], B, bm[s]);
-                    A = A * am[s];
+                    for (int s = 0; s < kSPL; ++s) {
+                        am[s] = pm.e[s];      // padding steps: h = 0 -> e = 1, inc = 0
+                        bm[s] = inc[s];
+                        B = fma(am[s], B, bm[s]);
+                        A = A * am[s];
+                    }
+                    scan_affine(A, B);
+                    double Ax, Bx;
+                    lane_prev_map(A, B, Ax, Bx);   // exclusive prefix
+                    double Mc = fma(Ax, M_s, Bx);            // Mdisc at this lane's first step start
+#pragma unroll
+                    for (int s = 0; s < kSPL; ++s) { Mc = fma(am[s], Mc, bm[s]); M1[s] = Mc; }
+                } else {
+                    // team: the own step maps go to LDS, every wavefront composes the maps of the lane's whole group in step order
+                    // (the arithmetic of the 4-steps-per-lane kernel), scans, and takes its own steps' values
+#pragma unroll
+                    for (int s = 0; s < kSPL; ++s) { tx->A[j0 + s][lane] = pm.e[s]; tx->B[j0 + s][lane] = inc[s]; }
+                    __syncthreads();
+                    double ga[kG], gb[kG], Mg[kG];
+#pragma unroll
+                    for (int j = 0; j < kG; ++j) { ga[j] = tx->A[j][lane]; gb[j] = tx->B[j][lane]; }
+#pragma unroll
+                    for (int j = 0; j < kG; ++j) { B = fma(ga[j], B, gb[j]); A = A * ga[j]; }
+                    scan_affine(A, B);
+                    double Ax, Bx;
+                    lane_prev_map(A, B, Ax, Bx);
+                    double Mc = fma(Ax, M_s, Bx);
+#pragma unroll
+                    for (int j = 0; j < kG; ++j) { Mc = fma(ga[j], Mc, gb[j]); Mg[j] = Mc; }
+#pragma unroll
+                    for (int s = 0; s < kSPL; ++s) M1[s] = own_of<kSPL, W>(Mg, wave, s);
                 }
-                scan_affine(A, B);
-                double Ax, Bx;
-                lane_prev_map(A, B, Ax, Bx);   // exclusive prefix
-                double Mc = fma(Ax, M_s, Bx);            // Mdisc at this lane's first step start
-#pragma unroll
-                for (int s = 0; s < kSPL; ++s) { Mc = fma(am[s], Mc, bm[s]); M1[s] = Mc; }
                 d1 = disc_point(sh, w, M1);
             }
 
@@ -666,7 +785,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 // interpolated inside the record's steps (a finer successor) carry the interpolant's ~1e-11 ripple, which
                 // the higher differences would amplify by the cube / fourth power of the tile length: quadratic then.
                 // (compile-time: the 2-steps-per-lane kernels, two waves per SIMD on 256 registers each, do not carry this code)
-                constexpr bool kLogPredEver = kSPL >= 4;
+                constexpr bool kLogPredEver = kG >= 4;
                 bool guessed = false;
                 if constexpr (kLogPredEver) {
                 if (!startup && kind >= MP_LOGPRED_MIN_KIND) {
@@ -688,7 +807,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                     Vd<kSPL> ex;
 #pragma unroll
                     for (int s = 0; s < kSPL; ++s) {
-                        const double k = (double)(lane * kSPL + s + 1);
+                        const double k = (double)(e0 + s + 1);
                         const double e = k * fma(k, fma(fma(k, 1.0 / 6.0, 0.25), d2, 0.5 * d1), a0);
                         ex[s] = fmin(fmax(e, -4.0), 4.0);     // (a guess only: never further than a factor of 55 from the start value)
                     }
@@ -704,7 +823,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 const double g4 = (startup || interp_hist || !have4) ? 0.0 : g3 - (d2b - ((cw2 - cw3) - (cw3 - cw4)));
 #pragma unroll
                 for (int s = 0; s < kSPL; ++s) {
-                    const double k = (double)(lane * kSPL + s + 1);
+                    const double k = (double)(e0 + s + 1);
                     const double c2 = 0.5 * k * (k + 1.0);
                     const double c3 = c2 * (k + 2.0) * (1.0 / 3.0);
                     wg[s] = fma(k, g1, fma(c2, g2, fma(c3, g3, fma(c3 * (k + 3.0) * 0.25, g4, om_s))));
@@ -768,24 +887,64 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 MP_PHASE(13)
                 // largest rotation parameter among this lane's step ends (the padding steps of a short tile repeat its
                 // last point once the first sweep has run; before that nothing is decided on them: `settled` is false)
-                const double rot_max = lane_max(rot.v);
+                double h1 = cf1, h2 = cf2, h3 = cf3, u1 = cw1, u2 = cw2, u3 = cw3;
+                if (startup) {   // the three points before the grid continue points 0 and 1 linearly in the index
+                    // (team kernels: point 1 belongs to the first wavefront, and only its first lane uses these values)
+                    const double fp1 = lane_bcast(Ef[4], 0), wp1 = lane_bcast(Ew[4], 0);
+                    h1 = 2.0 * cf0 - fp1; u1 = 2.0 * om_s - wp1;
+                    h2 = 3.0 * cf0 - 2.0 * fp1; u2 = 3.0 * om_s - 2.0 * wp1;
+                    h3 = 4.0 * cf0 - 3.0 * fp1; u3 = 4.0 * om_s - 3.0 * wp1;
+                }
+                double Wold[kG];                          // team kernels: omega at the step ends of the lane's whole group, as evaluated in this sweep
+                double rot_max;
+                if constexpr (W == 1) {
+                    rot_max = lane_max(rot.v);
+                } else {
+                    // exchange 1: (omega_dot, omega) at the own step ends to LDS; back come the four points before this lane's
+                    // first own step (other wavefronts' step ends, or the history in front of the tile) and omega of the group
+#pragma unroll
+                    for (int s = 0; s < kSPL; ++s) { tx->F[j0 + s][1 + lane] = f1[s]; tx->Wv[j0 + s][1 + lane] = wg[s]; }
+                    if (lead && (startup || sweep == 1)) {   // (the points in front of the tile: fixed, except in the walker's first tile)
+                        tx->F[3][0] = cf0; tx->F[2][0] = h1; tx->F[1][0] = h2; tx->F[0][0] = h3;
+                        tx->Wv[3][0] = om_s; tx->Wv[2][0] = u1; tx->Wv[1][0] = u2; tx->Wv[0][0] = u3;
+                    }
+                    // (the phi functions and the quadrature weights need nothing of the exchange: between the writes and the
+                    // barrier they cover the LDS latency and whatever the wavefronts are apart)
+                    if (!light) {
+                        Vd<kSPL> zw;
+#pragma unroll
+                        for (int s = 0; s < kSPL; ++s) zw[s] = h[s] * lam[s];
+                        const Phi5<kSPL> pw_ = phi12345(zw);
+                        ez = pw_.e;
+                        p5 = pw_.p5;
+                        cw = eam5_node_weights(wbase, pw_);
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {   // the point 4 - k steps before this lane's first own step: in the previous lane's group or in this one
+                        const int q = j0 + k;
+                        Ef[k] = tx->F[q & 3][lane + (q >> 2)];
+                        Ew[k] = tx->Wv[q & 3][lane + (q >> 2)];
+                    }
+#pragma unroll
+                    for (int j = 0; j < kG; ++j) Wold[j] = tx->Wv[j][1 + lane];
+                    double rg[kG];
+#pragma unroll
+                    for (int j = 0; j < kG; ++j) rg[j] = sh.crot * (Wold[j] * Wold[j]);
+                    rot_max = lane_max(rg);
+                }
                 const bool flg = rot_max > 0.27;
                 const bool near_limit = rot_max > 0.26;   // close to the break-up switch of the torque: no linearisation
                 // break-up reached by an iterate that is no longer a wild guess: the reference's 'flag'
                 flagged |= __ballot(settled && flg);
                 const unsigned long long over_now = __ballot(flg);
                 over_sweeps += over_now != 0ull;
-                double h1 = cf1, h2 = cf2, h3 = cf3, u1 = cw1, u2 = cw2, u3 = cw3;
-                if (startup) {   // the three points before the grid continue points 0 and 1 linearly in the index
-                    const double fp1 = lane_bcast(Ef[4], 0), wp1 = lane_bcast(Ew[4], 0);
-                    h1 = 2.0 * cf0 - fp1; u1 = 2.0 * om_s - wp1;
-                    h2 = 3.0 * cf0 - 2.0 * fp1; u2 = 3.0 * om_s - 2.0 * wp1;
-                    h3 = 4.0 * cf0 - 3.0 * fp1; u3 = 4.0 * om_s - 3.0 * wp1;
+                if constexpr (W == 1) {
+                    Ef[3] = lane_prev(Ef[kSPL + 3], cf0);  Ew[3] = lane_prev(Ew[kSPL + 3], om_s);
+                    Ef[2] = lane_prev(Ef[kSPL + 2], h1);   Ew[2] = lane_prev(Ew[kSPL + 2], u1);
+                    Ef[1] = lane_prev(Ef[kSPL + 1], h2);   Ew[1] = lane_prev(Ew[kSPL + 1], u2);
+                    Ef[0] = lane_prev(Ef[kSPL + 0], h3);   Ew[0] = lane_prev(Ew[kSPL + 0], u3);
                 }
-                Ef[3] = lane_prev(Ef[kSPL + 3], cf0);  Ew[3] = lane_prev(Ew[kSPL + 3], om_s);
-                Ef[2] = lane_prev(Ef[kSPL + 2], h1);   Ew[2] = lane_prev(Ew[kSPL + 2], u1);
-                Ef[1] = lane_prev(Ef[kSPL + 1], h2);   Ew[1] = lane_prev(Ew[kSPL + 1], u2);
-                Ef[0] = lane_prev(Ef[kSPL + 0], h3);   Ew[0] = lane_prev(Ew[kSPL + 0], u3);
 #pragma unroll
                 for (int s = 0; s < kSPL; ++s) {
                     n0[s] = fma(-lam[s], Ew[4 + s], Ef[4 + s]);
@@ -795,7 +954,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                     n4[s] = fma(-lam[s], Ew[s], Ef[s]);
                 }
                 MP_PHASE(14)
-                if (!light) {
+                if (W == 1 && !light) {
                     Vd<kSPL> zw;
 #pragma unroll
                     for (int s = 0; s < kSPL; ++s) zw[s] = h[s] * lam[s];
@@ -808,28 +967,65 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 const Vd<kSPL> inc = eam5_increment_nodes(cw, h, n0, n1, n2, n3, n4);
                 Vd<kSPL> aw, bw;
                 double A = 1.0, B = 0.0;
+                double wc, dsum = 0.0;
+                double Wnew[kG], Dg[kG];                  // team kernels: the new omega and the smoothness indicators of the lane's whole group
+                if constexpr (W == 1) {
 #pragma unroll
-                for (int s = 0; s < kSPL; ++s) {
-                    aw[s] = ez[s];
-                    bw[s] = inc[s];
-                    B = fma(aw[s], B, bw[s]);
-                    A = A * aw[s];
-                }
-                scan_affine(A, B);
-                double Ax, Bx;
-                lane_prev_map(A, B, Ax, Bx);
-                double wc = fma(Ax, om_s, Bx);           // omega at this lane's first step start
-                // The convergence tests look at the lane's MEAN correction (its steps are consecutive and move together):
-                // one set of comparisons per lane instead of one per step.  NaN propagates through the sum: "not converged".
-                double dsum = 0.0;
+                    for (int s = 0; s < kSPL; ++s) {
+                        aw[s] = ez[s];
+                        bw[s] = inc[s];
+                        B = fma(aw[s], B, bw[s]);
+                        A = A * aw[s];
+                    }
+                    scan_affine(A, B);
+                    double Ax, Bx;
+                    lane_prev_map(A, B, Ax, Bx);
+                    wc = fma(Ax, om_s, Bx);           // omega at this lane's first step start
+                    // The convergence tests look at the lane's MEAN correction (its steps are consecutive and move together):
+                    // one set of comparisons per lane instead of one per step.  NaN propagates through the sum: "not converged".
 #pragma unroll
-                for (int s = 0; s < kSPL; ++s) {
-                    wc = fma(aw[s], wc, bw[s]);
-                    dsum += fabs(wc - wg[s]);
-                    wg[s] = wc;
+                    for (int s = 0; s < kSPL; ++s) {
+                        wc = fma(aw[s], wc, bw[s]);
+                        dsum += fabs(wc - wg[s]);
+                        wg[s] = wc;
+                    }
+                } else {
+                    // exchange 2: the own step maps (and, at coarse strides, the own steps' smoothness indicators: the early give-up
+                    // below looks at them) to LDS; every wavefront composes the group's maps in step order, scans, propagates the
+                    // tile's start value through ALL steps of the group and forms the group's correction: the convergence tests and
+                    // every decision that follows see the same numbers in every wavefront
+#pragma unroll
+                    for (int s = 0; s < kSPL; ++s) { tx->A[j0 + s][lane] = ez[s]; tx->B[j0 + s][lane] = inc[s]; }
+                    if (kind >= 2) {
+#pragma unroll
+                        for (int s = 0; s < kSPL; ++s)
+                            tx->D4[j0 + s][lane] = 120.0 * fabs(p5[s]) * h[s] * fabs((n0[s] + n4[s]) - 4.0 * (n1[s] + n3[s]) + 6.0 * n2[s]);
+                    }
+                    __syncthreads();
+                    double ga[kG], gb[kG];
+#pragma unroll
+                    for (int j = 0; j < kG; ++j) { ga[j] = tx->A[j][lane]; gb[j] = tx->B[j][lane]; Dg[j] = 0.0; }
+                    if (kind >= 2) {
+#pragma unroll
+                        for (int j = 0; j < kG; ++j) Dg[j] = tx->D4[j][lane];
+                    }
+#pragma unroll
+                    for (int j = 0; j < kG; ++j) { B = fma(ga[j], B, gb[j]); A = A * ga[j]; }
+                    scan_affine(A, B);
+                    double Ax, Bx;
+                    lane_prev_map(A, B, Ax, Bx);
+                    wc = fma(Ax, om_s, Bx);
+#pragma unroll
+                    for (int j = 0; j < kG; ++j) {
+                        wc = fma(ga[j], wc, gb[j]);
+                        dsum += fabs(wc - Wold[j]);
+                        Wnew[j] = wc;
+                    }
+#pragma unroll
+                    for (int s = 0; s < kSPL; ++s) wg[s] = own_of<kSPL, W>(Wnew, wave, s);
                 }
                 MP_PHASE(16)
-                const double mag = (double)kSPL * fabs(wc);
+                const double mag = (double)kG * fabs(wc);
                 const bool all_settled = dsum <= 1.0e-6 * mag;                       // false for NaN
                 const bool all_small = dsum <= MP_LIGHT_TOL * mag;
                 const bool all_ok = dsum <= tol_k * mag;
@@ -849,7 +1045,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 // the step ends follows the last correction through its linearisation, f + lambda (omega_new - omega_old),
                 // exact to the second order in that correction.
                 if (sweep >= 2 && pending != 0ull) {
-                    const double dp = (double)(kSPL >= 4 ? dsum_prev : s_dsum_prev[lane]), lim_c = sh.stop_factor * tol_k * mag;
+                    const double dp = (double)(kG >= 4 ? dsum_prev : s_dsum_prev[lane]), lim_c = sh.stop_factor * tol_k * mag;
                     const bool pass = dsum <= lim_c || (all_small && dsum <= 0.1 * dp && dsum * dsum <= lim_c * dp);
                     if (__all(pass && !near_limit)) {
 #pragma unroll
@@ -860,12 +1056,12 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
 #endif
                     }
                 }
-                if constexpr (kSPL >= 4) dsum_prev = (float)dsum;
+                if constexpr (kG >= 4) dsum_prev = (float)dsum;
                 else s_dsum_prev[lane] = (float)dsum;
 #ifdef MP_SWEEP_TRACE
                 // developer build (make sweep-trace): how the converged region of a slowly converging tile over single intervals grows,
                 // one word per sweep in the walker's tile-log row: first pending lane | pending lanes << 8 | lanes beyond the break-up limit << 16
-                if (a.tile_log && lane == 0 && kind <= 1 && sweep <= MP_TILE_LOG && (tr_tile < 0 || tr_tile == tiles_total)) {
+                if (a.tile_log && lead && kind <= 1 && sweep <= MP_TILE_LOG && (tr_tile < 0 || tr_tile == tiles_total)) {
                     if (sweep > 12) tr_tile = tiles_total;
                     if (tr_tile < 0 || tr_tile == tiles_total)
                         a.tile_log[(size_t)walker * MP_TILE_LOG + sweep - 1] = (pending ? __ffsll(pending) - 1 : 64) | (__popcll(pending) << 8) | (__popcll(over_now) << 16) | (tiles_total << 24);
@@ -879,7 +1075,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                     if (!(rel >= 1.0e-25)) rel = rel == rel ? 1.0e-25 : 1.0;
                     for (int d = 32; d >= 1; d >>= 1) rel = fmax(rel, __shfl_xor(rel, d, 64));
                     const int q = min(255, max(0, (int)(-10.0 * log10(rel) + 0.5)));
-                    if (a.tile_log && lane == 0 && tr_word < MP_TILE_LOG)
+                    if (a.tile_log && lead && tr_word < MP_TILE_LOG)
                         a.tile_log[(size_t)walker * MP_TILE_LOG + tr_word++] = (tiles_total & 0xFF) | (kind << 8) | ((full ? 0 : 1) << 11) | ((est_stop ? 1 : 0) << 12) | (__popcll(pending) << 13) | (q << 20);
                 }
 #endif
@@ -897,12 +1093,21 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 if (kind >= 2 && sweep >= 2) {
                     const double margin = sweep == 2 ? 4.0 : 1.0;
                     bool hot = false, very_hot = false;
+                    if constexpr (W == 1) {
 #pragma unroll
-                    for (int s = 0; s < kSPL; ++s) {
-                        const double d4 = 120.0 * fabs(p5[s]) * h[s] * fabs((n0[s] + n4[s]) - 4.0 * (n1[s] + n3[s]) + 6.0 * n2[s]);
-                        const double lim = margin * tile_tol * wg[s];
-                        hot = hot || d4 > lim;
-                        very_hot = very_hot || d4 > MP_ABORT_SKIP_RATIO * lim;
+                        for (int s = 0; s < kSPL; ++s) {
+                            const double d4 = 120.0 * fabs(p5[s]) * h[s] * fabs((n0[s] + n4[s]) - 4.0 * (n1[s] + n3[s]) + 6.0 * n2[s]);
+                            const double lim = margin * tile_tol * wg[s];
+                            hot = hot || d4 > lim;
+                            very_hot = very_hot || d4 > MP_ABORT_SKIP_RATIO * lim;
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < kG; ++j) {   // (the group's indicators came with exchange 2)
+                            const double lim = margin * tile_tol * Wnew[j];
+                            hot = hot || Dg[j] > lim;
+                            very_hot = very_hot || Dg[j] > MP_ABORT_SKIP_RATIO * lim;
+                        }
                     }
                     if ((__ballot(hot) & ((1ull << kMinKeepLanes) - 1ull)) != 0ull) {
                         abort_tile = true;
@@ -942,7 +1147,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
 #else
                 const int hot_q = abort_skip ? 255 : 0;
 #endif
-                if (MP_TILE_LOG_ON && LOG && a.tile_log && lane == 0 && tiles_total <= MP_TILE_LOG)
+                if (MP_TILE_LOG_ON && LOG && a.tile_log && lead && tiles_total <= MP_TILE_LOG)
                     a.tile_log[(size_t)walker * MP_TILE_LOG + tiles_total - 1] = kind | (sweep << 4) | (hot_q << 16) | (64 << 24);
                 cool = 3;
                 ++trouble;
@@ -957,7 +1162,8 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 {
                     bool brk = false;
 #pragma unroll
-                    for (int s = 0; s < kSPL; ++s) brk = brk || (lane * kSPL + s < nc && branch_flags(w, d1.rmu[s], wg[s]) != flags_s);
+                    for (int s = 0; s < kSPL; ++s) brk = brk || (e0 + s < nc && branch_flags(w, d1.rmu[s], wg[s]) != flags_s);
+                    if constexpr (W > 1) brk = team_or<W>(tx, wave, lane, brk ? 1u : 0u) != 0u;   // (any step of the lane's group)
                     if ((__ballot(brk) & ((1ull << kMinKeepLanes) - 1ull)) != 0ull) drop = 4;
                 }
                 opt_kind = max(2, kind - (drop > 2 ? 1 : drop));
@@ -969,13 +1175,38 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
             // infinity anywhere shows in the sum, a non-positive value in the minimum, the break-up limit in the largest
             // omega (the padding steps of a short tile repeat its last point).
             unsigned long long mb, mf;
+            unsigned team_fl = 0u;   // team kernels: the per-step flags of this tile, OR-ed over the steps of the lane's group (all wavefronts)
             {
                 double vsum = M1[0] + wg[0];
 #pragma unroll
                 for (int s = 1; s < kSPL; ++s) vsum += M1[s] + wg[s];
                 const double vmin = min_raw(lane_min(M1.v), lane_min(wg.v)), wmax = lane_max(wg.v);
-                const bool bad = !isfinite(vsum) || !(vmin > 0.0);
-                const bool over = sh.crot * wmax * wmax > 0.27;
+                bool bad = !isfinite(vsum) || !(vmin > 0.0);
+                bool over = sh.crot * wmax * wmax > 0.27;
+                if constexpr (W > 1) {
+                    // One exchange for everything the rest of the tile decides on: these two and the flags of the acceptance
+                    // below, computed here for the own steps.  Its barrier is also the one behind which the image may be
+                    // rewritten (every earlier reader of the image is in front of it).
+                    const double prom8 = 64.0 / sh.k4_tol_factor;
+                    unsigned fl = (bad ? 1u << 9 : 0u) | (over ? 1u << 10 : 0u);
+#pragma unroll
+                    for (int s = 0; s < kSPL; ++s) {
+                        const bool valid = e0 + s < nc;
+                        const double d4 = 120.0 * fabs(p5[s]) * h[s] * fabs((n0[s] + n4[s]) - 4.0 * (n1[s] + n3[s]) + 6.0 * n2[s]);
+                        const double lim = tile_tol * wg[s];
+                        fl |= (valid && branch_flags(w, d1.rmu[s], wg[s]) != flags_s) ? 1u : 0u;
+                        fl |= d4 > lim ? 2u : 0u;
+                        fl |= 64.0 * d4 > lim ? 4u : 0u;
+                        fl |= 2048.0 * d4 > lim ? 8u : 0u;
+                        fl |= 65536.0 * d4 > lim ? 16u : 0u;
+                        fl |= prom8 * d4 > lim ? 32u : 0u;
+                        fl |= d4 > 16.0 * lim ? 128u : 0u;
+                        fl |= d4 > 512.0 * lim ? 256u : 0u;
+                    }
+                    team_fl = team_or<W>(tx, wave, lane, fl);
+                    bad = (team_fl & (1u << 9)) != 0u;
+                    over = (team_fl & (1u << 10)) != 0u;
+                }
                 mb = __ballot(bad);
                 // a step whose sweeps never settle is chattering on the Nacc discontinuity: same verdict as a flag
                 mf = flagged | __ballot(over) | ((flagged || early_stop) ? 0ull : pending);
@@ -1004,9 +1235,10 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
 #endif
                 const double prom8 = 64.0 / sh.k4_tol_factor;   // a tile over 8 intervals is held to k4_tol_factor x the bound: its
                                                                 // promotion asks the same of the scaled indicator
+                if constexpr (W == 1) {
 #pragma unroll
                 for (int s = 0; s < kSPL; ++s) {
-                    const bool valid = lane * kSPL + s < nc;
+                    const bool valid = e0 + s < nc;
                     brk = brk || (valid && branch_flags(w, d1.rmu[s], wg[s]) != flags_s);
                     // (the formula's error term: h phi_5(h lambda) x the 4th difference; 120 phi_5 = 1 at 0, -> 5/|h lambda| where
                     // the equation is stiff and the exponential integrator tracks the spin equilibrium)
@@ -1016,16 +1248,24 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                     ind64 = ind64 || 64.0 * d4 > lim;
                     ind2048 = ind2048 || 2048.0 * d4 > lim;
                     ind65536 = ind65536 || 65536.0 * d4 > lim;
-                    if constexpr (kSPL < 4) indpre = indpre || MP_PRE_EARLY_END_FACTOR * d4 > lim;
+                    if constexpr (kG < 4) indpre = indpre || MP_PRE_EARLY_END_FACTOR * d4 > lim;
                     indp8 = indp8 || prom8 * d4 > lim;
 #if MP_CUT_BY_RATIO > 0
                     ind16x = ind16x || d4 > 16.0 * lim;
                     ind512x = ind512x || d4 > 512.0 * lim;
 #endif
                 }
+                } else {   // (formed for the own steps in front of the failure detection and exchanged there)
+                    (void)prom8;
+                    brk = (team_fl & 1u) != 0u; ind1 = (team_fl & 2u) != 0u; ind64 = (team_fl & 4u) != 0u; ind2048 = (team_fl & 8u) != 0u;
+                    ind65536 = (team_fl & 16u) != 0u; indp8 = (team_fl & 32u) != 0u;
+#if MP_CUT_BY_RATIO > 0
+                    ind16x = (team_fl & 128u) != 0u; ind512x = (team_fl & 256u) != 0u;
+#endif
+                }
                 const unsigned long long B = __ballot(brk), I1 = __ballot(ind1), I64 = __ballot(ind64), I2048 = __ballot(ind2048),
                                          I65536 = __ballot(ind65536), Ip8 = __ballot(indp8);
-                const int full_lanes = (nc + kSPL - 1) / kSPL;                 // lanes that hold steps of this tile
+                const int full_lanes = (nc + kG - 1) / kG;                 // lanes that hold steps of this tile
                 why = (B != 0ull ? 1 : 0) | (I1 != 0ull ? 2 : 0) | (I64 != 0ull ? 4 : 0) | (I2048 != 0ull ? 8 : 0) | (unconv != 0ull ? 16 : 0) |
                       (I65536 != 0ull ? 32 : 0);
                 if (kind >= 2) {
@@ -1036,7 +1276,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                         if (first < kMinKeepLanes) {                            // nothing worth keeping: redo at stride 1
                             opt_kind = max(2, kind - 1);
                             ++trouble;
-                            if (MP_TILE_LOG_ON && LOG && a.tile_log && lane == 0 && tiles_total <= MP_TILE_LOG)
+                            if (MP_TILE_LOG_ON && LOG && a.tile_log && lead && tiles_total <= MP_TILE_LOG)
                                 a.tile_log[(size_t)walker * MP_TILE_LOG + tiles_total - 1] = kind | (sweep << 4) | (why << 24);
                             // a kink in those lanes: single intervals; else the next finer stride is tried at once
                             kind = (kind > 2 && (B & ((1ull << kMinKeepLanes) - 1ull)) == 0ull) ? kind - 1 : 1;
@@ -1059,7 +1299,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                             const unsigned long long X16 = __ballot(ind16x), X512 = __ballot(ind512x);
                             if ((B & win) == 0ull) {
                                 next_kind = (X16 & win) == 0ull ? kind - 1 : ((X512 & win) == 0ull ? max(kind - 2, 1) : 1);
-                                by_ratio = kSPL < 4;
+                                by_ratio = kG < 4;
                             }
                         }
 #endif
@@ -1070,14 +1310,14 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                         // (256-step tiles: the hold ends early when the held tile shows that the slow zone is behind -- sweeps converged
                         // in three passes, indicator with room for four times the step: burnt-in ensembles 0.107 -> 0.103 ms; with
                         // 128-step tiles it cost the sampler 1 %: profiles/r04_ab_hold_release.log)
-                        if (kSPL >= 4 && hold > 0 && kind == hold_kind && sweep <= 3 && I2048 == 0ull) hold = 0;
+                        if (kG >= 4 && hold > 0 && kind == hold_kind && sweep <= 3 && I2048 == 0ull) hold = 0;
                         if (hold > 0 && kind == hold_kind) --hold;
                         else next_kind = (kind == 3 ? Ip8 : I64) == 0ull ? kind + 1 : kind;
                         opt_kind = max(opt_kind, min(next_kind, max_kind));
                     }
                 } else if (unconv != 0ull) {                                    // kinds 0, 1 stopped early: the converged lanes
                     keep_lanes = __ffsll(unconv) - 1;
-                    if (pre) keep_lanes &= ~(8 / kSPL - 1);                    // (whole grid intervals of sub-steps)
+                    if (pre) keep_lanes &= ~(8 / kG - 1);                    // (whole grid intervals of sub-steps)
                 } else if (kind == 1 && nc + 8 > kTile) {
                     // No kink in this tile: the scaled indicator decides while a recent coarse attempt has failed early
                     // (cool > 0); otherwise the coarsest stride is simply tried (a tile is cut where it does not hold): the
@@ -1090,11 +1330,11 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                     else {
                         // a kink inside this tile: the history of a coarse successor must lie behind it
                         const int first_clean = __ffsll(B) - 1 + 2;            // lanes from here on are past the kink
-                        const int tail = nc - first_clean * kSPL;              // steps in them
+                        const int tail = nc - first_clean * kG;              // steps in them
                         const unsigned long long post = first_clean < 64 ? ~0ull << first_clean : 0ull;
-                        if (tail >= 24 + kSPL && (I65536 & post) == 0ull) next_kind = 4;
-                        else if (tail >= 12 + kSPL && (I2048 & post) == 0ull) next_kind = 3;
-                        else if (tail >= 6 + kSPL && (I64 & post) == 0ull) next_kind = 2;
+                        if (tail >= 24 + kG && (I65536 & post) == 0ull) next_kind = 4;
+                        else if (tail >= 12 + kG && (I2048 & post) == 0ull) next_kind = 3;
+                        else if (tail >= 6 + kG && (I64 & post) == 0ull) next_kind = 2;
                     }
                 }
                 // after the sub-stepped tiles: optimistic (a tile that meets a fast feature is cut) -- as far as the record of the
@@ -1102,16 +1342,16 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 // of 128 sub-steps (2 steps per lane) covers 16 grid intervals, not the 24 a step over 8 asks for.  (Until round 4
                 // that attempt was made, read a default for the third point, failed its indicator test in the first lanes and
                 // was redone over 4 intervals: a tile wasted per walker in every 2-steps-per-lane launch.)
-                if constexpr (kSPL < 4) {
+                if constexpr (kG < 4) {
                     if (pre && max_kind > 1 && keep_lanes == 64 && nc == kTile && pos8 + nc < pre_end8 && B == 0ull && __ballot(indpre) == 0ull)
                         pre_end8 = pos8 + nc;                                  // the sub-stepped start ends here
                 }
-                if (kind == 0) next_kind = ((keep_lanes * kSPL) >> 3) >= 24 ? 4 : (((keep_lanes * kSPL) >> 3) >= 12 ? 3 : (((keep_lanes * kSPL) >> 3) >= 6 ? 2 : 1));
+                if (kind == 0) next_kind = ((keep_lanes * kG) >> 3) >= 24 ? 4 : (((keep_lanes * kG) >> 3) >= 12 ? 3 : (((keep_lanes * kG) >> 3) >= 6 ? 2 : 1));
                 next_kind = min(next_kind, max_kind);
             }
             MP_PHASE(5)
-            const int keep = min(keep_lanes * kSPL, nc);                       // steps kept
-            if (MP_TILE_LOG_ON && LOG && a.tile_log && lane == 0 && tiles_total <= MP_TILE_LOG)
+            const int keep = min(keep_lanes * kG, nc);                       // steps kept
+            if (MP_TILE_LOG_ON && LOG && a.tile_log && lead && tiles_total <= MP_TILE_LOG)
                 a.tile_log[(size_t)walker * MP_TILE_LOG + tiles_total - 1] = kind | (sweep << 4) | (keep_lanes << 16) | (why << 24);
             const int end_kept8 = pos8 + keep * d8;
 
@@ -1125,7 +1365,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
             if constexpr (CURVES) {
                 bool lane_qs = true;
 #pragma unroll
-                for (int s = 0; s < kSPL; ++s) lane_qs = lane_qs && (lane * kSPL + s >= keep || h[s] * w.inv_tau >= 1.0);
+                for (int s = 0; s < kSPL; ++s) lane_qs = lane_qs && (e0 + s >= keep || h[s] * w.inv_tau >= 1.0);
                 all_qs = kind >= 2 && keep >= 3 && __all(lane_qs);
                 if (all_qs) {
                     const Vd<kSPL> iS = rcp_fast(S1);
@@ -1133,17 +1373,17 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                     for (int s = 0; s < kSPL; ++s) ratio[s] = M1[s] * iS[s];
                 }
             }
-            __syncthreads();                                                    // earlier readers of the image are done
+            if constexpr (W == 1) __syncthreads();                              // earlier readers of the image are done (team kernels: the flag exchange above)
 #pragma unroll
             for (int s = 0; s < kSPL; ++s) {
-                const int e = lane * kSPL + s + 1;
+                const int e = e0 + s + 1;
                 const double dM = fma(-M1[s], w.inv_tau, S1[s]);               // dM/dt = Mdotfb - M/tvisc, and its derivative
                 im.W[e] = wg[s]; im.F[e] = Ef[4 + s]; im.M[e] = M1[s]; im.D[e] = dM;
                 im.D2[e] = (CURVES && all_qs) ? ratio[s] : fma(-dM, w.inv_tau, dS1[s]);
                 im.R[e] = d1.rmu[s];
                 if (e == keep) { im.C[0] = S1[s]; im.C[1] = dS1[s]; im.C[2] = iu1[s]; }
             }
-            if (lane == 0) {
+            if (lead) {
                 const double dM = fma(-M_s, w.inv_tau, cS0);
                 im.W[0] = om_s; im.F[0] = cf0; im.M[0] = M_s; im.D[0] = dM;
                 if (CURVES && all_qs) { const Vd<1> s0{{cS0}}; im.D2[0] = M_s * rcp_fast(s0)[0]; }
@@ -1223,7 +1463,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                             const double cD = fma(-2.0, t3, 3.0 * t2), c0 = fma(-2.0, t2, th) + t3, c1 = t3 - t2;
 #pragma unroll
                             for (int s = 0; s < kSPL; ++s) {
-                                const int J = lane * kSPL + s;                 // nodes J (step start) and J + 1 of the image
+                                const int J = e0 + s;                 // nodes J (step start) and J + 1 of the image
                                 const double W0 = im.W[J];
                                 Wv[s] = fma(cD, wg[s] - W0, fma(c0, h[s] * im.F[J], fma(c1, h[s] * Ef[4 + s], W0)));
                             }
@@ -1234,7 +1474,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                                 const double thm1 = th - 1.0;
 #pragma unroll
                                 for (int s = 0; s < kSPL; ++s) {
-                                    const int J = lane * kSPL + s;
+                                    const int J = e0 + s;
                                     const int l0 = max(min(J - 1, keep - 3), 0), variant = min(J - l0, 2);
                                     const int base = kWtabDense + ((kind - 2) * 7 + (i - 1)) * 12 + variant * 4;
                                     double r = 0.0;
@@ -1258,7 +1498,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                                 bool any_qs = false;
 #pragma unroll
                                 for (int s = 0; s < kSPL; ++s) {
-                                    const int J = lane * kSPL + s;
+                                    const int J = e0 + s;
                                     const double hs = h[s], hh = hs * hs, M0 = im.M[J], dMs = M1[s] - M0;
                                     const double hD0 = hs * im.D[J], hD1 = hs * im.D[J + 1];
                                     const bool shortstep = hs * w.inv_tau < 1.0;
@@ -1270,7 +1510,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                                 if (__any(any_qs)) {   // the one tile in which the steps outgrow tvisc: node ratios formed on the spot
 #pragma unroll
                                     for (int s = 0; s < kSPL; ++s) {
-                                        const int J = lane * kSPL + s;
+                                        const int J = e0 + s;
                                         if (!(h[s] * w.inv_tau < 1.0 || keep < 3 || J >= keep))
                                             Mv[s] = dense_mdisc_qs(w, im, kind, i, J, keep, fma(th - 1.0, h[s], t_s * tt.E[kind - 1][J + 1]));
                                     }
@@ -1288,7 +1528,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                         }
 #pragma unroll
                         for (int s = 0; s < kSPL; ++s) {
-                            const int e = lane * kSPL + s;                     // step index in the tile
+                            const int e = e0 + s;                     // step index in the tile
                             if (pre) { if ((e & 7) == 7) stage[sw((e >> 3) + 1)] = val[s]; }
                             else stage[sw(e * ns + i)] = val[s];
                         }

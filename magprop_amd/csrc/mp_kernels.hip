@@ -53,9 +53,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPL >= 4 ? 1
     __shared__ TileImage<SPL> im;
     __shared__ TimeTable<SPL> tt;
     __shared__ double Lbuf[CURVES ? 8 * 64 * SPL + 1 : 1];   // up to 8 grid points per step
-    ktab_init();
-    wtab_init(sh.wtab);
-    time_table_init(sh, tt);
+    tables_init<SPL, 64>(sh, tt);
     const int walker = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
     double par[MP_MAX_NDIM];
     const double *pw = a.pars + (size_t)walker * a.ndim;
@@ -72,6 +70,36 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPL >= 4 ? 1
         aa.want_chi2 = 1;
         walker_eval<CURVES, SPL, LONG, LOG>(sh, aa, walker, par, im, tt, Lbuf, lnp, status, sweeps, tiles);
     }
+    if (threadIdx.x == 0) {
+        a.lnprob[walker] = lnp;
+        if (a.status) a.status[walker] = status;
+        if (a.sweeps) a.sweeps[walker] = sweeps;
+        if (a.tiles) a.tiles[walker] = tiles;
+    }
+}
+
+// The same on a team of W wavefronts per walker (mp_eval.hpp TeamX): launches that would leave SIMDs idle.  One wavefront per
+// SIMD (each takes what it needs of the register file), so a workgroup is spread over W SIMDs of its CU.
+// OCC = wavefronts resident per SIMD the build is made for: 1 while the launch has a SIMD for every wavefront (n <= n_simd / W),
+// 2 for twice as many walkers (256 registers; the walker's constants in scalar registers).
+template <int SPL, int W, int OCC, bool LOG = false>
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void lnprob_team_kernel(const DevShared sh, const LaunchArgs a) {
+    __shared__ TileImage<SPL * W> im;
+    __shared__ TimeTable<SPL * W> tt;
+    __shared__ TeamX<SPL * W> tx;
+    __shared__ double Lbuf[1];
+    tables_init<SPL * W, 64 * W>(sh, tt);
+    const int walker = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
+    double par[MP_MAX_NDIM];
+    const double *pw = a.pars + (size_t)walker * a.ndim;
+#pragma unroll
+    for (int i = 0; i < MP_MAX_NDIM; ++i) par[i] = i < a.ndim ? pw[i] : 0.0;
+    double lnp;
+    int status, sweeps, tiles;
+    LaunchArgs aa = a;
+    aa.physical = 0;
+    aa.want_chi2 = 1;
+    walker_eval<false, SPL, false, LOG, W, OCC >= 2>(sh, aa, walker, par, im, tt, Lbuf, lnp, status, sweeps, tiles, &tx);
     if (threadIdx.x == 0) {
         a.lnprob[walker] = lnp;
         if (a.status) a.status[walker] = status;
@@ -169,9 +197,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPL >= 4 ? 1
     __shared__ TimeTable<SPL> tt;
     __shared__ double lds[1];
     __shared__ double park[MP_MAX_NDIM + 3];
-    ktab_init();
-    wtab_init(sh.wtab);
-    time_table_init(sh, tt);
+    tables_init<SPL, 64>(sh, tt);
     const int gs = g.slot_lo + (int)blockIdx.x;                    // slot of the active half, all ensembles flattened
     const int w_ens = ens_of_slot(g, gs / g.n_half);               // which ensemble (longest light curve first)
     const int slot = gs % g.n_half;                                // which walker of the active half
@@ -306,9 +332,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPL >= 4 ? 1
     __shared__ TileImage<SPL> im;
     __shared__ TimeTable<SPL> tt;
     __shared__ double lds[1];
-    ktab_init();
-    wtab_init(sh.wtab);
-    time_table_init(sh, tt);
+    tables_init<SPL, 64>(sh, tt);
     const int n_slots = g.n_half * g.n_ensembles;
     const int blk = g.slot_lo + (int)blockIdx.x;                    // a launch covers blocks [slot_lo, slot_lo + gridDim.x) (sharded: a rank's share)
     const int type = blk / n_slots, gs = blk - type * n_slots;
@@ -469,6 +493,28 @@ int launch_lnprob(const DevShared &sh, const LaunchArgs &a, void *stream) {
     const bool wide = (sh.force_spl ? sh.force_spl : kernel_spl(sh, a.n)) == 4;
     const bool lng = sh.has_long != 0;
     hipStream_t st = (hipStream_t)stream;
+    //  - launches that would leave SIMDs idle (n <= n_simd / 2): a team of four wavefronts per walker, one step per lane each
+    //    (the same 256-step tiles and policy; mode A on light curves of up to 64 points).  Up to n_simd / 4 walkers every
+    //    wavefront has a SIMD of its own; up to n_simd / 2 two share one and fill each other's stalls.  Measured on one box
+    //    (profiles/r05_team_*.log): 256 walkers 0.0755 -> 0.0577 ms, 512 walkers 0.0767 -> 0.0699 ms near the truth
+    //    (0.197 -> 0.165 ms prior-wide); a team of two (2 steps per lane) at 512 walkers 0.0701 / 0.197 ms.
+    const int team = (curves || !a.want_chi2 || a.physical) ? 1 : kernel_waves(sh, a.n);
+    if (team > 1) {
+        const bool log = a.tile_log != nullptr || kAlwaysLog;
+        if (team == 4 && 4 * a.n <= sh.n_simd) {
+            if (log) hipLaunchKernelGGL((lnprob_team_kernel<1, 4, 1, true>), grid, dim3(256), 0, st, sh, a);
+            else hipLaunchKernelGGL((lnprob_team_kernel<1, 4, 1, false>), grid, dim3(256), 0, st, sh, a);
+        } else if (team == 4) {
+            if (log) hipLaunchKernelGGL((lnprob_team_kernel<1, 4, 2, true>), grid, dim3(256), 0, st, sh, a);
+            else hipLaunchKernelGGL((lnprob_team_kernel<1, 4, 2, false>), grid, dim3(256), 0, st, sh, a);
+        } else {
+#ifdef MP_EXPERIMENTS
+            if (log) hipLaunchKernelGGL((lnprob_team_kernel<2, 2, 1, true>), grid, dim3(128), 0, st, sh, a);
+            else hipLaunchKernelGGL((lnprob_team_kernel<2, 2, 1, false>), grid, dim3(128), 0, st, sh, a);
+#endif
+        }
+        return (int)hipGetLastError();
+    }
     if (curves) {
         if (wide) hipLaunchKernelGGL((lnprob_kernel<true, 4, false>), grid, block, 0, st, sh, a);
         else hipLaunchKernelGGL((lnprob_kernel<true, 2, false>), grid, block, 0, st, sh, a);

@@ -76,11 +76,16 @@ def test_every_kernel_variant_against_the_c_oracle(gsynth, tarr, seed):
     summary = {"n": N_SOAK, "seed": int(seed), "oracle_status_counts": np.bincount(rst, minlength=4).tolist(), "variants": {}}
     # strict: sweep tolerance 1e-9 and every grid interval a step, i.e. the scheme the serial C restatement integrates
     # (mode 0); product defaults: sweep tolerance 1e-7, steps over 1, 2, 4 or 8 grid intervals (include/magprop_amd.h)
-    for batch, label, env in ((256, "4 steps per lane, small batches", {}),
+    # (batches of <= n_simd / 2 walkers run the team kernels, four wavefronts per walker: <= n_simd / 4 one wavefront per
+    # SIMD, above two: mp_kernels.hip launch_lnprob; n_simd = 1 024 on an MI355X)
+    for batch, label, env in ((256, "team of 4 wavefronts, one per SIMD", {}),
+                              (512, "team of 4 wavefronts, two per SIMD", {}),
                               (1024, "4 steps per lane", {}),
                               (4096, "2 steps per lane", {}),
                               (4096, "2 steps per lane, product defaults (adaptive stride)", {"defaults": True}),
-                              (1024, "4 steps per lane, product defaults (adaptive stride)", {"defaults": True})):
+                              (1024, "4 steps per lane, product defaults (adaptive stride)", {"defaults": True}),
+                              (512, "team of 4 wavefronts, two per SIMD, product defaults (adaptive stride)", {"defaults": True}),
+                              (256, "team of 4 wavefronts, one per SIMD, product defaults (adaptive stride)", {"defaults": True})):
         loose = bool(env.get("defaults"))
         lp_ = LogProb(*sets[0]) if loose else LogProb(*sets[0], sweep_tol=STRICT, max_stride=1)
         for s in sets[1:]:
@@ -136,7 +141,7 @@ def test_library_variant_against_the_c_oracle(glib, grid, seed):
     ref = np.concatenate([r[0] for r in res])
     rst = np.concatenate([r[1] for r in res])
     lp_ = LogProb(*ds, variant="lib", GRBtype=grid, lower=lo, upper=hi, sweep_tol=STRICT, max_stride=1)
-    for batch in (256, 1024, 4096):
+    for batch in (256, 512, 1024, 4096):
         out = np.empty(n)
         st = np.empty(n, dtype=np.int32)
         for a in range(0, n, batch):
@@ -149,7 +154,7 @@ def test_library_variant_against_the_c_oracle(glib, grid, seed):
     # the product defaults (adaptive stride) on the same walkers: identical verdicts, values within the documented bound
     lpd = LogProb(*ds, variant="lib", GRBtype=grid, lower=lo, upper=hi)
     worst = {}
-    for batch in (1024, 4096):
+    for batch in (256, 1024, 4096):
         out = np.empty(n)
         st = np.empty(n, dtype=np.int32)
         for a in range(0, n, batch):
