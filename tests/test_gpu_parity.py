@@ -19,10 +19,13 @@ CROSS_VARIANT_RTOL = 1e-7       # kernel variants (tile lengths: the adaptive ti
 
 
 def kernel_variant(n):
-    """(wavefronts per walker, steps per lane) the library picks for a batch of n (mp_device.h; always ONE wavefront per walker
-    since round 3, four steps per lane up to one wave per SIMD, two beyond): batches of different variants agree to
-    CROSS_VARIANT_RTOL, batches of the same variant bit for bit."""
-    return (1, 4) if n <= 1024 else (1, 2)
+    """(wavefronts per walker, steps per lane, wavefronts resident per SIMD) the library picks for a batch of n on an MI355X
+    (mp_device.h kernel_waves / kernel_spl, mp_kernels.hip launch_lnprob): a team of four wavefronts per walker up to
+    n_simd / 2 = 512 walkers (its own build up to 256, where every wavefront has a SIMD), one wavefront with four steps per
+    lane up to 1 024, two steps per lane beyond.  Batches of different variants agree to CROSS_VARIANT_RTOL (the team kernels and
+    the 4-steps-per-lane kernel, which share tiles and policy, to TEAM_RTOL), batches of the same variant bit for bit."""
+    return (4, 1, 1) if n <= 256 else ((4, 1, 2) if n <= 512 else ((1, 4, 1) if n <= 1024 else (1, 2, 2)))
+TEAM_RTOL = 1e-11
 LOG_MASK = 0b111100
 
 
@@ -561,9 +564,22 @@ def test_batch_size_does_not_change_a_walker(synth_handle, gsynth):
     P[9] = [1.8171068, 3.68147895, -2.61786801, 1.99840102, -0.33083576, 2.95613803]   # flags
     big, st_big = synth_handle.lnprob_batch(P, ds_id=3, want_status=True)
     assert st_big[5] == 3 and st_big[9] == 1 and big[6] == -np.inf
-    for lo, hi in ((0, 512), (512, 1024), (100, 400)):
+    ns = synth_handle.n_simd                                           # 1 024 on an MI355X
+    assert len(P) == ns
+    # the kernel variant goes by the launch size (mp_kernels.hip launch_lnprob): one wavefront per walker above n_simd / 2
+    # walkers, a team of four up to there (two resident per SIMD), and up to n_simd / 4 with a SIMD for every wavefront
+    for lo, hi in ((0, ns // 2 + 88), (ns // 2 - 88, ns), (100, 700)):
         out, st = synth_handle.lnprob_batch(P[lo:hi], ds_id=3, want_status=True)
         assert np.array_equal(out, big[lo:hi]) and np.array_equal(st, st_big[lo:hi])
+    for size, subs in ((ns // 2, ((0, ns // 4 + 44), (ns // 4 - 44, ns // 2))), (ns // 4, ((0, 100), (56, ns // 4)))):
+        mid, st_mid = synth_handle.lnprob_batch(P[:size], ds_id=3, want_status=True)
+        assert np.array_equal(st_mid, st_big[:size])
+        # across variants: the same tiles and sweeps, the group's step maps composed in the same order -- rounding apart
+        ok = st_mid == 0
+        assert np.all(mid[~ok] == -np.inf) and np.allclose(mid[ok], big[:size][ok], rtol=1e-11, atol=0.0)
+        for lo, hi in subs:
+            out, st = synth_handle.lnprob_batch(P[lo:hi], ds_id=3, want_status=True)
+            assert np.array_equal(out, mid[lo:hi]) and np.array_equal(st, st_mid[lo:hi])
 
 
 def test_edge_cases(mpa, synth_handle, gsynth):
