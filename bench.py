@@ -37,6 +37,9 @@ Prints one JSON line on rank 0 (contract in the task description) with extra obj
   check            the reference's own golden walkers (tests/golden/golden_synth.npz) evaluated in this run.
   ensemble_sampler the same metric through the device-resident stretch move (N = 1: fused single-GPU sampler;
                    N > 1: walker-sharded half-steps with one all-gather each — dependent launches, nothing overlapped).
+  dropin           N = 1: the same metric through the drop-in boundary as the reference's caller uses it: an emcee-shaped
+                   loop (vectorize=True) over magprop_amd.synth.lnprob, numpy in / numpy out, two dependent calls of
+                   N_walk / 2 proposals per step; with the time inside those host-buffer calls alone.
   cpu_baseline     oracle/lsoda_port.py in its reference_cost mode (scipy odeint + Python RHS that re-derives the constants
                    in every call + element-wise torque loop: within +5 % of the real reference per evaluation, identical
                    values) timed on this box's host cores over a bounded sample of the same walkers (rank 0, at every N,
@@ -272,6 +275,56 @@ def sampler_leg(c, n_walk, datasets, p0, steps, seed, **kw):
            "launches": "one per step (3/2 x walkers evaluations) + commit" if whole else "one fused launch per half-step"}
     es.close()
     return out
+
+
+def dropin_leg(g, n_walk, steps, seed, device):
+    """The drop-in boundary as the reference's own caller drives it (code/synthetic_datasets/synth_mcmc.py:170-185):
+    `magprop_amd.synth.lnprob(pars, x, y, yerr, fbad)` with x, y, yerr as pandas Series, called by an emcee-shaped loop
+    with vectorize=True -- ONE call with all n_walk rows, then per step TWO dependent calls of n_walk / 2 proposals, numpy
+    in / numpy out (the stretch move of tests/test_gpu_emcee_contract.py's test double; emcee itself is absent from the
+    image).  walker_steps_per_sec is the whole loop; host_entry_ms_per_call is the time inside the n_walk / 2-row calls
+    alone (PCIe both ways, launch, synchronisation and the Python front end included)."""
+    import pandas as pd
+
+    import magprop_amd as mpa
+    x, y, yerr = (pd.Series(g["Humped_" + k]) for k in ("x", "y", "yerr"))
+    args = (x, y, yerr, None)
+    rng = np.random.RandomState(seed % (2 ** 31))
+    pos = np.array(TRUTH["Humped"]) + 1.0e-4 * rng.standard_normal((n_walk, 6))
+    half, a_ = n_walk // 2, 2.0
+    lp = np.asarray(mpa.synth.lnprob(pos, *args, device=device))
+    t_calls, n_calls, n_acc = 0.0, 0, 0
+
+    def step():
+        nonlocal t_calls, n_calls, n_acc
+        inds = rng.permutation(n_walk)
+        for S, C in ((inds[:half], inds[half:]), (inds[half:], inds[:half])):
+            zz = ((a_ - 1.0) * rng.rand(half) + 1.0) ** 2.0 / a_
+            partner = C[rng.randint(half, size=half)]
+            q = pos[partner] - (pos[partner] - pos[S]) * zz[:, None]
+            t0 = time.perf_counter()
+            new = mpa.synth.lnprob(q, *args, device=device)
+            t_calls += time.perf_counter() - t0
+            n_calls += 1
+            with np.errstate(invalid="ignore"):
+                acc = 5.0 * np.log(zz) + new - lp[S] > np.log(rng.rand(half))
+            pos[S[acc]] = q[acc]
+            lp[S[acc]] = new[acc]
+            n_acc += int(acc.sum())
+    for _ in range(5):
+        step()
+    t_calls, n_calls, n_acc = 0.0, 0, 0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    dt = time.perf_counter() - t0
+    return {"walkers": n_walk, "steps": steps, "walker_steps_per_sec": n_walk * steps / dt, "ms_per_step": 1e3 * dt / steps,
+            "host_entry_ms_per_call": 1e3 * t_calls / n_calls, "rows_per_call": half, "calls": n_calls,
+            "acceptance_fraction": n_acc / (n_walk * steps),
+            "entry": "magprop_amd.synth.lnprob(pars, x, y, yerr, fbad), pandas Series arguments, numpy in / numpy out",
+            "note": "emcee-shaped loop (vectorize=True): two dependent host-buffer calls of n_walk / 2 proposals per step; "
+                    "the loop's own numpy arithmetic (proposals, accept / reject) is inside walker_steps_per_sec, outside "
+                    "host_entry_ms_per_call"}
 
 
 class Ctx:
@@ -720,6 +773,9 @@ def main():
                          "host_enqueue_seconds": t_enq, "sclk_mhz": {"before": clk0, "during": clk1, "after": clk2, "pci": pci},
                          "what": f"{n_pass} back-to-back passes of the headline workload ({n_local} walkers), no events, one "
                                  "synchronisation at the end"}
+    dropin = None
+    if world == 1 and headline and not a.no_mcmc:
+        dropin = dropin_leg(g, n_global, max(20, min(a.mcmc_steps, 200)), a.seed, c.dev_index)
     config1 = None
     if world == 1 and headline and not a.no_extra:
         rng1 = np.random.default_rng(a.seed + 24)
@@ -798,6 +854,8 @@ def main():
             out["config1"] = config1
         if mcmc is not None:
             out["ensemble_sampler"] = mcmc
+        if dropin is not None:
+            out["dropin"] = dropin
         if cpu is not None:
             out["cpu_baseline"] = cpu
             out["speedup_vs_cpu_baseline"] = r["value"] / cpu["value"]

@@ -121,7 +121,7 @@ def lib():
     L.mp_destroy.argtypes = [vp]
     L.mp_set_dataset.argtypes = [vp, C.c_int, dp, dp, dp, C.c_int]
     L.mp_set_prior.argtypes = [vp, dp, dp, C.c_int, C.c_uint32]
-    L.mp_lnprob_batch.argtypes = [vp, dp, ip, C.c_int, C.c_int, dp, ip, dp]
+    L.mp_lnprob_batch.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp, vp]   # (host pointers as integers: the hot entry)
     L.mp_lnprob_batch_dev.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]
     L.mp_model_lc.argtypes = [vp, dp, C.c_int, dp, dp, ip]
     L.mp_rhs_batch.argtypes = [vp, dp, C.c_int, dp, dp, C.c_int, dp, dp]
@@ -284,10 +284,12 @@ class Handle:
         lt = np.empty((n, self.tgrid.size), dtype=np.float64) if want_ltot else None
         ids = None
         if ds_id is not None:
-            ids = np.ascontiguousarray(np.broadcast_to(np.asarray(ds_id, dtype=np.int32), (n,)))
-        check(self._L.mp_lnprob_batch(self._h, _dptr(p), _iptr(ids) if ids is not None else None, n, nd,
-                                      _dptr(out), _iptr(st), _dptr(lt) if lt is not None else None),
-              "mp_lnprob_batch")
+            ids = (np.full(n, ds_id, dtype=np.int32) if np.ndim(ds_id) == 0
+                   else np.ascontiguousarray(np.broadcast_to(np.asarray(ds_id, dtype=np.int32), (n,))))
+        rc = self._L.mp_lnprob_batch(self._h, p.ctypes.data, ids.ctypes.data if ids is not None else None, n, nd,
+                                     out.ctypes.data, st.ctypes.data, lt.ctypes.data if lt is not None else None)
+        if rc:
+            check(rc, "mp_lnprob_batch")
         res = (out,)
         if want_status:
             res += (st,)

@@ -83,20 +83,22 @@ struct DevBuf {
 // (pageable user buffers would be staged by the runtime copy by copy).
 struct PinnedBuf {
     unsigned char *p = nullptr;
+    unsigned char *dev = nullptr;   // the same memory as the device sees it (mapped, coherent): kernels may read and write it in place
     size_t cap = 0;
     int ensure(size_t n) {
         if (n <= cap) return MP_OK;
         if (p) (void)hipHostFree(p);
-        p = nullptr;
+        p = dev = nullptr;
         cap = 0;
         const size_t want = std::max<size_t>(n, 4096);
-        HIP_TRY(hipHostMalloc((void **)&p, want, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void **)&p, want, hipHostMallocMapped | hipHostMallocCoherent));
+        HIP_TRY(hipHostGetDevicePointer((void **)&dev, p, 0));
         cap = want;
         return MP_OK;
     }
     void release() {
         if (p) (void)hipHostFree(p);
-        p = nullptr;
+        p = dev = nullptr;
         cap = 0;
     }
 };
@@ -126,8 +128,7 @@ struct mp_handle {
     bool tile_log_on = false;
     DevBuf<int32_t> w_tile_log;
     std::vector<int32_t> last_tile_log;
-    DevBuf<unsigned char> w_io;   // mp_lnprob_batch: [pars | ds_id] in, [lnprob | status | sweeps] out, one copy each way
-    PinnedBuf h_io;
+    PinnedBuf h_io;               // mp_lnprob_batch: [pars | ds_id] in, [lnprob | status | sweeps | tiles] out, read and written in place by the kernel
     double last_mean_sweeps = 0.0;
     std::vector<int32_t> last_sweeps, last_tiles;   // per walker, most recent host-buffer batch (diagnostic)
     // Launch order of mixed-length batches (mp_kernels.hip order_kernel): a ring of index buffers, one per launch in flight.
@@ -481,7 +482,7 @@ int mp_destroy(mp_handle *h) {
     h->d_obs_yerr.release(); h->d_obs_g.release(); h->d_tile_ptr.release(); h->d_ds.release();
     h->w_pars.release(); h->w_lnprob.release(); h->w_curves.release();
     h->w_dsid.release(); h->w_status.release(); h->w_sweeps.release(); h->w_tile_log.release();
-    h->w_io.release(); h->h_io.release();
+    h->h_io.release();
     for (int i = 0; i < mp_handle::kOrderRing; ++i) {
         h->order[i].release();
         if (h->order_done[i]) (void)hipEventDestroy(h->order_done[i]);
@@ -584,21 +585,22 @@ int mp_lnprob_batch(mp_handle *h, const double *pars, const int32_t *ds_id, int 
     }
     DeviceScope scope(h->device);
     const size_t ng = h->tgrid.size();
-    // one staging block each way: [pars n*ndim f64 | ds_id n i32] in, [lnprob n f64 | status n i32 | sweeps n i32] out
+    // One page-locked staging block owned by the handle, mapped into the device's address space: [pars n*ndim f64 | ds_id n i32]
+    // in, [lnprob n f64 | status n i32 | sweeps n i32 | tiles n i32] out.  The kernel reads a walker's 48 - 72 bytes and writes
+    // its 20 bytes IN PLACE over PCIe (round 5): no copy command either way -- one launch and one wait per call where the
+    // two asynchronous copies around the kernel cost as much as the kernel itself.
     const size_t in_pars = sizeof(double) * (size_t)n * ndim, in_ids = ds_id ? sizeof(int32_t) * (size_t)n : 0;
     const size_t in_bytes = (in_pars + in_ids + 7) & ~(size_t)7;
     const size_t out_bytes = (sizeof(double) + 4 * sizeof(int32_t)) * (size_t)n;   // lnprob | status | sweeps | tiles (+ pad)
-    if ((rc = h->w_io.ensure(in_bytes + out_bytes)) || (rc = h->h_io.ensure(in_bytes + out_bytes)) ||
-        (ltot_out && (rc = h->w_curves.ensure((size_t)n * ng))))
+    if ((rc = h->h_io.ensure(in_bytes + out_bytes)) || (ltot_out && (rc = h->w_curves.ensure((size_t)n * ng))))
         return rc;
     hipStream_t st = h->stream;
     std::memcpy(h->h_io.p, pars, in_pars);
     if (ds_id) std::memcpy(h->h_io.p + in_pars, ds_id, in_ids);
-    HIP_TRY(hipMemcpyAsync(h->w_io.p, h->h_io.p, in_pars + in_ids, hipMemcpyHostToDevice, st));
-    unsigned char *d_out = h->w_io.p + in_bytes, *h_out = h->h_io.p + in_bytes;
+    unsigned char *d_out = h->h_io.dev + in_bytes, *h_out = h->h_io.p + in_bytes;
     mp::LaunchArgs a{};
-    a.pars = (const double *)h->w_io.p;
-    a.ds_id = ds_id ? (const int32_t *)(h->w_io.p + in_pars) : nullptr;
+    a.pars = (const double *)h->h_io.dev;
+    a.ds_id = ds_id ? (const int32_t *)(h->h_io.dev + in_pars) : nullptr;
     a.n = n;
     a.ndim = ndim;
     a.physical = 0;
@@ -618,7 +620,6 @@ int mp_lnprob_batch(mp_handle *h, const double *pars, const int32_t *ds_id, int 
         h->last_tile_log.resize((size_t)n * MP_TILE_LOG);
         HIP_TRY(hipMemcpyAsync(h->last_tile_log.data(), h->w_tile_log.p, (size_t)n * MP_TILE_LOG * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     } else h->last_tile_log.clear();
-    HIP_TRY(hipMemcpyAsync(h_out, d_out, out_bytes, hipMemcpyDeviceToHost, st));
     if (ltot_out)
         HIP_TRY(hipMemcpyAsync(ltot_out, h->w_curves.p, sizeof(double) * (size_t)n * ng, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));

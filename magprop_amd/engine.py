@@ -2,6 +2,7 @@
 import contextlib
 import hashlib
 import threading
+import zlib
 
 import numpy as np
 
@@ -21,6 +22,14 @@ def grid(GRBtype=None):
     raise ValueError("Please provide a valid value for GRBtype.\nOptions are: L, S, or None.")
 
 
+def _as_f64(a):
+    """`a` as a contiguous 1-D-compatible float64 ndarray, without a copy where it already is one (pandas: its values)."""
+    v = getattr(a, "values", a)
+    if type(v) is np.ndarray and v.dtype == np.float64 and v.flags.c_contiguous:
+        return v
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
 def _cfg_key(cfg):
     return tuple(getattr(cfg, f[0]) for f in cfg._fields_)
 
@@ -33,14 +42,17 @@ class Engine:
         self._slots = {}      # digest -> slot
         self._order = []      # LRU of digests
         self._prior_key = None
-        self.lock = threading.Lock()
+        self.lock = threading.RLock()   # re-entrant: a thread may call clear() (or evaluate again) inside its own use() block
         self.pins = 0         # callers between use()'s entry and exit (guarded by the module lock): never evicted
 
     def dataset_slot(self, x, y, yerr):
-        x = np.ascontiguousarray(x, dtype=np.float64)
-        y = np.ascontiguousarray(y, dtype=np.float64)
-        yerr = np.ascontiguousarray(yerr, dtype=np.float64)
-        dig = hashlib.blake2b(x.tobytes() + y.tobytes() + yerr.tobytes(), digest_size=16).digest()
+        """Slot of the light curve (x, y, yerr) on this handle, registering it on first sight.  Content-addressed: the same
+        numbers give the same slot whatever object carries them, and an array changed in place is a new light curve.  The
+        digest is taken over the arrays' own buffers where they are float64 and contiguous (numpy arrays, pandas Series as
+        the reference driver passes them: code/synthetic_datasets/synth_mcmc.py:170-172) -- a repeated call costs three
+        checksums, no copy (round 5: the conversions and the hash of copies were a third of the host entry's Python time)."""
+        x, y, yerr = _as_f64(x), _as_f64(y), _as_f64(yerr)
+        dig = (x.size, y.size, yerr.size, zlib.crc32(x), zlib.adler32(x), zlib.crc32(y), zlib.adler32(y), zlib.crc32(yerr), zlib.adler32(yerr))
         slot = self._slots.get(dig)
         if slot is None:
             if len(self._order) >= _capi.MAX_DATASETS:
@@ -56,8 +68,7 @@ class Engine:
         return slot
 
     def set_prior(self, lower, upper, log_mask):
-        key = (None if lower is None else (tuple(np.asarray(lower, float)), tuple(np.asarray(upper, float))),
-               int(log_mask))
+        key = (None if lower is None else (np.asarray(lower, float).tobytes(), np.asarray(upper, float).tobytes()), int(log_mask))
         if key != self._prior_key:
             self.handle.set_prior(lower, upper, log_mask)
             self._prior_key = key
@@ -67,7 +78,7 @@ def engine(cfg, GRBtype=None, device=-1, _pin=False):
     """Cached Engine for (model configuration, grid, device).  The least recently used engines beyond MAX_ENGINES are
     closed, except those a caller currently holds through use().  Front ends that evaluate go through use(); a bare
     engine() is a look-up for single-threaded callers (tests, introspection)."""
-    key = (_cfg_key(cfg), "S" if GRBtype == "S" else "L", int(device))
+    key = (cfg.__dict__.get("_mp_key") or _cfg_key(cfg), "S" if GRBtype == "S" else "L", int(device))   # (_mp_key: set by the front ends on configurations they cache and never modify)
     with _lock:
         e = _handles.pop(key, None)
         if e is None:
@@ -80,25 +91,34 @@ def engine(cfg, GRBtype=None, device=-1, _pin=False):
         return e
 
 
+def acquire(cfg, GRBtype=None, device=-1):
+    """The cached Engine, pinned against eviction and with its lock held; pair with release() (what `use` does)."""
+    while True:
+        e = engine(cfg, GRBtype, device, _pin=True)  # look-up (or creation) and pin in one critical section
+        e.lock.acquire()
+        if getattr(e.handle, "_h", True) is not None:
+            return e
+        e.lock.release()                             # closed by clear() while this thread waited: take a fresh one
+        with _lock:
+            e.pins -= 1
+
+
+def release(e):
+    e.lock.release()
+    with _lock:
+        e.pins -= 1
+
+
 @contextlib.contextmanager
 def use(cfg, GRBtype=None, device=-1):
     """`with engine.use(cfg, ...) as eng:` — the cached Engine, pinned against eviction and with its lock held for the
     duration of the block (the pin is taken under the module lock, so another thread's engine() for a ninth
     configuration can never close the handle between look-up and use; the module lock is not held while waiting)."""
-    while True:
-        e = engine(cfg, GRBtype, device, _pin=True)  # look-up (or creation) and pin in one critical section
-        e.lock.acquire()
-        if getattr(e.handle, "_h", True) is not None:
-            break
-        e.lock.release()                             # closed by clear() while this thread waited: take a fresh one
-        with _lock:
-            e.pins -= 1
+    e = acquire(cfg, GRBtype, device)
     try:
         yield e
     finally:
-        e.lock.release()
-        with _lock:
-            e.pins -= 1
+        release(e)
 
 
 def clear():
@@ -106,7 +126,9 @@ def clear():
     thread has left its block: the cache forgets all engines at once, under the module lock, and then each one's own lock is
     taken before its handle is destroyed (use() holds that lock for the whole block; mp_destroy on a handle in use would be a
     use-after-free on the native side).  A thread that was still waiting for the engine's lock finds it closed and looks up a
-    fresh one (use() above)."""
+    fresh one (use() above).  The engines' locks are re-entrant: a thread that calls clear() INSIDE its own `with use(...)`
+    block (a cleanup helper, a test fixture) does not wait for itself -- its engine is closed then and there, and what the
+    block does with it afterwards raises instead of touching freed memory."""
     with _lock:
         engines = list(_handles.values())
         _handles.clear()

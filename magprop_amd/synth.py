@@ -13,16 +13,33 @@ PRIOR_LOWER = np.array([1.0e-3, 0.69, -6.0, np.log10(50.0), -2.0, -1.0])  # :41
 LOG_MASK = 0b111100                                                       # arr[2:] = 10**arr[2:]  (:16-17)
 
 
+_cfg_cache = {}
+
+
+def _cfg():
+    """The synthetic variant's model configuration (one object per pair of solver defaults in force: building the ctypes
+    structure and its cache key costs more than the rest of a call's Python)."""
+    key = (_capi.DEFAULT_SWEEP_TOL, _capi.DEFAULT_MAX_STRIDE)
+    c = _cfg_cache.get(key)
+    if c is None:
+        c = _cfg_cache[key] = _capi.cfg_synth()
+        c._mp_key = engine._cfg_key(c)
+    return c
+
+
 def _evaluate(pars, x, y, yerr, lower, upper, device=-1, want_status=False):
     p = np.asarray(pars, dtype=np.float64)
     scalar = p.ndim == 1
     p2 = np.atleast_2d(p)
     if p2.shape[1] != 6:
         raise ValueError("pars must have 6 entries: B, P, log10 MdiscI, log10 RdiscI, log10 epsilon, log10 delta")
-    with engine.use(_capi.cfg_synth(), None, device) as eng:
+    eng = engine.acquire(_cfg(), None, device)      # (what `with engine.use(...)` does, without the generator: this is the hot entry)
+    try:
         slot = eng.dataset_slot(x, y, yerr)
         eng.set_prior(lower, upper, LOG_MASK)
         out, st = eng.handle.lnprob_batch(p2, ds_id=slot, want_status=True)
+    finally:
+        engine.release(eng)
     if scalar:
         return (float(out[0]), int(st[0])) if want_status else float(out[0])
     return (out, st) if want_status else out

@@ -1,5 +1,6 @@
-"""Wall time per call of the host-buffer entry (numpy in, numpy out: PCIe both ways + synchronisation), the path
-`emcee.EnsembleSampler(..., vectorize=True)` drives.  python tools/host_entry_time.py [--reps 200]"""
+"""Wall time per call of the host-buffer entries (numpy in, numpy out: PCIe both ways + synchronisation), the path
+`emcee.EnsembleSampler(..., vectorize=True)` drives, next to the kernel time of the same rows (device-pointer entry).
+    python tools/host_entry_time.py [--reps 200]"""
 import argparse
 import os
 import sys
@@ -14,19 +15,43 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=200)
     a = ap.parse_args()
+    import pandas as pd
+    import torch
+
     import magprop_amd as mpa
     g = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "golden_synth.npz"))
-    lp = mpa.LogProb(g["Humped_x"], g["Humped_y"], g["Humped_yerr"])
+    x, y, yerr = g["Humped_x"], g["Humped_y"], g["Humped_yerr"]
+    xs, ys, es = pd.Series(x), pd.Series(y), pd.Series(yerr)
+    lp = mpa.LogProb(x, y, yerr)
     rng = np.random.default_rng(1)
-    for n in (24, 512, 1024, 4096):
-        P = np.array([1.0, 5.0, -3.0, 2.0, -1.0, 0.0]) + 1.0e-4 * rng.standard_normal((n, 6))
+
+    def timed(f):
         for _ in range(10):
-            lp(P)
+            f()
         t0 = time.perf_counter()
         for _ in range(a.reps):
-            lp(P)
-        dt = (time.perf_counter() - t0) / a.reps
-        print(f"n={n:5d}  {dt * 1e3:.4f} ms/call  {n / dt:,.0f} evals/s", flush=True)
+            f()
+        return (time.perf_counter() - t0) / a.reps * 1e3
+
+    for n in (24, 256, 512, 1024, 4096):
+        P = np.array([1.0, 5.0, -3.0, 2.0, -1.0, 0.0]) + 1.0e-4 * rng.standard_normal((n, 6))
+        dP = torch.from_numpy(P).cuda()
+        out = torch.empty(n, dtype=torch.float64, device="cuda")
+        for _ in range(10):
+            lp.lnprob_device(dP, out=out)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(a.reps):
+            lp.lnprob_device(dP, out=out)
+        e1.record()
+        torch.cuda.synchronize()
+        k = e0.elapsed_time(e1) / a.reps
+        t_obj = timed(lambda: lp(P))
+        t_np = timed(lambda: mpa.synth.lnprob(P, x, y, yerr, None))
+        t_pd = timed(lambda: mpa.synth.lnprob(P, xs, ys, es, None))
+        print(f"n={n:5d}  kernel {k:.4f} ms | LogProb.__call__ {t_obj:.4f} ms | synth.lnprob (ndarray args) {t_np:.4f} ms | "
+              f"synth.lnprob (pandas Series args) {t_pd:.4f} ms", flush=True)
 
 
 if __name__ == "__main__":
