@@ -327,7 +327,13 @@ enum {
     MP_POLICY_TROUBLE_LIMIT,         /* failed coarse attempts after which stride 8 is no longer tried         */
     MP_POLICY_STOP_FACTOR,           /* MP_STOP_FACTOR: estimated next correction / sweep_tol that ends a tile  */
     MP_POLICY_FORCED_STEPS_PER_LANE, /* 0 = by batch size                                                      */
-    MP_POLICY_EXPERIMENTS,           /* 1: developer build that honours MAGPROP_AMD_* environment overrides    */
+    MP_POLICY_EXPERIMENTS,           /* 1: developer build that honours MAGPROP_AMD_* environment overrides, or a build */
+                                     /*    whose compile-time policy constants (the five below) were overridden with -D  */
+    MP_POLICY_LIGHT_TOL,             /* correction below which the next sweep keeps the Jacobian and the weights         */
+    MP_POLICY_CUT_BY_RATIO,          /* lanes behind a cut over which a fast feature's excess picks the next stride     */
+    MP_POLICY_ABORT_SKIP_RATIO,      /* excess over the bound beyond which a given-up coarse tile skips a stride         */
+    MP_POLICY_LOGPRED_MIN_KIND,      /* tile kinds from this one on start from the log-space extrapolation               */
+    MP_POLICY_PRE_EARLY_END_FACTOR,  /* 65 536 x 100: the calm-first-tile test of the 128-step kernels' sub-stepped start */
     MP_POLICY_COUNT
 };
 int mp_get_policy(const mp_handle *h, double *out, int n);

@@ -32,7 +32,8 @@ EXPORTS = (
 ABI_VERSION = 4
 # order of mp_get_policy()'s vector (include/magprop_amd.h MP_POLICY_*)
 POLICY_FIELDS = ("max_stride", "stride_tol", "sweep_tol", "early_hold_seconds", "k4_tol_factor", "coarse_tol_factor",
-                 "coarse_max_sweeps", "fine_max_sweeps", "trouble_limit", "stop_factor", "forced_steps_per_lane", "experiments_build")
+                 "coarse_max_sweeps", "fine_max_sweeps", "trouble_limit", "stop_factor", "forced_steps_per_lane", "experiments_build",
+                 "light_tol", "cut_by_ratio", "abort_skip_ratio", "logpred_min_kind", "pre_early_end_factor")
 
 
 class MagpropAmdError(RuntimeError):

@@ -1201,8 +1201,13 @@ int mp_get_policy(const mp_handle *h, double *out, int n) {
 #ifdef MP_EXPERIMENTS
     v[MP_POLICY_EXPERIMENTS] = 1.0;
 #else
-    v[MP_POLICY_EXPERIMENTS] = 0.0;
+    v[MP_POLICY_EXPERIMENTS] = (MP_POLICY_MACROS_MODIFIED) ? 1.0 : 0.0;   // a -D build of the policy macros is an experiments build too
 #endif
+    v[MP_POLICY_LIGHT_TOL] = MP_LIGHT_TOL;
+    v[MP_POLICY_CUT_BY_RATIO] = (double)MP_CUT_BY_RATIO;
+    v[MP_POLICY_ABORT_SKIP_RATIO] = MP_ABORT_SKIP_RATIO;
+    v[MP_POLICY_LOGPRED_MIN_KIND] = (double)MP_LOGPRED_MIN_KIND;
+    v[MP_POLICY_PRE_EARLY_END_FACTOR] = MP_PRE_EARLY_END_FACTOR;
     const int m = std::min(n, (int)MP_POLICY_COUNT);
     std::copy(v, v + m, out);
     return m;

@@ -152,6 +152,40 @@ struct StretchArgs {
     uint64_t ens_order;     // half-step launches: ensemble at position p of the launch = (ens_order >> 4p) & 15; 0 = identity
 };
 
+// ---------------------------------------------------------------- compile-time constants of the stride policy
+// (used by mp_eval.hpp; reported by mp_get_policy so that an A/B build made with -D overrides cannot pass for the shipped one)
+// Tile kinds from this one on start their sweeps from the log-space extrapolation (5: none).  Tiles of 256 steps (4 steps
+// per lane) over 2, 4, 8 grid intervals reach 0.6 - 1.2 decades ahead; at 128 steps (2 steps per lane) the quartic in the
+// index is as good and cheaper (same-box A/B, profiles/r04_ab_predictor.log: 4 096 near-truth walkers +3 % slower with it).
+#ifndef MP_LOGPRED_MIN_KIND
+#define MP_LOGPRED_MIN_KIND 2
+#endif
+#ifndef MP_ABORT_SKIP_RATIO
+#define MP_ABORT_SKIP_RATIO 32.0   // excess of the indicator over its bound beyond which a given-up coarse tile skips a stride
+#endif
+// A coarse tile that is cut at a fast feature of the solution (no kink) is followed by the stride its excess over the bound
+// asks for, judged over this many lanes from the cut on (0: always single intervals, as until round 3)
+#ifndef MP_CUT_BY_RATIO
+#define MP_CUT_BY_RATIO 24
+#endif
+// 2-steps-per-lane kernels, adaptive stride: the sub-stepped start ends after its first tile (16 grid intervals) when that tile's
+// indicator, scaled to a step of a whole interval (8^5 with the margin of 2 = 65 536) and held to a HUNDREDTH of the bound
+// (MP_PRE_EARLY_END_FACTOR = 65 536 x 100; a tenth raised the soak's maximum from 5.6e-8 to 8.0e-8 for 1 % more speed:
+// profiles/r04_ab_substeps_spl2.log), stays below the bound everywhere and no kink lies in it.  (Simply halving the sub-stepped stretch put one
+// golden point -- a spin-up transient at t = 1 s -- at 1.01 of the tight bound in the serial restatement: tests/test_oracle.py.)
+// Corrections below this (relative) let the next sweep keep the Jacobian, e^{h lambda} and the weights ("light" sweep).  1e-4
+// until the tiles ended on the contraction estimate; scanned then on one box (profiles/r04_ab_light_tol.log): 3e-4 / 1e-3 / 3e-3 /
+// 1e-2 speed up the passes near the truths by 0.7 / 1.3 / 1.3 / 2 %, and from 3e-3 on the slowest prior-wide walkers need
+// more sweeps (chord iterations stall where the Jacobian changes from step to step): 0.228 -> 0.220 -> 0.239 ms.
+#ifndef MP_LIGHT_TOL
+#define MP_LIGHT_TOL 1.0e-3
+#endif
+#ifndef MP_PRE_EARLY_END_FACTOR
+#define MP_PRE_EARLY_END_FACTOR 6553600.0
+#endif
+// 1 if any of the above differs from its shipped value (mp_get_policy()[MP_POLICY_EXPERIMENTS] is then set as for MP_EXPERIMENTS)
+#define MP_POLICY_MACROS_MODIFIED (MP_LOGPRED_MIN_KIND != 2 || MP_ABORT_SKIP_RATIO != 32.0 || MP_CUT_BY_RATIO != 24 || MP_LIGHT_TOL != 1.0e-3 || MP_PRE_EARLY_END_FACTOR != 6553600.0)
+
 // Steps per lane of the kernel variant used for a batch of n walkers (tiles are 64*spl steps): see launch_lnprob.
 // Up to one wave per SIMD (256 CUs x 4 on MI355X) four steps per lane; beyond, two resident waves win (tools/spl_scan.sh).
 inline int kernel_spl(const DevShared &sh, int n) { return n <= sh.n_simd ? 4 : 2; }

@@ -29,6 +29,12 @@ class ShardedLnprob:
     without making the compute stream wait for it, so the next independent batch's kernel overlaps the collective
     (two batches in flight, double-buffered; the tensor returned by finish() stays valid until the second start() after
     it).  Dependent batches (the two half-steps of one stretch move) have nothing to overlap and use the blocking form.
+
+    Slot reuse is ordered explicitly: a slot remembers the collective that last read its send buffer (and wrote its receive
+    buffer), and the start() that takes the slot again -- two passes later -- lets its stream wait for that collective
+    before the kernel rewrites the buffer, UNLESS it has completed already (the normal case: one host-side poll, no
+    cross-queue wait).  Without this nothing would order kernel i+2 behind all-gather i once finish() waits on a consumer
+    stream instead of the compute stream: a rank running ahead of a slow peer would send pass i+2 values labelled pass i.
     """
 
     def __init__(self, eval_local, group=None, via_host=False, writes_out=False, always_gather=False):
@@ -39,7 +45,7 @@ class ShardedLnprob:
         self.always_gather = always_gather   # run the collective even in a group of one (exercises RCCL on a 1-GPU box)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        self._slots = [None, None]    # per slot: (key, send buffer [per], receive buffer [per * world])
+        self._slots = [None, None]    # per slot: [key, send buffer [per], receive buffer [per * world], last collective on it]
         self._k = 0
 
     def _buffers(self, n, per, device):
@@ -47,11 +53,17 @@ class ShardedLnprob:
         self._k ^= 1
         key = (n, per, str(device))
         slot = self._slots[k]
+        if slot is not None and slot[3] is not None:
+            # the collective that used this slot two passes ago may still be reading the send buffer (a slow peer): the
+            # stream about to rewrite it waits for that collective -- only if it is really still in flight
+            if not slot[3].is_completed():
+                slot[3].wait()
+            slot[3] = None
         if slot is None or slot[0] != key:
             local = torch.full((per,), float("-inf"), dtype=torch.float64, device=device)   # a short tail block stays -inf
-            slot = (key, local, torch.empty(per * self.world, dtype=torch.float64, device=device))
+            slot = [key, local, torch.empty(per * self.world, dtype=torch.float64, device=device), None]
             self._slots[k] = slot
-        return slot[1], slot[2]
+        return slot[1], slot[2], slot
 
     def start(self, pars, recv=None):
         """recv: optional caller-owned float64 tensor that receives the full lnprob vector (at least
@@ -63,7 +75,7 @@ class ShardedLnprob:
                 return None, recv, n
             return None, self.eval_local(pars), n
         lo, hi, per = shard_range(n, self.rank, self.world)
-        local, buf = self._buffers(n, per, pars.device)
+        local, buf, slot = self._buffers(n, per, pars.device)
         if recv is not None:
             buf = recv[: per * self.world]
         if hi > lo:
@@ -77,6 +89,7 @@ class ShardedLnprob:
             buf.copy_(hbuf)
             return None, buf, n
         work = dist.all_gather_into_tensor(buf, local, group=self.group, async_op=True)
+        slot[3] = work
         return work, buf, n
 
     @staticmethod

@@ -411,6 +411,7 @@ typedef struct {
 
 #define MPO_PRE_FINE 32   /* grid intervals covered by the sub-stepped tiles */
 #define MPO_PRE_SUB 8     /* sub-steps per grid interval there */
+#define MPO_PRE_EARLY_END_FACTOR 6553600.0   /* mp_device.h MP_PRE_EARLY_END_FACTOR: 65 536 x 100, the calm-first-tile test holds the scaled indicator to a HUNDREDTH of the bound */
 #define MPO_EARLY_HOLD_SECONDS 4.0   /* coarse tiles starting before this time are held to a tenth of stride_tol */
 #define MPO_MIN_KEEP 8    /* a coarse tile is kept if at least this many lanes precede the first offending one */
 #define MPO_CUT_WINDOW 24 /* lanes from a cut on over which the excess of the indicator decides the next stride (mp_eval.hpp MP_CUT_BY_RATIO) */
@@ -643,11 +644,11 @@ int mpo_trajectory_mode(const mpo_cfg *c, const double *pars, int ndim, const do
             if (next_s > max_stride) next_s = max_stride;
         }
         /* 128-step tiles (spl < 4), adaptive stride: the sub-stepped start ends after a tile that was calm -- its indicator scaled
-           to a step of a whole interval (8^5, margin 2: 65 536) and held to a tenth stays below the bound everywhere, no kink in
+           to a step of a whole interval (8^5, margin 2: 65 536) and held to a hundredth stays below the bound everywhere, no kink in
            it (mp_eval.hpp MP_PRE_EARLY_END) */
         if (pre && mode == 1 && spl < 4 && max_stride > 1 && keep == nc && nc == TILE && sub_done + keep < pre_fine * MPO_PRE_SUB) {
             int calm = 1;
-            for (int e = 0; e < keep; ++e) if (brk[e] || 6553600.0 * ind[e] > stride_tol) calm = 0;
+            for (int e = 0; e < keep; ++e) if (brk[e] || MPO_PRE_EARLY_END_FACTOR * ind[e] > stride_tol) calm = 0;
             if (calm) pre_fine = (sub_done + keep) / MPO_PRE_SUB;
         }
         if (pre) {

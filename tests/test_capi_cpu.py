@@ -41,6 +41,12 @@ def test_python_mirror_follows_the_header_constants():
     names = re.findall(r"MP_POLICY_([A-Z0-9_]+)", body)[:-1]
     alias = {"FORCED_STEPS_PER_LANE": "forced_steps_per_lane", "EXPERIMENTS": "experiments_build"}
     assert [alias.get(n, n.lower()) for n in names] == list(_capi.POLICY_FIELDS)
+    # the compile-time policy constants: one definition (mp_device.h), mirrored by name in the serial restatement
+    dev = open(os.path.join(ROOT, "magprop_amd", "csrc", "mp_device.h")).read()
+    orc = open(os.path.join(ROOT, "oracle", "mp_oracle.c")).read()
+    pre = float(re.search(r"#define\s+MP_PRE_EARLY_END_FACTOR\s+([0-9.eE+-]+)", dev).group(1))
+    assert pre == float(re.search(r"#define\s+MPO_PRE_EARLY_END_FACTOR\s+([0-9.eE+-]+)", orc).group(1)) == 65536.0 * 100.0
+    assert "6553600.0 *" not in orc                           # (the literal is gone from the oracle's code)
 
 
 def test_cfg_struct_layout_and_presets():

@@ -80,6 +80,50 @@ def test_sharded_lnprob_gloo_world2(n):
         assert sum(calls) == shard_range(n, rank, 2)[1] - shard_range(n, rank, 2)[0]
 
 
+def _skew_worker(rank, world, port, q):
+    """Five independent passes started back to back, finished late, with rank 1 arriving LATE at every collective: rank 0
+    runs ahead and takes send slot k again (pass i + 2) while all-gather i is still waiting for the slow peer."""
+    import time
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n = 64
+    passes = [torch.full((n, 6), float(i + 1), dtype=torch.float64) for i in range(5)]
+
+    def eval_out(p, out):
+        if rank == 1:
+            time.sleep(0.15)                  # the slow peer
+        out.copy_(p[:, 0] * 10.0 + rank)      # pass number and rank readable from every value
+
+    sh = ShardedLnprob(eval_out, writes_out=True)
+    recv = [torch.zeros(n, dtype=torch.float64) for _ in passes]
+    tickets = [sh.start(p, recv=r) for p, r in zip(passes, recv)]    # all five in flight before the first finish
+    got = [sh.finish(t).clone() for t in tickets]
+    per = n // world
+    ok = all(torch.equal(g[r * per:(r + 1) * per], torch.full((per,), (i + 1) * 10.0 + r, dtype=torch.float64))
+             for i, g in enumerate(got) for r in range(world))
+    q.put((rank, ok, [g[::per].tolist() for g in got]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_slot_reuse_waits_for_a_collective_still_in_flight():
+    """with finish() waiting on a consumer stream nothing ordered kernel i+2 (which rewrites send slot k)
+    behind all-gather i (which reads it).  A rank that runs ahead of a slow peer must still deliver pass i's values."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29300 + os.getpid() % 150
+    procs = [ctx.Process(target=_skew_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, seen in res:
+        assert ok, (rank, seen)
+
+
 # ---------------------------------------------------------------- sharded stretch-move sampler
 # The product engine is the HIP sampler (tests/test_gpu_sampler.py runs it across two processes on the GPU box); here the
 # SAME driver class runs the numpy restatement of the shard / gather / commit protocol over gloo.

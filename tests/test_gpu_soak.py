@@ -19,10 +19,11 @@ STRICT = 1.0e-11   # MP_SWEEP_TOL_STRICT: the kernels against the serial restate
 TUNING_SEED = 20261003
 FRESH_SEED = int(os.environ.get("MAGPROP_SOAK_SEED", "77120264"))
 # Product defaults (adaptive stride, sweep tolerance 1e-7) against the fixed-step scheme (C oracle mode 0).  Round 4, both
-# seeds, 32 768 walkers: max 4.5e-8 / 4.8e-8, 99.9 % below 8e-9 (profiles/r04_soak_parity.json) -- asserted at 1e-7, a
-# margin of 2.  The maximum of a sample grows with its size (round 3, 262 144 walkers: 7.3e-8): larger runs
-# (MAGPROP_SOAK_N) are held to the documented bound of 2e-7.
-DEFAULTS_VS_FIXED_MAX, DEFAULTS_VS_FIXED_P999 = (1.0e-7 if N_SOAK <= 65536 else 2.0e-7), 2.0e-8
+# seeds, 32 768 walkers: max 4.5e-8 / 4.8e-8, 99.9 % below 8e-9 (profiles/r04_soak_parity.json) -- asserted at 1e-7, the
+# bound the API documents, at EVERY sample size (round 4's 262 144-walker runs reach 7.2e-8; until round 5 runs beyond 65 536
+# walkers were held to 2e-7 only, which would have let a regression of nearly 3 x the observed maximum pass in exactly the
+# runs that probe the tail), and the 99.99th percentile at 5e-8 so that tail growth shows before the maximum does.
+DEFAULTS_VS_FIXED_MAX, DEFAULTS_VS_FIXED_P999, DEFAULTS_VS_FIXED_P9999 = 1.0e-7, 2.0e-8, 5.0e-8
 
 
 def _walkers(rng, n, lo, hi):
@@ -113,6 +114,8 @@ def test_every_kernel_variant_against_the_c_oracle(gsynth, tarr, seed):
         # scheme's own deviation from the reference's tight-integrator values), 99.9 % of the walkers below 2e-8
         assert rel.max() <= (DEFAULTS_VS_FIXED_MAX if loose else 1e-9), summary["variants"][label]
         assert np.quantile(rel, 0.999) <= (DEFAULTS_VS_FIXED_P999 if loose else 1e-10), summary["variants"][label]
+        if loose:
+            assert np.quantile(rel, 0.9999) <= DEFAULTS_VS_FIXED_P9999, summary["variants"][label]
     out_dir = os.path.join(os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(__file__))), "gpurun_out")
     if os.path.isdir(out_dir):
         with open(os.path.join(out_dir, f"soak_parity_seed{seed}.json"), "w") as f:
