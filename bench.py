@@ -22,9 +22,13 @@ slices follows so every rank sees the full ensemble (what the stretch move needs
 the timed region (generated on device, replicated on every rank from a common seed).
 
 Prints one JSON line on rank 0 (contract in the task description) with extra objects:
-  roofline         the lnprob kernel's algorithmic HBM bytes / measured kernel time vs the 8 TB/s peak.  This path is
-                   NOT HBM-bound (and has no MFMA work): it is a latency-bound fp64 VALU recurrence; "valu" prices the
-                   same kernel against the fp64 vector peak with the flops the PMC counters saw (profiles/).
+  roofline         what binds the lnprob kernel.  Mode A moves 60 algorithmic bytes per evaluation, so its HBM fraction is
+                   ~1e-4 by construction (kept as roofline.hbm) and there is no MFMA work: the line prices the kernel against
+                   the fp64 VECTOR peak with the flops the PMC counters saw (profiles/pmc_figures.json, `stale` if those
+                   were collected on another build) and carries roofline.latency, the cycles one walker keeps a wavefront
+                   resident: the floor of every launch of up to n_simd walkers.  Mode B (--curve) is priced against HBM.
+  predicted        what one-GPU kernel times predict for N GPUs (weak and strong; profiles/scaling_inputs.json): the first
+                   8-GPU run is to be read against it.  Also printed by --dry-run.
   configs          the other BASELINE workloads through the same timed loop, shorter: N = 1: configs 3, 4 (8 192 walkers
                    on one GPU), 5 and mode B ("curve": config 2 with the model light curve written to HBM); N > 1: configs
                    4 and 5 with their fixed totals sharded over the N GPUs (strong scaling).
@@ -95,6 +99,74 @@ def usable_cores():
     except (OSError, ValueError):
         pass
     return max(1, min(n, 64))
+
+
+def csrc_hash():
+    """16 hex digits over the sources the kernels are built from (include/magprop_amd.h + magprop_amd/csrc/*): what ties
+    profiles/pmc_figures.json and profiles/scaling_inputs.json (counters and kernel times of ONE build) to the build that
+    runs.  tools/collect_profiles.py and tools/scaling_inputs.py store it; a mismatch is reported as `stale`."""
+    import hashlib
+    h = hashlib.sha256()
+    files = [os.path.join(ROOT, "include", "magprop_amd.h")] + sorted(
+        f for f in glob.glob(os.path.join(ROOT, "magprop_amd", "csrc", "*")) if f.endswith((".h", ".hpp", ".hip", ".cpp")))
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0" + open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def _interp_ms(table, n):
+    """Kernel time of a launch of n walkers from a {walkers: ms} table (log-log between the measured sizes, flat outside)."""
+    pts = sorted((int(k), float(v)) for k, v in table.items())
+    if n <= pts[0][0]:
+        return pts[0][1]
+    if n >= pts[-1][0]:
+        return pts[-1][1] * n / pts[-1][0]          # beyond the table the device is full: time grows with the walkers
+    for (a, ta), (b, tb) in zip(pts, pts[1:]):
+        if a <= n <= b:
+            w = (np.log(n) - np.log(a)) / (np.log(b) - np.log(a))
+            return float(np.exp((1 - w) * np.log(ta) + w * np.log(tb)))
+
+
+def predicted_scaling(world):
+    """What ONE-GPU measurements predict for `world` GPUs (no multi-GPU hardware is available to the builder: the driver's
+    8-GPU run is the first; its line is to be read against this).  Inputs: profiles/scaling_inputs.json -- kernel time
+    against launch size on one MI355X (tools/scaling_inputs.py) -- and the cost of keeping one RCCL all-gather per pass in
+    flight, +8.5 % per pass (measured in a group of one with the real torch.distributed path, profiles/r04_rccl_overlap.md).
+    A prediction, not evidence."""
+    try:
+        inp = json.load(open(os.path.join(ROOT, "profiles", "scaling_inputs.json")))
+    except Exception:  # noqa: BLE001
+        return None
+    ov = float(inp.get("collective_overhead_frac", 0.085))
+    near, c5 = inp["lnprob_near_truth_ms"], inp["config5_ms"]
+
+    def leg(total, table, weak):
+        per = total if weak else -(-total // world)
+        n_all = per * world if weak else total
+        # the one-GPU line it is compared with: weak -- the N = 1 run of the same per-GPU load (what the driver's
+        # value(N) / value(1) measures); strong -- the same total on one GPU
+        n_one = per if weak else n_all
+        v1 = n_one / _interp_ms(table, n_one) * 1e3
+        tN = _interp_ms(table, per) * (1.0 + (ov if world > 1 else 0.0))
+        vN = n_all / tN * 1e3
+        return {"walkers_per_gpu": per, "walkers_total": n_all, "kernel_ms_of_the_share": _interp_ms(table, per),
+                "ms_per_pass": tN, "evals_per_sec": vN, "one_gpu_walkers": n_one, "one_gpu_evals_per_sec": v1,
+                "speedup_vs_one_gpu": vN / v1}
+    out = {"inputs": "profiles/scaling_inputs.json", "inputs_build": inp.get("build"), "inputs_stale": inp.get("build") != csrc_hash(),
+           "collective_overhead_frac": ov, "n_gpus": world,
+           "weak_config2_1024_per_gpu": leg(1024, near, True), "strong_config4_8192_total": leg(8192, near, False),
+           "strong_config5_4096_total": leg(4096, c5, False),
+           "claim": "north star '>= 6x at 8 GPUs': claimed on WEAK scaling -- value(8 GPUs x 1 024 walkers) / value(1 GPU x 1 024 "
+                    "walkers), the ratio the driver forms from bench.py's per-N lines (BASELINE configs[3] is 8 x 1 024 = 8 192 "
+                    "walkers); predicted 8 / (1 + collective overhead).  The same 8 192 walkers against ONE GPU holding all of "
+                    "them (strong scaling, strong_config4_8192_total) is predicted BELOW 6x: one GPU runs 8 192 walkers two "
+                    "wavefronts per SIMD at a higher rate (18 M/s) than 1 024 walkers one per SIMD (13 M/s)",
+           "note": "a prediction from one-GPU kernel times; nothing multi-GPU has been measured by the builder"}
+    if world == 1:
+        p8 = predicted_scaling(8)
+        out["at_8_gpus"] = {k: {"speedup_vs_one_gpu": p8[k]["speedup_vs_one_gpu"], "evals_per_sec": p8[k]["evals_per_sec"]}
+                            for k in ("weak_config2_1024_per_gpu", "strong_config4_8192_total", "strong_config5_4096_total")}
+    return out
 
 
 # ---------------------------------------------------------------- CPU legs (before this process touches the GPU: they fork)
@@ -448,8 +520,11 @@ def run_passes(c, config, scaling, steps, warmup, curve=False, nwalk=None, grb=N
     dt = float(tmax.item())
     kern_ms = np.array([ev0[i].elapsed_time(ev1[i]) for i in range(warmup, total) if i % EVENT_EVERY == 0 or i == warmup])
     n_simd = lp.handle.n_simd
-    variant = ("curve kernel, " if curve else "") + ("4 steps per lane, one wavefront per SIMD" if n_local <= n_simd
-                                                      else "2 steps per lane, two wavefronts per SIMD")
+    if not curve and config != 5 and 2 * n_local <= n_simd:
+        variant = "team of four wavefronts per walker (one step per lane each), " + ("one" if 4 * n_local <= n_simd else "two") + " per SIMD"
+    else:
+        variant = ("curve kernel, " if curve else "") + ("4 steps per lane, one wavefront per SIMD" if n_local <= n_simd
+                                                          else "2 steps per lane, two wavefronts per SIMD")
     variant += "; order-5 exponential Adams-Moulton, steps over 1/2/4/8 grid intervals (adaptive)"
     if config == 5:
         workload = (f"BASELINE config 5: four GRB types x {n_global // 4} walkers at truth+{a.spread:g}*randn, {len(n_obs_desc)} light "
@@ -475,18 +550,36 @@ def run_passes(c, config, scaling, steps, warmup, curve=False, nwalk=None, grb=N
     achieved = bytes_eval * n_local / kavg / 1e9
     fig = c.pmc.get("curve" if curve else ("config5" if config == 5 else "lnprob"), {}).get(str(n_local), {})
     traffic, flops = fig.get("traffic_bytes"), fig.get("fp64_flops")
+    stale = c.pmc.get("build") != csrc_hash()       # the counters were collected on another build than the one that runs
+    hbm = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+           "traffic": traffic, "algorithmic_bytes_per_eval": bytes_eval}
+    common = {"kernel": "mp::lnprob_team_kernel" if variant.startswith("team") else "mp::lnprob_kernel",
+              "kernel_ms_avg": 1e3 * kavg, "kernel_ms_min": float(kern_ms.min()),
+              "kernel_ms_max_over_ranks": float(np.nanmax(k_ranks)), "kernel_ms_min_over_ranks": float(np.nanmin(k_ranks)),
+              "algorithmic_bytes_per_eval": bytes_eval, "evals_per_launch": n_local}
+    if hbm["frac"] < 0.01 and flops is not None:
+        # Mode A moves 60 bytes per evaluation: the HBM fraction is ~1e-4 by construction and says nothing.  What binds is
+        # the fp64 vector unit's issue (and, with one wavefront per SIMD, the latency of one walker's dependent chain).
+        cyc = fig.get("wave_cycles_per_wave")
+        roofline = {"bound": "fp64_valu", "achieved": flops / kavg / 1e12, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": flops / kavg / 1e12 / FP64_VALU_PEAK_TFLOPS, "traffic": traffic, "stale": stale, "hbm": hbm,
+                    "latency": None if cyc is None else {
+                        "wave_cycles_per_walker": cyc, "ms_at_2.4_GHz": cyc / 2.4e6,
+                        "note": "cycles one wavefront is resident for one walker (PMC, mean): the floor of any launch of up to "
+                                "n_simd walkers, whatever the rate of the vector unit"},
+                    "note": "fp64 flops executed (PMC: 64 x (2 FMA + MUL + ADD) instructions, profiles/pmc_figures.json) / kernel "
+                            "time measured here vs the fp64 vector peak; HBM (roofline.hbm) does not bind: 60 algorithmic bytes "
+                            "per evaluation", **common}
+    else:
+        roofline = dict(hbm, stale=stale, note="mode B streams the model light curve to HBM; the fp64 recurrence in front of "
+                                               "the stores still decides the time: see valu" if curve else
+                                               "no PMC figures for this launch size: HBM figures only (it does not bind)", **common)
     res = {
         "value": n_global * steps / dt, "ms_per_step": 1e3 * dt / steps, "steps": steps, "warmup": warmup, "scaling": scaling,
         "workload": workload, "baseline_config": config, "n_walk_per_gpu": n_local, "n_walk_total": n_global,
         "n_obs": n_obs_desc, "kernel_variant": variant, "sweep_tol": lp.handle.sweep_tol, "policy": lp.handle.policy,
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "mp::lnprob_kernel",
-                     "kernel_ms_avg": 1e3 * kavg, "kernel_ms_min": float(kern_ms.min()),
-                     "kernel_ms_max_over_ranks": float(np.nanmax(k_ranks)), "kernel_ms_min_over_ranks": float(np.nanmin(k_ranks)),
-                     "algorithmic_bytes_per_eval": bytes_eval, "evals_per_launch": n_local,
-                     "note": "latency-bound fp64 VALU recurrence: neither HBM nor MFMA binds; see valu"},
-        "valu": {"bound": "fp64 VALU issue", "unit": "TFLOP/s", "fp64_flops_per_launch_pmc": flops,
+        "roofline": roofline,
+        "valu": {"bound": "fp64 VALU issue", "unit": "TFLOP/s", "fp64_flops_per_launch_pmc": flops, "stale": stale,
                  "achieved": None if flops is None else flops / kavg / 1e12, "peak": FP64_VALU_PEAK_TFLOPS,
                  "frac": None if flops is None else flops / kavg / 1e12 / FP64_VALU_PEAK_TFLOPS,
                  "note": "flops executed = 64 x (2 FMA + MUL + ADD) fp64 instructions counted by rocprofv3 PMC for this "
@@ -505,7 +598,8 @@ def brief(r):
                               "kernel_variant", "kernel_evals_per_sec_per_gpu")} | {
         "kernel_ms_avg": r["roofline"]["kernel_ms_avg"], "kernel_ms_max_over_ranks": r["roofline"]["kernel_ms_max_over_ranks"],
         "roofline": {k: r["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel",
-                                                   "algorithmic_bytes_per_eval")},
+                                                   "algorithmic_bytes_per_eval", "stale") if k in r["roofline"]} |
+                    ({"hbm": r["roofline"]["hbm"]} if "hbm" in r["roofline"] else {}),
         "valu": {k: r["valu"][k] for k in ("achieved", "peak", "frac", "fp64_flops_per_launch_pmc")},
         "n_not_ok": r["check"]["n_not_ok"]}
 
@@ -571,7 +665,11 @@ def main():
             seen = int(t.item())
             dist.destroy_process_group()
         if rank == 0:
-            json_out.write(json.dumps({"dry_run": True, "n_gpus": world, "ranks_seen": seen}) + "\n")
+            line = {"dry_run": True, "n_gpus": world, "ranks_seen": seen}
+            pred = predicted_scaling(world)
+            if pred is not None:
+                line["predicted"] = pred
+            json_out.write(json.dumps(line) + "\n")
             json_out.flush()
         return
 
@@ -856,6 +954,9 @@ def main():
             out["ensemble_sampler"] = mcmc
         if dropin is not None:
             out["dropin"] = dropin
+        pred = predicted_scaling(world)
+        if pred is not None:
+            out["predicted"] = pred
         if cpu is not None:
             out["cpu_baseline"] = cpu
             out["speedup_vs_cpu_baseline"] = r["value"] / cpu["value"]

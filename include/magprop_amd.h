@@ -56,7 +56,7 @@
 extern "C" {
 #endif
 
-#define MP_ABI_VERSION 4
+#define MP_ABI_VERSION 5
 
 /* return codes */
 #define MP_OK 0
@@ -147,6 +147,21 @@ void mp_cfg_lib(mp_model_cfg *cfg);   /* magnetar/funcs.py:105-106 defaults; ODE
  */
 mp_handle *mp_create(const mp_model_cfg *cfg, const double *tgrid, int n_grid, int device);
 int mp_destroy(mp_handle *h);
+
+/*
+ * The same evaluator over SEVERAL devices of the node in ONE process (SURVEY.md 8(b)'s `device_mask`; ABI 5): what a
+ * plain, single-process emcee user of `EnsembleSampler(..., vectorize=True)` needs to use more than one GPU -- the
+ * reference's counterpart is `Pool()` over walkers, code/synthetic_datasets/synth_mcmc.py:178-185.  devices[n_devices]
+ * lists HIP device indices (a device may be listed more than once: its share of every batch grows accordingly).
+ * mp_set_dataset / mp_set_prior reach every device; mp_lnprob_batch (host buffers) deals the rows out in contiguous blocks
+ * of ceil(n / n_devices) -- the partitioning of SURVEY.md 8(e) -- enqueues every device's kernel before it waits for the
+ * first, and returns one vector: no torch, no RCCL, no second process.  mp_model_lc / mp_rhs_batch run on the first
+ * device.  The device-pointer entry (mp_lnprob_batch_dev) and the device-resident sampler belong to one device and
+ * return MP_ESTATE on such a handle; walker-sharded SAMPLING across devices is magprop_amd/distributed.py (one process per
+ * GPU, RCCL).  Not measured on several GPUs by the builder (one-GPU boxes): tested with the same device listed twice.
+ */
+mp_handle *mp_create_multi(const mp_model_cfg *cfg, const double *tgrid, int n_grid, const int *devices, int n_devices);
+int mp_n_devices(const mp_handle *h);   /* 1 for mp_create's handles */
 
 /*
  * Register (or replace) observed light curve `ds_id` (0 <= ds_id < MP_MAX_DATASETS):

@@ -27,9 +27,9 @@ EXPORTS = (
     "mp_sampler_get_bad", "mp_sampler_n_slots", "mp_sampler_row_doubles", "mp_sampler_halfstep_shard",
     "mp_sampler_halfstep_apply", "mp_sampler_step_blocks", "mp_sampler_step_row_doubles", "mp_sampler_step_shard",
     "mp_sampler_step_apply", "mp_sampler_state_ptrs", "mp_sweep_tol", "mp_n_simd", "mp_last_sweeps", "mp_last_tiles", "mp_tile_log", "mp_last_tile_log",
-    "mp_get_policy",
+    "mp_get_policy", "mp_create_multi", "mp_n_devices",
 )
-ABI_VERSION = 4
+ABI_VERSION = 5
 # order of mp_get_policy()'s vector (include/magprop_amd.h MP_POLICY_*)
 POLICY_FIELDS = ("max_stride", "stride_tol", "sweep_tol", "early_hold_seconds", "k4_tol_factor", "coarse_tol_factor",
                  "coarse_max_sweeps", "fine_max_sweeps", "trouble_limit", "stop_factor", "forced_steps_per_lane", "experiments_build",
@@ -119,6 +119,10 @@ def lib():
     L.mp_cfg_lib.restype = None
     L.mp_create.restype = vp
     L.mp_create.argtypes = [C.POINTER(ModelCfg), dp, C.c_int, C.c_int]
+    L.mp_create_multi.restype = vp
+    L.mp_create_multi.argtypes = [C.POINTER(ModelCfg), dp, C.c_int, ip, C.c_int]
+    L.mp_n_devices.argtypes = [vp]
+    L.mp_n_devices.restype = C.c_int
     L.mp_destroy.argtypes = [vp]
     L.mp_set_dataset.argtypes = [vp, C.c_int, dp, dp, dp, C.c_int]
     L.mp_set_prior.argtypes = [vp, dp, dp, C.c_int, C.c_uint32]
@@ -231,12 +235,22 @@ class Handle:
     """Owns one mp_handle: a model configuration + time grid bound to one GPU."""
 
     def __init__(self, cfg, tgrid, device=-1):
+        """device: a HIP device index (-1: the current one), or a sequence of indices for a multi-device handle
+        (mp_create_multi: host-buffer batches are dealt out over the listed devices inside the library)."""
         self._L = lib()
         self.tgrid = np.ascontiguousarray(tgrid, dtype=np.float64)
         self.cfg = cfg
-        self._h = self._L.mp_create(C.byref(cfg), _dptr(self.tgrid), int(self.tgrid.size), int(device))
+        if np.ndim(device) > 0:
+            devs = np.ascontiguousarray(device, dtype=np.int32)
+            self._h = self._L.mp_create_multi(C.byref(cfg), _dptr(self.tgrid), int(self.tgrid.size), _iptr(devs), int(devs.size))
+        else:
+            self._h = self._L.mp_create(C.byref(cfg), _dptr(self.tgrid), int(self.tgrid.size), int(device))
         if not self._h:
             raise MagpropAmdError("mp_create failed: " + last_error())
+
+    @property
+    def n_devices(self):
+        return self._L.mp_n_devices(self._h)
 
     def close(self):
         if getattr(self, "_h", None):

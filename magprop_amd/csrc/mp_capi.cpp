@@ -143,6 +143,13 @@ struct mp_handle {
     // `mu` for its duration.  Launches share nothing writable but their own outputs (round 4: no per-walker scratch rows),
     // so launches of one handle on different streams may overlap freely.
     std::recursive_mutex mu;
+    // Multi-device handle (mp_create_multi): one evaluator per listed device; this object then holds no device state of
+    // its own -- datasets and prior are forwarded to every evaluator, a host-buffer batch is dealt out in contiguous blocks.
+    std::vector<mp_handle *> sub;
+    int pend_n = 0;               // rows of the host-buffer batch between batch_begin and batch_end
+    size_t pend_in_bytes = 0;
+    double last_tot_sweeps = 0.0, last_tot_tiles = 0.0;   // over the walkers of the last batch that finished (status ok) ...
+    int last_cnt_ok = 0;                                  // ... and how many those were
 };
 
 namespace {
@@ -473,8 +480,36 @@ mp_handle *mp_create(const mp_model_cfg *cfg, const double *tgrid, int n_grid, i
     return h;
 }
 
+mp_handle *mp_create_multi(const mp_model_cfg *cfg, const double *tgrid, int n_grid, const int *devices, int n_devices) {
+    if (!devices || n_devices < 1 || n_devices > 64) {
+        fail(MP_EINVAL, "mp_create_multi: devices NULL or n_devices outside 1..64");
+        return nullptr;
+    }
+    mp_handle *h = new mp_handle();
+    for (int g = 0; g < n_devices; ++g) {
+        mp_handle *s = mp_create(cfg, tgrid, n_grid, devices[g]);     // (validates cfg / tgrid; its message stays in mp_last_error)
+        if (!s) {
+            mp_destroy(h);
+            return nullptr;
+        }
+        h->sub.push_back(s);
+    }
+    h->device = h->sub[0]->device;
+    h->tgrid = h->sub[0]->tgrid;
+    h->n_tiles = h->sub[0]->n_tiles;
+    h->sh = h->sub[0]->sh;          // the scalar settings (policy, tolerances, n_simd of the first device); no device pointer of it is used
+    return h;
+}
+
+int mp_n_devices(const mp_handle *h) { return h ? (h->sub.empty() ? 1 : (int)h->sub.size()) : 0; }
+
 int mp_destroy(mp_handle *h) {
     if (!h) return MP_OK;
+    if (!h->sub.empty()) {
+        for (mp_handle *s : h->sub) (void)mp_destroy(s);
+        delete h;
+        return MP_OK;
+    }
     DeviceScope scope(h->device);
     (void)hipDeviceSynchronize();
     h->d_wtab.release();
@@ -497,6 +532,11 @@ int mp_set_dataset(mp_handle *h, int ds_id, const double *x, const double *y, co
     if (ds_id < 0 || ds_id >= MP_MAX_DATASETS) return fail(MP_EINVAL, "mp_set_dataset: ds_id %d out of range", ds_id);
     if (n_obs <= 0) return fail(MP_EINVAL, "mp_set_dataset: n_obs must be positive");
     Lock lock(h->mu);
+    if (!h->sub.empty()) {
+        for (mp_handle *s : h->sub) { const int rc = mp_set_dataset(s, ds_id, x, y, yerr, n_obs); if (rc) return rc; }
+        h->sh.n_ds = h->sub[0]->sh.n_ds;
+        return MP_OK;
+    }
     const std::vector<double> &t = h->tgrid;
     const int n = (int)t.size();
     for (int j = 0; j < n_obs; ++j) {
@@ -533,6 +573,7 @@ int mp_set_prior(mp_handle *h, const double *lower, const double *upper, int ndi
     if (ndim < 0 || ndim > MP_MAX_NDIM) return fail(MP_EINVAL, "mp_set_prior: ndim %d out of range", ndim);
     if (ndim > 0 && (!lower || !upper)) return fail(MP_EINVAL, "mp_set_prior: NULL bounds");
     Lock lock(h->mu);
+    for (mp_handle *s : h->sub) { const int rc = mp_set_prior(s, lower, upper, ndim, log_mask); if (rc) return rc; }
     for (int i = 0; i < MP_MAX_NDIM; ++i) {
         h->sh.lower[i] = i < ndim ? lower[i] : -INFINITY;
         h->sh.upper[i] = i < ndim ? upper[i] : INFINITY;
@@ -554,6 +595,7 @@ int mp_lnprob_batch_dev(mp_handle *h, const double *d_pars, const int32_t *d_ds_
                         double *d_lnprob, int32_t *d_status, double *d_ltot, void *stream) {
     int rc = check_batch_args(h, d_pars, n, ndim, d_lnprob);
     if (rc) return rc;
+    if (!h->sub.empty()) return fail(MP_ESTATE, "mp_lnprob_batch_dev: device pointers belong to ONE device; a multi-device handle serves the host-buffer entries");
     Lock lock(h->mu);
     if (!d_ds_id && !h->ds[0].set) return fail(MP_ESTATE, "lnprob batch: ds_id is NULL but dataset 0 is not set");
     DeviceScope scope(h->device);
@@ -570,19 +612,11 @@ int mp_lnprob_batch_dev(mp_handle *h, const double *d_pars, const int32_t *d_ds_
     return launch_lnprob_ordered(h, a, (hipStream_t)stream);
 }
 
-int mp_lnprob_batch(mp_handle *h, const double *pars, const int32_t *ds_id, int n, int ndim, double *lnprob_out,
-                    int32_t *status_out, double *ltot_out) {
-    int rc = check_batch_args(h, pars, n, ndim, lnprob_out);
-    if (rc) return rc;
-    if (n == 0) return MP_OK;
-    Lock lock(h->mu);
-    if (ds_id) {
-        for (int i = 0; i < n; ++i)
-            if (ds_id[i] < 0 || ds_id[i] >= MP_MAX_DATASETS || !h->ds[ds_id[i]].set)
-                return fail(MP_EINVAL, "lnprob batch: walker %d refers to unset dataset %d", i, ds_id[i]);
-    } else if (!h->ds[0].set) {
-        return fail(MP_ESTATE, "lnprob batch: ds_id is NULL but dataset 0 is not set");
-    }
+// The host-buffer batch in two halves, so that a multi-device handle can have every device's launch in flight before it
+// waits for the first: batch_begin stages the rows and enqueues the kernel on the handle's stream, batch_end waits and
+// hands the results over.  (Caller holds h->mu and has validated the arguments.)
+static int batch_begin(mp_handle *h, const double *pars, const int32_t *ds_id, int n, int ndim, double *ltot_out) {
+    int rc;
     DeviceScope scope(h->device);
     const size_t ng = h->tgrid.size();
     // One page-locked staging block owned by the handle, mapped into the device's address space: [pars n*ndim f64 | ds_id n i32]
@@ -597,7 +631,7 @@ int mp_lnprob_batch(mp_handle *h, const double *pars, const int32_t *ds_id, int 
     hipStream_t st = h->stream;
     std::memcpy(h->h_io.p, pars, in_pars);
     if (ds_id) std::memcpy(h->h_io.p + in_pars, ds_id, in_ids);
-    unsigned char *d_out = h->h_io.dev + in_bytes, *h_out = h->h_io.p + in_bytes;
+    unsigned char *d_out = h->h_io.dev + in_bytes;
     mp::LaunchArgs a{};
     a.pars = (const double *)h->h_io.dev;
     a.ds_id = ds_id ? (const int32_t *)(h->h_io.dev + in_pars) : nullptr;
@@ -622,7 +656,16 @@ int mp_lnprob_batch(mp_handle *h, const double *pars, const int32_t *ds_id, int 
     } else h->last_tile_log.clear();
     if (ltot_out)
         HIP_TRY(hipMemcpyAsync(ltot_out, h->w_curves.p, sizeof(double) * (size_t)n * ng, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    h->pend_n = n;
+    h->pend_in_bytes = in_bytes;
+    return MP_OK;
+}
+
+static int batch_end(mp_handle *h, double *lnprob_out, int32_t *status_out) {
+    DeviceScope scope(h->device);
+    const int n = h->pend_n;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const unsigned char *h_out = h->h_io.p + h->pend_in_bytes;
     std::memcpy(lnprob_out, h_out, sizeof(double) * (size_t)n);
     const int32_t *status = (const int32_t *)(h_out + sizeof(double) * (size_t)n), *sweeps = status + n, *tiles = sweeps + n;
     if (status_out) std::memcpy(status_out, status, sizeof(int32_t) * (size_t)n);
@@ -632,14 +675,71 @@ int mp_lnprob_batch(mp_handle *h, const double *pars, const int32_t *ds_id, int 
     h->last_tiles.assign(tiles, tiles + n);
     for (int i = 0; i < n; ++i)
         if (status[i] == MP_STATUS_OK) { tot += sweeps[i]; tot_tiles += tiles[i]; ++cnt; }
+    h->last_tot_sweeps = tot; h->last_tot_tiles = tot_tiles; h->last_cnt_ok = cnt;
     h->last_mean_sweeps = tot_tiles > 0.0 ? tot / tot_tiles : 0.0;
     h->last_mean_tiles = cnt ? tot_tiles / (double)cnt : 0.0;
+    return MP_OK;
+}
+
+int mp_lnprob_batch(mp_handle *h, const double *pars, const int32_t *ds_id, int n, int ndim, double *lnprob_out,
+                    int32_t *status_out, double *ltot_out) {
+    int rc = check_batch_args(h, pars, n, ndim, lnprob_out);
+    if (rc) return rc;
+    if (n == 0) return MP_OK;
+    Lock lock(h->mu);
+    const mp_handle *hd = h->sub.empty() ? h : h->sub[0];     // (the datasets of a multi-device handle live in its evaluators)
+    if (ds_id) {
+        for (int i = 0; i < n; ++i)
+            if (ds_id[i] < 0 || ds_id[i] >= MP_MAX_DATASETS || !hd->ds[ds_id[i]].set)
+                return fail(MP_EINVAL, "lnprob batch: walker %d refers to unset dataset %d", i, ds_id[i]);
+    } else if (!hd->ds[0].set) {
+        return fail(MP_ESTATE, "lnprob batch: ds_id is NULL but dataset 0 is not set");
+    }
+    if (h->sub.empty()) {
+        if ((rc = batch_begin(h, pars, ds_id, n, ndim, ltot_out))) return rc;
+        return batch_end(h, lnprob_out, status_out);
+    }
+    // Multi-device: contiguous blocks of ceil(n / G) rows (SURVEY.md 8(e)'s partitioning), every device's kernel enqueued before
+    // the first is waited for; one host thread drives them all (a launch returns in microseconds, the kernels run side by side).
+    const int G = (int)h->sub.size(), per = (n + G - 1) / G;
+    const size_t ng = h->tgrid.size();
+    int used = 0;
+    for (int g = 0; g < G; ++g) {
+        const int lo = std::min(g * per, n), cnt = std::min(lo + per, n) - lo;
+        if (cnt <= 0) break;
+        mp_handle *s = h->sub[(size_t)g];
+        Lock sl(s->mu);
+        if ((rc = batch_begin(s, pars + (size_t)lo * ndim, ds_id ? ds_id + lo : nullptr, cnt, ndim, ltot_out ? ltot_out + (size_t)lo * ng : nullptr))) {
+            for (int k = 0; k < used; ++k) (void)hipStreamSynchronize(h->sub[(size_t)k]->stream);   // nothing may still write the caller's buffers
+            return rc;
+        }
+        ++used;
+    }
+    int first_rc = MP_OK;
+    h->last_sweeps.clear();
+    h->last_tiles.clear();
+    double tot = 0.0, tot_tiles = 0.0;
+    int cnt_ok = 0;
+    for (int g = 0; g < used; ++g) {
+        mp_handle *s = h->sub[(size_t)g];
+        const int lo = g * per;
+        Lock sl(s->mu);
+        rc = batch_end(s, lnprob_out + lo, status_out ? status_out + lo : nullptr);
+        if (rc && !first_rc) first_rc = rc;
+        h->last_sweeps.insert(h->last_sweeps.end(), s->last_sweeps.begin(), s->last_sweeps.end());
+        h->last_tiles.insert(h->last_tiles.end(), s->last_tiles.begin(), s->last_tiles.end());
+        tot += s->last_tot_sweeps; tot_tiles += s->last_tot_tiles; cnt_ok += s->last_cnt_ok;
+    }
+    if (first_rc) return first_rc;
+    h->last_mean_sweeps = tot_tiles > 0.0 ? tot / tot_tiles : 0.0;
+    h->last_mean_tiles = cnt_ok ? tot_tiles / (double)cnt_ok : 0.0;
     return MP_OK;
 }
 
 int mp_model_lc(mp_handle *h, const double *pars, int ndim, double *out, double *traj, int32_t *status) {
     if (!h || !pars || !out) return fail(MP_EINVAL, "mp_model_lc: NULL argument");
     if (ndim < 6 || ndim > MP_MAX_NDIM) return fail(MP_EINVAL, "mp_model_lc: ndim must be 6..9, got %d", ndim);
+    if (!h->sub.empty()) return mp_model_lc(h->sub[0], pars, ndim, out, traj, status);   // one walker: the first device
     Lock lock(h->mu);
     DeviceScope scope(h->device);
     const size_t ng = h->tgrid.size();
@@ -679,6 +779,7 @@ int mp_rhs_batch(mp_handle *h, const double *pars, int ndim, const double *t, co
     if (ndim < 6 || ndim > MP_MAX_NDIM) return fail(MP_EINVAL, "mp_rhs_batch: ndim must be 6..9, got %d", ndim);
     if (n < 0) return fail(MP_EINVAL, "mp_rhs_batch: negative n");
     if (n == 0) return MP_OK;
+    if (!h->sub.empty()) return mp_rhs_batch(h->sub[0], pars, ndim, t, y, n, dydt, lam);
     Lock lock(h->mu);
     DeviceScope scope(h->device);
     // one device block: [pars n*ndim | t n | y 2n] in, [dydt 2n | lam n] out
@@ -709,6 +810,10 @@ int mp_rhs_batch(mp_handle *h, const double *pars, int ndim, const double *t, co
 int mp_synchronize(mp_handle *h) {
     if (!h) return fail(MP_EINVAL, "mp_synchronize: NULL handle");
     Lock lock(h->mu);
+    if (!h->sub.empty()) {
+        for (mp_handle *s : h->sub) { const int rc = mp_synchronize(s); if (rc) return rc; }
+        return MP_OK;
+    }
     DeviceScope scope(h->device);
     HIP_TRY(hipStreamSynchronize(h->stream));
     return MP_OK;
@@ -828,6 +933,7 @@ static mp::StretchArgs stretch_args(const mp_sampler *s, const int32_t *d_perm, 
 mp_sampler *mp_sampler_create(mp_handle *h, int n_walkers, int n_ensembles, int ndim, const int32_t *ens_ds_id,
                               uint64_t seed, double a, int target) {
     if (!h) { fail(MP_EINVAL, "mp_sampler_create: NULL handle"); return nullptr; }
+    if (!h->sub.empty()) { fail(MP_ESTATE, "mp_sampler_create: the device-resident sampler lives on ONE device (walker sharding across devices: magprop_amd/distributed.py)"); return nullptr; }
     if (n_walkers < 2 || (n_walkers & 1)) { fail(MP_EINVAL, "mp_sampler_create: n_walkers must be even and >= 2"); return nullptr; }
     if (n_ensembles < 1 || ndim < 1 || ndim > MP_MAX_NDIM || (target == 0 && ndim < 6)) {
         fail(MP_EINVAL, "mp_sampler_create: bad n_ensembles / ndim");
@@ -1152,7 +1258,7 @@ int mp_sampler_get_state(mp_sampler *s, double *pos, double *lnprob, int64_t *n_
 }
 
 int mp_device(const mp_handle *h) { return h ? h->device : -1; }
-void *mp_stream(const mp_handle *h) { return h ? (void *)h->stream : nullptr; }
+void *mp_stream(const mp_handle *h) { return h ? (void *)h->stream : nullptr; }   // (a multi-device handle has none: NULL)
 int mp_n_grid(const mp_handle *h) { return h ? (int)h->tgrid.size() : 0; }
 double mp_last_mean_sweeps(const mp_handle *h) { return h ? h->last_mean_sweeps : 0.0; }
 double mp_last_mean_tiles(const mp_handle *h) { return h ? h->last_mean_tiles : 0.0; }
@@ -1165,11 +1271,17 @@ int mp_last_sweeps(const mp_handle *h, int32_t *out, int n) {
 int mp_tile_log(mp_handle *h, int enable) {
     if (!h) return fail(MP_EINVAL, "mp_tile_log: NULL handle");
     Lock lock(h->mu);
+    for (mp_handle *s : h->sub) (void)mp_tile_log(s, enable);
     h->tile_log_on = enable != 0;
     return MP_OK;
 }
 int mp_last_tile_log(const mp_handle *h, int walker, int32_t *out, int n) {
     if (!h || !out || n < 0 || walker < 0) return fail(MP_EINVAL, "mp_last_tile_log: bad argument");
+    if (!h->sub.empty()) {   // the walker's block and its row inside it (contiguous blocks of ceil(n / G) rows)
+        const int G = (int)h->sub.size(), total = (int)h->last_tiles.size(), per = (total + G - 1) / std::max(G, 1);
+        if (per <= 0 || walker >= total) return 0;
+        return mp_last_tile_log(h->sub[(size_t)(walker / per)], walker % per, out, n);
+    }
     const size_t off = (size_t)walker * MP_TILE_LOG;
     if (off + MP_TILE_LOG > h->last_tile_log.size()) return 0;
     int m = 0;

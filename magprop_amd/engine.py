@@ -78,7 +78,7 @@ def engine(cfg, GRBtype=None, device=-1, _pin=False):
     """Cached Engine for (model configuration, grid, device).  The least recently used engines beyond MAX_ENGINES are
     closed, except those a caller currently holds through use().  Front ends that evaluate go through use(); a bare
     engine() is a look-up for single-threaded callers (tests, introspection)."""
-    key = (cfg.__dict__.get("_mp_key") or _cfg_key(cfg), "S" if GRBtype == "S" else "L", int(device))   # (_mp_key: set by the front ends on configurations they cache and never modify)
+    key = (cfg.__dict__.get("_mp_key") or _cfg_key(cfg), "S" if GRBtype == "S" else "L", tuple(int(d) for d in device) if np.ndim(device) > 0 else int(device))   # (_mp_key: set by the front ends on configurations they cache and never modify)
     with _lock:
         e = _handles.pop(key, None)
         if e is None:

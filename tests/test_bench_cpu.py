@@ -25,7 +25,11 @@ def test_self_launch_two_ranks_prints_one_line():
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
-    assert d == {"dry_run": True, "n_gpus": 2, "ranks_seen": 2}
+    assert {k: d[k] for k in ("dry_run", "n_gpus", "ranks_seen")} == {"dry_run": True, "n_gpus": 2, "ranks_seen": 2}
+    # what the one-GPU measurements predict for this N rides along
+    p = d["predicted"]
+    assert p["n_gpus"] == 2 and p["strong_config4_8192_total"]["walkers_per_gpu"] == 4096
+    assert p["weak_config2_1024_per_gpu"]["walkers_total"] == 2048 and 1.0 < p["weak_config2_1024_per_gpu"]["speedup_vs_one_gpu"] <= 2.0
 
 
 def test_self_launch_propagates_a_failing_rank():
@@ -59,4 +63,19 @@ def test_self_launch_eight_ranks():
     r = _run(["--gpus", "8", "--dry-run"], timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
-    assert len(lines) == 1 and json.loads(lines[0]) == {"dry_run": True, "n_gpus": 8, "ranks_seen": 8}
+    d = json.loads(lines[0])
+    assert len(lines) == 1 and {k: d[k] for k in ("dry_run", "n_gpus", "ranks_seen")} == {"dry_run": True, "n_gpus": 8, "ranks_seen": 8}
+    p = d["predicted"]
+    assert p["strong_config4_8192_total"]["walkers_per_gpu"] == 1024 and p["strong_config5_4096_total"]["walkers_per_gpu"] == 512
+    assert "WEAK" in p["claim"] and 4.0 < p["weak_config2_1024_per_gpu"]["speedup_vs_one_gpu"] <= 8.0
+
+
+def test_committed_counters_and_kernel_times_belong_to_this_build():
+    """profiles/pmc_figures.json (PMC counters behind bench.py's roofline object) and profiles/scaling_inputs.json (one-GPU
+    kernel times behind `predicted`) record the hash of the kernel sources they were collected on; bench.py flags a
+    mismatch as `stale` at run time, and the committed pair must match the committed sources."""
+    sys.path.insert(0, ROOT)
+    import bench
+    h = bench.csrc_hash()
+    assert json.load(open(os.path.join(ROOT, "profiles", "pmc_figures.json"))).get("build") == h
+    assert json.load(open(os.path.join(ROOT, "profiles", "scaling_inputs.json"))).get("build") == h

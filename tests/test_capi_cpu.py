@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/magprop_amd.h but not exported"
     assert set(names) == set(_capi.EXPORTS)
-    assert L.mp_abi_version() == _capi.ABI_VERSION == 4
+    assert L.mp_abi_version() == _capi.ABI_VERSION == 5
 
 
 def test_python_mirror_follows_the_header_constants():

@@ -453,3 +453,52 @@ def test_registering_64_datasets_is_incremental(gsynth, tarr):
     assert np.isclose(again[17], LogProb(*sets[3])(P[17:18])[0], rtol=1e-9, atol=0.0) and again[17] != got[17]
     with pytest.raises(ValueError):
         lp.add_dataset(*sets[0])                                # a 65th set: MP_MAX_DATASETS
+
+
+def test_multi_device_handle_deals_a_batch_out_inside_the_library(gsynth):
+    """mp_create_multi (ABI 5): ONE handle over several devices, one process, no torch: a host-buffer batch goes out in
+    contiguous blocks of ceil(n / G) rows, every device's kernel is enqueued before the first is waited for, one vector comes
+    back.  The box has one GPU: the same device listed twice (and three times) -- results and statuses equal the single-device
+    handle's bit for bit where the blocks select the same kernel variant, to rounding (same tiles, same policy) where a block
+    falls into the team kernels' range; datasets and the prior reach every evaluator; diagnostics are per walker of the batch."""
+    from magprop_amd import LogProb, _capi
+    sets = [(gsynth[t + "_x"], gsynth[t + "_y"], gsynth[t + "_yerr"]) for t in TYPES]
+    one = LogProb(*sets[0])
+    two = LogProb(*sets[0], device=[0, 0])
+    three = LogProb(*sets[0], device=[0, 0, 0])
+    for lp_ in (one, two, three):
+        for s_ in sets[1:]:
+            lp_.add_dataset(*s_)
+    assert one.handle.n_devices == 1 and two.handle.n_devices == 2 and three.handle.n_devices == 3
+    rng = np.random.default_rng(11)
+    lo, hi = gsynth["prior_lower"], gsynth["prior_upper"]
+    for n in (4096, 2400, 1, 7):
+        P = lo + (hi - lo) * rng.random((n, 6))
+        P[: n // 2] = np.array(TRUTHS["Humped"]) + 1.0e-3 * rng.standard_normal((n // 2, 6))
+        if n > 5:
+            P[5] = hi + 0.5                                                         # outside the prior
+        ids = rng.integers(0, 4, n).astype(np.int32)
+        ref, st_ref = one.handle.lnprob_batch(P, ds_id=ids, want_status=True)
+        for lp_ in (two, three):
+            out, st = lp_.handle.lnprob_batch(P, ds_id=ids, want_status=True)
+            assert np.array_equal(st, st_ref)
+            ok = st == 0
+            assert np.all(out[~ok] == -np.inf)
+            per = -(-n // lp_.handle.n_devices)
+            if n > 1024 and per > 1024:                                             # 2-steps-per-lane kernel on both sides
+                assert np.array_equal(out, ref)
+            else:
+                assert np.allclose(out[ok], ref[ok], rtol=1e-7, atol=0.0)
+            assert len(lp_.handle.last_tiles(n)) == n and np.array_equal(lp_.handle.last_tiles(n) > 0, one.handle.last_tiles(n) > 0)
+    # mode B rows land at the right offsets too
+    P = np.array(TRUTHS["Classic"]) + 1.0e-3 * rng.standard_normal((6, 6))
+    a, sa, la = one.handle.lnprob_batch(P, ds_id=1, want_status=True, want_ltot=True)
+    b, sb, lb = two.handle.lnprob_batch(P, ds_id=1, want_status=True, want_ltot=True)
+    assert np.array_equal(a, b) and np.array_equal(sa, sb) and np.array_equal(la, lb)
+    # one-device entries say so instead of guessing a device
+    import torch
+    d = torch.zeros(4, 6, dtype=torch.float64, device="cuda")
+    with pytest.raises(_capi.MagpropAmdError, match="ONE device"):
+        two.lnprob_device(d)
+    # the model light curve of one walker: the first device
+    assert np.array_equal(two.handle.model_lc(np.array([1.0, 5.0, 1e-3, 100.0, 0.1, 1.0]))[1], one.handle.model_lc(np.array([1.0, 5.0, 1e-3, 100.0, 0.1, 1.0]))[1])

@@ -32,4 +32,7 @@ for spec in sys.argv[1:]:
         "f64_arith_insts_per_wave": d.get("f64_arith_insts_per_wave"), "wave_cycles_per_wave": d.get("wave_cycles_per_wave"),
         "fp64_tflops": d.get("fp64_tflops_achieved"), "hbm_write_GBps": d.get("hbm_write_GBps"), "source": f"profiles/{tag}_rocprof_summary.json"}
     print(tag, mode, n, fig[mode][n])
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+fig["build"] = bench.csrc_hash()      # the sources these counters belong to (bench.py reports `stale` on a mismatch)
 json.dump(fig, open(fig_path, "w"), indent=1)
