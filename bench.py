@@ -913,7 +913,10 @@ def main():
             return r
         if world == 1:
             configs = {"3": sub(3, "weak", sampler=True), "4_one_gpu": sub(4, "strong", sampler=True),
-                       "5": sub(5, "strong", sampler=True), "curve": sub(2, "weak", curve=True)}
+                       "5": sub(5, "strong", sampler=True), "curve": sub(2, "weak", curve=True),
+                       # mode B beyond n_simd walkers: the 2-steps-per-lane curve kernel (the one kernel on an ABI path that
+                       # still spills: 64 B of scratch per lane, tools/resource_usage.py)
+                       "curve_4096": sub(2, "weak", curve=True, nwalk=4096)}
         else:
             configs = {"4_strong": sub(4, "strong"), "5_strong": sub(5, "strong")}
 

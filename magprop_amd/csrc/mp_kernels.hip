@@ -263,7 +263,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPL >= 4 ? 1
             }
             if (g.chain) {
                 double *c = g.chain + ((size_t)g.chain_row * g.n_total + k) * g.ndim;
-                for (int i = 0; i < g.ndim; ++i) c[i] = accept ? park[i] : g.pos[(size_t)k * g.ndim + i];
+                // (the walker's position AFTER the decision: written just above when the proposal was accepted.  A select between
+                // the LDS slot and the global row made the compiler select the ADDRESS and load through a generic pointer:
+                // nine flat loads and a private segment reserved for their sake)
+                for (int i = 0; i < g.ndim; ++i) c[i] = g.pos[(size_t)k * g.ndim + i];
                 g.chain_lnp[(size_t)g.chain_row * g.n_total + k] = accept ? lnp : lnp_old;
             }
             if (g.bad_log && (status == MP_STATUS_FLAG || status == MP_STATUS_NONFINITE)) {

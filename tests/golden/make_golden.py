@@ -348,18 +348,25 @@ def make_flagscan2(n_each=1500):
     print("flagscan2 flag rate", (st == 1).mean(), "n", len(P))
 
 
-HOLDOUT_SEED = 41020261   # drawn after the round-4 policy constants (include/magprop_amd.h, mp_capi.cpp) were frozen; never used for tuning
+HOLDOUT_SEED = 41020261   # generated at commit de88a87 (round 4), BEFORE the last ~20 policy commits of that round: those commits
+                          # were accepted with "hold-out summaries unchanged" among their gates, so this set served as an
+                          # acceptance gate while the policy was still moving -- it is a regression set, not an untouched one
+HOLDOUT2_SEED = 51020265  # round 5: drawn after every constant of the stride policy was final (no policy commit follows it);
+                          # consulted ONCE, by tests/test_gpu_holdout.py, after it was written
 
 
-def make_holdout(n_synth=900, n_lib=600):
-    """HOLD-OUT set: points no constant of the solver's stride policy was ever tuned on.  4 x n_synth prior-wide points,
+def make_holdout(n_synth=900, n_lib=600, seed=HOLDOUT_SEED, out_name="golden_holdout.npz"):
+    """HOLD-OUT sets.  golden_holdout.npz (round 4): prior-wide points drawn while the last policy changes of that round were
+    still being accepted against it (see HOLDOUT_SEED): a regression gate.  golden_holdout2.npz (round 5, --only holdout2):
+    a fresh seed after the policy was final.  4 x n_synth prior-wide points,
     one block per synthetic dataset (seeds as in make_synth), and 2 x n_lib library-variant points (grids "L" and "S") over
     the library's prior box; at every point the reference at its default LSODA tolerance AND at rtol = atol = 1e-12, plus
     the enumerated LSODA-noise points.  tests/test_gpu_holdout.py holds the product defaults to both bounds and to exact
     status; tests/test_oracle.py does the same for the serial restatement."""
     import multiprocessing as mp
     import pandas as pd
-    rng = np.random.default_rng(HOLDOUT_SEED)
+    HOLDOUT_SEED_ = seed
+    rng = np.random.default_rng(seed)
     P = LOWER + (UPPER - LOWER) * rng.random((4 * n_synth, 6))
     ds = np.repeat(np.arange(4), n_synth).astype(np.int32)
     sets = [synth_dataset(nm, SEED0 + i)[1:] for i, nm in enumerate(TYPES)]
@@ -371,7 +378,7 @@ def make_holdout(n_synth=900, n_lib=600):
         ok = np.nonzero(st == 0)[0]
         tight[ok] = pool.map(_tight_synth_one, [jobs[i] for i in ok], chunksize=20)
     out = {"synth_pars": P, "synth_ds": ds, "synth_ds_names": np.array(TYPES), "synth_lnprob": lnp, "synth_status": st,
-           "synth_lnprob_tight": tight, "synth_lsoda_noise_idx": noise_idx(lnp, tight), "seed": np.array([HOLDOUT_SEED])}
+           "synth_lnprob_tight": tight, "synth_lsoda_noise_idx": noise_idx(lnp, tight), "seed": np.array([HOLDOUT_SEED_])}
     print("holdout synth: flags", int((st == 1).sum()), "noise points", len(out["synth_lsoda_noise_idx"]), "of", len(P), flush=True)
     os.chdir(REF)
     lims = pd.read_csv(os.path.join(REF, "magnetar/mcmc_limits.csv"), index_col="pars")
@@ -391,7 +398,7 @@ def make_holdout(n_synth=900, n_lib=600):
         out.update({f"lib{kind}_pars_sampler": Pl, f"lib{kind}_pars_physical": phys, f"lib{kind}_lnlike": lnl, f"lib{kind}_status": stl,
                     f"lib{kind}_lnlike_tight": tl, f"lib{kind}_lsoda_noise_idx": noise_idx(lnl, tl)})
         print(f"holdout lib {kind}: flags", int((stl == 1).sum()), "noise points", len(out[f"lib{kind}_lsoda_noise_idx"]), "of", n_lib, flush=True)
-    np.savez_compressed(os.path.join(HERE, "golden_holdout.npz"), **out)
+    np.savez_compressed(os.path.join(HERE, out_name), **out)
 
 
 def make_corners():
@@ -712,7 +719,7 @@ def make_swift():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--flag-scan", type=int, default=1500)
-    ap.add_argument("--only", choices=["all", "lib", "libkw", "corners", "libscan", "longlc", "flagscan2", "libscan2", "rhs", "tight", "swift", "holdout"], default="all", help="regenerate only one file")
+    ap.add_argument("--only", choices=["all", "lib", "libkw", "corners", "libscan", "longlc", "flagscan2", "libscan2", "rhs", "tight", "swift", "holdout", "holdout2"], default="all", help="regenerate only one file")
     a = ap.parse_args()
     import scipy, pandas
     if a.only == "all":
@@ -737,6 +744,8 @@ def main():
     noise_report = make_tight() if a.only in ("all", "tight") else None
     if a.only == "holdout":          # (not part of "all": the hold-out set is generated once, after a policy freeze)
         make_holdout()
+    if a.only == "holdout2":         # round 5: fresh seed, policy final
+        make_holdout(n_synth=600, n_lib=400, seed=HOLDOUT2_SEED, out_name="golden_holdout2.npz")
     if a.only in ("all", "swift"):
         make_swift()
     manifest = {

@@ -1,11 +1,16 @@
-"""Hold-out parity (run with -m gpu): the product defaults against reference values at points NO constant of the solver's
-stride policy was tuned on.
+"""Hold-out parity (run with -m gpu): the product defaults against reference values at prior-wide points.
 
-tests/golden/golden_holdout.npz (tests/golden/make_golden.py --only holdout, seed 41020261, drawn after the round-4 policy
-freeze): 4 x 900 prior-wide points, one block per synthetic dataset, and 2 x 600 library-variant points on the reference's
-two grids; at every point the reference as it runs (default LSODA) and re-run with rtol = atol = 1e-12.  Contract
-(tests/conftest.py::assert_vs_reference): exact status; |d| <= 1e-5 + 2e-6 |ref| against the default run
-except at the enumerated LSODA-noise points; |d| <= 1e-7 + 1e-7 |ref| against the tight run at every point."""
+tests/golden/golden_holdout.npz (tests/golden/make_golden.py --only holdout, seed 41020261): 4 x 900 prior-wide points, one
+block per synthetic dataset, and 2 x 600 library-variant points on the reference's two grids.  HONESTLY: this set was written
+at commit de88a87 in round 4 and about twenty later commits of that round changed the stride / sweep policy (cut by ratio,
+abort skip, kink drop, realign, contraction stop, light tolerance 1e-3, hold release, early end of the sub-steps), each
+accepted with "hold-out summaries unchanged" among its gates: it served as an acceptance gate while the policy was still
+moving, so it is a regression set, not points the policy never saw.  tests/golden/golden_holdout2.npz (round 5,
+--only holdout2, seed 51020265: 4 x 600 + 2 x 400 points) was drawn after every policy constant was final and is consulted by
+this file alone; `fresh` below.  At every point the reference as it runs (default LSODA) and re-run with
+rtol = atol = 1e-12.  Contract (tests/conftest.py::assert_vs_reference): exact status;
+|d| <= 1e-5 + 2e-6 |ref| against the default run except at the enumerated LSODA-noise points; |d| <= 1e-7 + 1e-7 |ref| against
+the tight run at every point."""
 import json
 import os
 
@@ -17,9 +22,11 @@ from conftest import GOLDEN, TIGHT_ATOL, TIGHT_RTOL, TYPES, assert_vs_reference,
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def gh():
-    return np.load(os.path.join(GOLDEN, "golden_holdout.npz"))
+@pytest.fixture(scope="module", params=["golden_holdout.npz", "golden_holdout2.npz"], ids=["round4-gate", "fresh"])
+def gh(request):
+    g = dict(np.load(os.path.join(GOLDEN, request.param)))
+    g["_tag"] = "" if request.param == "golden_holdout.npz" else "fresh_"
+    return g
 
 
 def _record(name, frac):
@@ -31,7 +38,7 @@ def _record(name, frac):
         json.dump(d, open(path, "w"), indent=1)
 
 
-@pytest.mark.parametrize("batch", [1024, 3600], ids=["4-steps-per-lane", "2-steps-per-lane"])
+@pytest.mark.parametrize("batch", [1024, 3600, 500, 250], ids=["4-steps-per-lane", "2-steps-per-lane", "team-two-per-simd", "team-one-per-simd"])
 def test_synth_holdout_every_dataset(gh, gsynth, batch):
     from magprop_amd import LogProb
     assert list(gh["synth_ds_names"]) == list(TYPES)
@@ -50,7 +57,7 @@ def test_synth_holdout_every_dataset(gh, gsynth, batch):
     assert np.all(out[~ok] == -np.inf)
     fin = np.isfinite(gh["synth_lnprob_tight"])
     frac = np.abs(out[fin] - gh["synth_lnprob_tight"][fin]) / (TIGHT_ATOL + TIGHT_RTOL * np.abs(gh["synth_lnprob_tight"][fin]))
-    _record(f"synth_batch{batch}", {"points": int(fin.sum()), "flags": int((st == 1).sum()), "max_fraction_of_tight_bound": float(frac.max()),
+    _record(gh["_tag"] + f"synth_batch{batch}", {"points": int(fin.sum()), "flags": int((st == 1).sum()), "max_fraction_of_tight_bound": float(frac.max()),
                                     "p999_fraction": float(np.quantile(frac, 0.999)), "lsoda_noise_points": int(len(gh["synth_lsoda_noise_idx"]))})
     assert frac.max() <= 1.0
 
@@ -70,4 +77,4 @@ def test_library_holdout_both_grids(gh, glib, grid):
     assert np.allclose(out2, out[ok], rtol=1e-12, atol=0.0)
     fin = np.isfinite(tight)
     frac = np.abs(out[fin] - tight[fin]) / (TIGHT_ATOL + TIGHT_RTOL * np.abs(tight[fin]))
-    _record(f"lib_{grid}", {"points": int(fin.sum()), "max_fraction_of_tight_bound": float(frac.max()), "p999_fraction": float(np.quantile(frac, 0.999))})
+    _record(gh["_tag"] + f"lib_{grid}", {"points": int(fin.sum()), "max_fraction_of_tight_bound": float(frac.max()), "p999_fraction": float(np.quantile(frac, 0.999))})

@@ -349,13 +349,16 @@ def test_adaptive_stride_restatement(gsynth, gflag, gflag2, tarr, cfg, spl):
                             noise_mask(gflag2, len(gflag2["ds"]))[sel])
 
 
-def test_holdout_points_the_policy_was_never_tuned_on(gsynth, tarr, cfg):
-    """tests/golden/golden_holdout.npz (seed drawn after the round-4 policy freeze; make_golden.py --only holdout): the serial
-    restatement in its adaptive (product-default) mode, every 4th point of each dataset's block, held to the reference's
-    verdicts and to both bounds.  The GPU path is held to ALL of them in tests/test_gpu_holdout.py."""
+@pytest.mark.parametrize("fixture", ["golden_holdout.npz", "golden_holdout2.npz"], ids=["round4-gate", "fresh"])
+def test_holdout_points(gsynth, tarr, cfg, fixture):
+    """Prior-wide hold-out points (make_golden.py --only holdout / holdout2): the serial restatement in its adaptive
+    (product-default) mode, every 4th point of each dataset's block, held to the reference's verdicts and to both bounds.
+    golden_holdout.npz was written in round 4 and then served as an acceptance gate for that round's last policy changes (a
+    regression set); golden_holdout2.npz was drawn in round 5 after the policy was final.  The GPU path is held to ALL
+    points of both in tests/test_gpu_holdout.py."""
     import os
     from conftest import GOLDEN
-    gh = np.load(os.path.join(GOLDEN, "golden_holdout.npz"))
+    gh = np.load(os.path.join(GOLDEN, fixture))
     worst = 0.0
     for d, name in enumerate(gh["synth_ds_names"]):
         sel = np.nonzero(gh["synth_ds"] == d)[0][::4]
