@@ -207,7 +207,9 @@ static int append_dataset(mp_handle *h, int d) {
     HIP_TRY(hipMemcpy(h->d_obs_y.p + o, s.y.data(), n * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->d_obs_yerr.p + o, s.yerr.data(), n * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->d_tile_ptr.p + t, s.tile_ptr.data(), s.tile_ptr.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    h->desc[d] = mp::DsDesc{(int32_t)n, (int32_t)o, (int32_t)t, 0};
+    int32_t flags = mp::kDsOnKnots;
+    for (size_t j = 0; j < n; ++j) if (s.dx[j] != 0.0) { flags = 0; break; }
+    h->desc[d] = mp::DsDesc{(int32_t)n, (int32_t)o, (int32_t)t, flags};
     HIP_TRY(hipMemcpy(h->d_ds.p + d, &h->desc[d], sizeof(mp::DsDesc), hipMemcpyHostToDevice));
     h->obs_used = o + n;
     h->tp_used = t + s.tile_ptr.size();

@@ -21,8 +21,11 @@ struct DsDesc {
     int32_t n_obs;
     int32_t obs_off;   // first observation in the packed obs_* arrays
     int32_t tile_off;  // first entry of this dataset's tile_ptr[n_tiles + 1]
-    int32_t pad;
+    int32_t flags;     // bit 0: every observed time IS a grid point (x - tgrid[g] == 0 throughout: the reference's synthetic sets,
+                       // code/synthetic_datasets/generate_data.py:61-67) -- np.interp then returns the model at grid point g itself and
+                       // the state at g + 1 is never needed
 };
+constexpr int kDsOnKnots = 1;
 
 // What a tile of the time-parallel solver needs to know about its step: tiles step over 1/8 of a grid interval (kind 0,
 // the first intervals), 1, 2, 4 or 8 intervals (kinds 1 .. 4).  The grid is geometric, so the ratio Q of consecutive step

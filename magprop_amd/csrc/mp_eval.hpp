@@ -519,7 +519,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
     // pass as a perfect fit (chi^2 = 0): lnprob = -inf with its own status, on every entry point.
     const int dsid = a.ds_id ? a.ds_id[walker] : 0;
     const bool ds_in_range = sh.ds != nullptr && dsid >= 0 && dsid < sh.n_ds;
-    const DsDesc dsd = ds_in_range ? sh.ds[dsid] : DsDesc{0, 0, 0, 0};
+    const DsDesc dsd = ds_in_range ? sh.ds[dsid] : DsDesc{0, 0, 0, 0};   // (n_obs, obs_off, tile_off, flags)
     if (a.want_chi2 && dsd.n_obs <= 0) status = MP_STATUS_BADDATASET;
     const int32_t *tptr = sh.tile_ptr + dsd.tile_off;
     // The first 64 observations of the walker's light curve live in registers, one per lane (time-sorted;
@@ -544,6 +544,10 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
     // handle holds such a dataset; the short variant keeps that code out of the register budget)
     const bool long_lc = (CURVES || LONG) && a.want_chi2 && dsd.n_obs > 64;
     const bool deferred = !CURVES && a.want_chi2;               // see "observations" below
+    // Every observed time of this light curve is a grid point (the reference's synthetic sets are built that way): np.interp's
+    // weight of the upper bracket is exactly zero, fma((L1 - L0) idt, 0, L0) = L0 bit for bit (the luminosities are finite by
+    // construction), so neither the state nor the luminosity at grid point g + 1 is formed (mode A, the first 64 observations).
+    const bool on_knots = !LONG && (dsd.flags & kDsOnKnots) != 0;
     double obM[2] = {1.0e30, 1.0e30}, obW[2] = {1.0e3, 1.0e3};  // (Mdisc, omega) at the observation's bracketing grid points
     double chi = 0.0, chi_long = 0.0;
     int sweeps_total = 0, tiles_total = 0;
@@ -1379,7 +1383,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                     const int p8 = 8 * ob_g;
                     if (ob_g >= 0 && p8 >= pos8 && p8 < end_kept8) {
                         image_state(sh, w, im, tt, kind, pos8, keep, t_s, p8, obM[0], obW[0]);
-                        image_state(sh, w, im, tt, kind, pos8, keep, t_s, p8 + 8, obM[1], obW[1]);
+                        if (!on_knots) image_state(sh, w, im, tt, kind, pos8, keep, t_s, p8 + 8, obM[1], obW[1]);
                     }
                     if constexpr (LONG) {
                         if (long_lc) {
@@ -1581,7 +1585,17 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
             kind = next_kind;
             MP_PHASE(12)
         }
-        if (deferred && status == MP_STATUS_OK) {   // the luminosity evaluations of this walker: one per 64 observations
+        if (deferred && status == MP_STATUS_OK && on_knots) {   // the luminosity at the observations' own grid points
+            const Vd<1> Mv{{obM[0]}}, Wv{{obW[0]}};
+            const DiscPt<1> dp = disc_point(sh, w, Mv);
+            Vd<1> Lt, Lp, Ld;
+            luminosity(sh, w, dp, Wv, Lt, Lp, Ld);
+            if (ob_g >= 0) {
+                const int jj = dsd.obs_off + lane;
+                const double res = (sh.obs_y[jj] - Lt[0] / 1.0e50) / sh.obs_yerr[jj];
+                chi = res * res;
+            }
+        } else if (deferred && status == MP_STATUS_OK) {   // the luminosity evaluations of this walker: one per 64 observations
             const Vd<2> Mv{{obM[0], obM[1]}}, Wv{{obW[0], obW[1]}};
             const DiscPt<2> dp = disc_point(sh, w, Mv);
             Vd<2> Lt, Lp, Ld;

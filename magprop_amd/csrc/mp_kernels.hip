@@ -512,8 +512,13 @@ int launch_lnprob(const DevShared &sh, const LaunchArgs &a, void *stream) {
             else hipLaunchKernelGGL((lnprob_team_kernel<1, 4, 2, false>), grid, dim3(256), 0, st, sh, a);
         } else {
 #ifdef MP_EXPERIMENTS
-            if (log) hipLaunchKernelGGL((lnprob_team_kernel<2, 2, 1, true>), grid, dim3(128), 0, st, sh, a);
-            else hipLaunchKernelGGL((lnprob_team_kernel<2, 2, 1, false>), grid, dim3(128), 0, st, sh, a);
+            if (2 * a.n <= sh.n_simd) {
+                if (log) hipLaunchKernelGGL((lnprob_team_kernel<2, 2, 1, true>), grid, dim3(128), 0, st, sh, a);
+                else hipLaunchKernelGGL((lnprob_team_kernel<2, 2, 1, false>), grid, dim3(128), 0, st, sh, a);
+            } else {
+                if (log) hipLaunchKernelGGL((lnprob_team_kernel<2, 2, 2, true>), grid, dim3(128), 0, st, sh, a);
+                else hipLaunchKernelGGL((lnprob_team_kernel<2, 2, 2, false>), grid, dim3(128), 0, st, sh, a);
+            }
 #endif
         }
         return (int)hipGetLastError();
