@@ -7,7 +7,8 @@ if [ $PART != b ]; then
 KERN=lnprob_kernel    bash tools/profile.sh ${R}_n1024 --no-mcmc > /dev/null || exit 1
 KERN=lnprob_kernel    bash tools/profile.sh ${R}_n4096_classic --config 3 --no-mcmc > /dev/null || exit 2
 KERN=lnprob_kernel    bash tools/profile.sh ${R}_n8192 --config 4 --no-mcmc > /dev/null || exit 3
-KERN=lnprob_kernel    bash tools/profile.sh ${R}_n512 --nwalk 512 --no-mcmc > /dev/null || exit 6
+KERN=lnprob_team_kernel bash tools/profile.sh ${R}_n512 --nwalk 512 --no-mcmc > /dev/null || exit 6
+KERN=lnprob_team_kernel bash tools/profile.sh ${R}_n256 --nwalk 256 --no-mcmc > /dev/null || exit 8
 fi
 if [ $PART = a ]; then echo done; exit 0; fi
 KERN=lnprob_kernel    bash tools/profile.sh ${R}_curve1024 --curve --no-mcmc > /dev/null || exit 4
