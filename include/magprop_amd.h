@@ -104,6 +104,13 @@ typedef struct mp_model_cfg {
     double stride_tol;         /* smoothness indicator h |4th difference of (f - lambda omega)| / omega above which a tile   */
                                /* stepping over 2, 4 or 8 grid intervals is cut back to single intervals; 0 =                */
                                /* MP_STRIDE_TOL_DEFAULT                                                                      */
+    int32_t dipole_torque;     /* ABI 5.  0: Ndip = -mu^2 omega^3 / (6 c^3), every model of the reference's packages          */
+                               /* (magnetar/funcs.py:78; "Piro & Ott" in code/figure_3.py:79).  1: the alternative torque law */
+                               /* of code/figure_3.py:105-165 ("Bucciantini"): Ndip = -(2/3) (mu^2 omega^3 / c^3) (Rlc/Rm)^3  */
+                               /* with Rm after the light-cylinder cap.  It changes the ODE's torque only, as in that script  */
+                               /* (which integrates and plots radii and torques, no luminosity).  Served by the curve kernels */
+                               /* (mp_model_lc, mp_rhs_batch, mp_lnprob_batch); the device-resident sampler refuses it        */
+    int32_t reserved;          /* 0                                                                                           */
 } mp_model_cfg;
 
 /* Stride adaptivity of the solver: where the solution is smooth on the scale of the output grid the

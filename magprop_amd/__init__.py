@@ -6,7 +6,7 @@
 Everything is evaluated by hand-written HIP kernels behind the C ABI of include/magprop_amd.h; there
 is no CPU fallback.
 """
-from . import _capi, engine, fit_stats, funcs, mcmc_eqns, synth  # noqa: F401
+from . import _capi, engine, figure_3, fit_stats, funcs, mcmc_eqns, synth  # noqa: F401
 from .ensemble import EnsembleSampler  # noqa: F401
 from .logprob import LogProb  # noqa: F401
 from ._capi import MagpropAmdError  # noqa: F401

@@ -45,7 +45,8 @@ class ModelCfg(C.Structure):
     _fields_ = [(n, C.c_double) for n in (
         "inertia_factor", "rm_massflow_factor", "n_ode", "n_lum", "alpha", "cs7", "k",
         "dipeff", "propeff", "f_beam", "nacc_lum_threshold")] + [
-        ("lprop_gm_term", C.c_int32), ("max_stride", C.c_int32), ("sweep_tol", C.c_double), ("stride_tol", C.c_double)]
+        ("lprop_gm_term", C.c_int32), ("max_stride", C.c_int32), ("sweep_tol", C.c_double), ("stride_tol", C.c_double),
+        ("dipole_torque", C.c_int32), ("reserved", C.c_int32)]
 
 
 def build(force=False, verbose=False):

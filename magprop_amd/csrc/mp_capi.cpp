@@ -257,12 +257,12 @@ const char *mp_last_error(void) { return g_err.c_str(); }
 
 void mp_cfg_synth(mp_model_cfg *c) {
     if (!c) return;
-    *c = mp_model_cfg{0.35, 3.0, 10.0, 10.0, 0.1, 1.0, 0.9, 1.0, 1.0, 1.0, 0.27, 1, 0, 0.0, 0.0};
+    *c = mp_model_cfg{0.35, 3.0, 10.0, 10.0, 0.1, 1.0, 0.9, 1.0, 1.0, 1.0, 0.27, 1, 0, 0.0, 0.0, 0, 0};
 }
 
 void mp_cfg_lib(mp_model_cfg *c) {
     if (!c) return;
-    *c = mp_model_cfg{0.8, 1.0, 1.0, 1.0, 0.1, 1.0, 0.9, 0.05, 0.4, 1.0, 0.0, 0, 0, 0.0, 0.0};
+    *c = mp_model_cfg{0.8, 1.0, 1.0, 1.0, 0.1, 1.0, 0.9, 0.05, 0.4, 1.0, 0.0, 0, 0, 0.0, 0.0, 0, 0};
 }
 
 mp_handle *mp_create(const mp_model_cfg *cfg, const double *tgrid, int n_grid, int device) {
@@ -301,6 +301,10 @@ mp_handle *mp_create(const mp_model_cfg *cfg, const double *tgrid, int n_grid, i
         !(cfg->max_stride == 0 || cfg->max_stride == 1 || cfg->max_stride == 2 || cfg->max_stride == 4 ||
           cfg->max_stride == 8)) {
         fail(MP_EINVAL, "mp_create: cfg.max_stride must be 0, 1, 2, 4 or 8 and cfg.stride_tol 0 or in (0, 1e-3]");
+        return nullptr;
+    }
+    if (cfg->dipole_torque != 0 && cfg->dipole_torque != 1) {
+        fail(MP_EINVAL, "mp_create: cfg.dipole_torque must be 0 (the packages' dipole torque) or 1 (code/figure_3.py's Bucciantini law)");
         return nullptr;
     }
     int count = 0;
@@ -942,6 +946,7 @@ mp_sampler *mp_sampler_create(mp_handle *h, int n_walkers, int n_ensembles, int 
         return nullptr;
     }
     if (!(a > 1.0)) { fail(MP_EINVAL, "mp_sampler_create: stretch scale a must exceed 1"); return nullptr; }
+    if (target == 0 && h->sh.cfg.dipole_torque != 0) { fail(MP_ESTATE, "mp_sampler_create: the alternative dipole torque (cfg.dipole_torque = 1) is served by the curve kernels only"); return nullptr; }
     Lock lock(h->mu);
     if (target == 0) {
         for (int e = 0; e < n_ensembles; ++e) {

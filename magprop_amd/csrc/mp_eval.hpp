@@ -115,11 +115,41 @@ MP_DEV Flow<N> flow_state(const Walker &w, double n, const DiscPt<N> &p, const V
 }
 
 // d(omega)/dt, code/synthetic_datasets/funcs.py:119,131-140; lam = d(omega_dot)/d(omega)
-template <bool WANT_LAM, int N>
+// ALT: built with the alternative dipole torque of code/figure_3.py:105-165 (cfg.dipole_torque = 1; the curve kernels and the
+// right-hand-side kernel only: the hot mode-A kernels do not carry the branch):
+//   Ndip = -(2/3) (mu^2 omega^3 / c^3) (Rlc / Rm)^3 = -(2/3) mu^2 / Rm^3 with Rm after the cap, i.e. Ndip / I = -4 DI (c / Rm)^3
+// (DI = mu^2 / (6 c^3 I)); it depends on omega through the capped radius Rm = k c / omega only: d/d omega = -12 DI omega^2 / k^3.
+template <bool WANT_LAM, bool ALT = false, int N>
 MP_DEV Vd<N> omega_rhs(const DevShared &sh, const Walker &w, const DiscPt<N> &p, const Vd<N> &om, Vd<N> &rot,
                        Vd<N> &lam) {
     const Flow<N> f = flow_state(w, sh.cfg.n_ode, p, om);
     Vd<N> out;
+    if constexpr (ALT) {
+        if (sh.cfg.dipole_torque == 1) {
+            const Vd<N> irm = rcp_fast(f.Rm);
+            FORN {
+                const double om2 = om[i] * om[i];
+                rot[i] = sh.crot * om2;
+                const double live = __hiloint2double(rot[i] > 0.27 ? 0 : 0x3FF00000, 0);
+                const double arm = live * (w.armI * fmax(f.sq[i], sh.sqrtR));
+                const double nacc = -arm * p.mdot[i] * f.th[i];
+                const double cr = kC * irm[i];                                   // c / Rm  (= omega / k where the radius is capped)
+                const double dip = -4.0 * w.DI * (cr * cr * cr);
+                if (WANT_LAM) {
+                    const double cf = __hiloint2double(f.capped[i] ? (int)0xBFE00000 : 0x3FF00000, 0);
+                    const double dfast = cf * f.fast[i] * f.inv_om[i];
+                    const double dth = sh.cfg.n_ode * (4.0 * f.e[i] * f.r[i] * f.r[i]) * dfast;
+                    const double cd = __hiloint2double((f.capped[i] && f.sq[i] >= sh.sqrtR) ? (int)0xBFE00000 : 0, 0);
+                    const double darm = cd * arm * f.inv_om[i];
+                    const double dn = -p.mdot[i] * fma(darm, f.th[i], arm * dth);
+                    const double ddip = f.capped[i] ? 3.0 * dip * f.inv_om[i] : 0.0;   // d/d omega of -4 DI (omega / k)^3
+                    lam[i] = ddip + dn;
+                }
+                out[i] = dip + nacc;
+            }
+            return out;
+        }
+    }
     FORN {
         const double om2 = om[i] * om[i];
         rot[i] = sh.crot * om2;
@@ -501,7 +531,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
         const Vd<1> Mv{{M_s}}, ov{{om_s}};
         const DiscPt<1> d_s = disc_point(sh, w, Mv);
         Vd<1> rot0, dummy, Lt0, Lp0, Ld0;
-        cf0 = omega_rhs<false>(sh, w, d_s, ov, rot0, dummy)[0];
+        cf0 = omega_rhs<false, CURVES>(sh, w, d_s, ov, rot0, dummy)[0];
         flags_s = branch_flags(w, d_s.rmu[0], om_s);
         if (status == MP_STATUS_OK) {
             if (!(isfinite(M_s) && isfinite(om_s)) || M_s <= 0.0 || om_s <= 0.0) status = MP_STATUS_NONFINITE;
@@ -853,9 +883,9 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
 #endif
                 if (light) {
                     Vd<kSPL> unused;
-                    f1 = omega_rhs<false>(sh, w, d1, wg, rot, unused);
+                    f1 = omega_rhs<false, CURVES>(sh, w, d1, wg, rot, unused);
                 } else {
-                    f1 = omega_rhs<true>(sh, w, d1, wg, rot, lam);
+                    f1 = omega_rhs<true, CURVES>(sh, w, d1, wg, rot, lam);
                 }
 #pragma unroll
                 for (int s = 0; s < kSPL; ++s) {

@@ -470,7 +470,7 @@ __global__ __launch_bounds__(64) void rhs_kernel(const DevShared sh, const RhsAr
     const Vd<1> S = mdot_fb(w, tv);
     const DiscPt<1> d = disc_point(sh, w, Mv);
     Vd<1> rot, lam;
-    const Vd<1> f = omega_rhs<true>(sh, w, d, ov, rot, lam);
+    const Vd<1> f = omega_rhs<true, true>(sh, w, d, ov, rot, lam);
     if (i < r.n) {
         r.dydt[2 * (size_t)i] = S[0] - Mv[0] * w.inv_tau;
         r.dydt[2 * (size_t)i + 1] = f[0];
@@ -486,7 +486,9 @@ int launch_rhs(const DevShared &sh, const RhsArgs &r, void *stream) {
 
 int launch_lnprob(const DevShared &sh, const LaunchArgs &a, void *stream) {
     if (a.n <= 0) return 0;
-    const bool curves = a.ltot || a.lprop || a.ldip || a.mdisc || a.omega;
+    // (the alternative dipole torque, cfg.dipole_torque = 1, lives in the curve kernels only: such a handle runs them for
+    // every batch, with or without curve outputs)
+    const bool curves = a.ltot || a.lprop || a.ldip || a.mdisc || a.omega || sh.cfg.dipole_torque != 0;
     dim3 grid((unsigned)a.n), block(64);
     // Variants (results agree to rounding); sh.n_simd = SIMDs of the device:
     //  - up to n_simd walkers (one wave per SIMD): four steps per lane (256-step tiles amortise the wavefront scans best;

@@ -20,7 +20,7 @@ class Cfg(C.Structure):
     _fields_ = [(n, C.c_double) for n in (
         "inertia_factor", "rm_massflow_factor", "n_ode", "n_lum", "alpha", "cs7", "k",
         "dipeff", "propeff", "f_beam", "nacc_lum_threshold")] + [
-        ("lprop_gm_term", C.c_int32), ("reserved", C.c_int32)]
+        ("lprop_gm_term", C.c_int32), ("dipole_torque", C.c_int32)]
 
 
 def cfg_synth(**kw):

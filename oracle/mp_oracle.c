@@ -54,7 +54,9 @@
 typedef struct mpo_cfg {
     double inertia_factor, rm_massflow_factor, n_ode, n_lum, alpha, cs7, k;
     double dipeff, propeff, f_beam, nacc_lum_threshold;
-    int32_t lprop_gm_term, reserved;
+    int32_t lprop_gm_term;
+    int32_t dipole_torque;   /* 0: Ndip = -mu^2 omega^3 / (6 c^3) (magnetar/funcs.py:78; code/figure_3.py:79, "Piro & Ott");
+                                1: Ndip = -(2/3) (mu^2 omega^3 / c^3) (Rlc / Rm)^3, Rm after the cap (code/figure_3.py:140-141, "Bucciantini") */
 } mpo_cfg;
 
 enum { MPO_OK = 0, MPO_FLAG = 1, MPO_NONFINITE = 2, MPO_PRIOR = 3 };
@@ -123,6 +125,10 @@ static double omega_dot(const mpo_cfg *c, const wk *w, double Mdisc, double omeg
     flow f;
     flow_state(c, w, c->n_ode, Mdisc, omega, &f);
     double Ndip = (-1.0 * pow(w->mu, 2.0) * pow(omega, 3.0)) / (6.0 * pow(C_, 3.0));
+    if (c->dipole_torque == 1) {   /* code/figure_3.py:140-141 */
+        double Rlc = C_ / omega;
+        Ndip = (-2.0 / 3.0) * ((pow(w->mu, 2.0) * pow(omega, 3.0)) / pow(C_, 3.0)) * pow(Rlc / f.Rm, 3.0);
+    }
     double Nacc;
     int branch;
     if (f.rot_param > 0.27) {
@@ -151,6 +157,8 @@ static double omega_dot(const mpo_cfg *c, const wk *w, double Mdisc, double omeg
         else if (branch == 2)
             dNacc = pow(w->GM * R_, 0.5) * ddiff;
         double dNdip = (-3.0 * pow(w->mu, 2.0) * pow(omega, 2.0)) / (6.0 * pow(C_, 3.0));
+        if (c->dipole_torque == 1)   /* Ndip = -(2/3) mu^2 / Rm^3: depends on omega through the capped radius only */
+            dNdip = 2.0 * pow(w->mu, 2.0) * dRm / pow(f.Rm, 4.0);
         *dfdw = (dNacc + dNdip) / w->I;
     }
     return (Nacc + Ndip) / w->I;

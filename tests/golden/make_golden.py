@@ -20,7 +20,8 @@ What is called (paths relative to /root/reference):
 `*_tight` arrays: the same reference code with its odeint call given rtol=atol=1e-12 (integrator noise
 removed; see tight_lsoda).
 Outputs: golden_synth.npz, golden_lib.npz, golden_flagscan.npz, golden_corners.npz, golden_libscan.npz, golden_longlc.npz,
-golden_flagscan2.npz, golden_libscan2.npz, golden_rhs.npz, golden_libkw.npz, golden_swift.npz, MANIFEST.json.
+golden_flagscan2.npz, golden_libscan2.npz, golden_rhs.npz, golden_libkw.npz, golden_swift.npz, golden_fig3.npz (the two models of
+code/figure_3.py: piroott :40-102, bucciantini :105-165), golden_holdout.npz / golden_holdout2.npz (--only), MANIFEST.json.
 `--only tight` (make_tight) adds to the scan fixtures the tight-integrator value of EVERY successful point and the
 enumerated LSODA-noise points (`*lsoda_noise_idx`): where the reference's default run is itself off by more than the
 SURVEY.md 8(c) contract 1e-5 + 2e-6 |ref|.
@@ -401,6 +402,66 @@ def make_holdout(n_synth=900, n_lib=600, seed=HOLDOUT_SEED, out_name="golden_hol
     np.savez_compressed(os.path.join(HERE, out_name), **out)
 
 
+def make_fig3(n_sets=12, n_rhs=400):
+    """code/figure_3.py: the script's two right-hand sides, `piroott` (:40-102) and `bucciantini` (:105-165), and the two
+    trajectories it integrates (:194-201).  The script plots at import: it is imported ONCE, in a scratch directory with a
+    non-interactive backend (its `plots/` folder lands there), and its functions and results are used as they are.  Stored:
+    the script's own (default LSODA) trajectories decimated, the same at rtol = atol = 1e-12, both models over `n_sets`
+    further parameter sets (tight, decimated; the break-up verdict where the integrator gives up), and both right-hand
+    sides at `n_rhs` states along and around those trajectories."""
+    import importlib.util
+    import tempfile
+    os.environ["MPLBACKEND"] = "Agg"
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as td:
+        os.chdir(td)
+        spec = importlib.util.spec_from_file_location("ref_figure_3", os.path.join(REF, "code", "figure_3.py"))
+        fig = importlib.util.module_from_spec(spec)
+        with contextlib.redirect_stdout(io.StringIO()):
+            spec.loader.exec_module(fig)
+        os.chdir(cwd)
+    tarr = fig.tarr
+    dec = 10
+    out = {"decim": np.array([dec]), "tarr": tarr[::dec],
+           "script_pars": np.array([fig.B, fig.P, fig.MdiscI, fig.RdiscI, fig.epsilon, fig.delta]),
+           "script_piroott": np.stack([fig.po_Mdisc, fig.po_omega])[:, ::dec],
+           "script_bucciantini": np.stack([fig.b_Mdisc, fig.b_omega])[:, ::dec]}
+    args0 = (fig.B, fig.MdiscI, fig.RdiscI, fig.epsilon, fig.delta)
+    y0 = fig.init_conds(fig.MdiscI, fig.P)
+    for name, f in (("piroott", fig.piroott), ("bucciantini", fig.bucciantini)):
+        sol = odeint(f, y0, tarr, args=args0, rtol=1e-12, atol=1e-12, mxstep=100000)
+        out[f"script_{name}_tight"] = sol.T[:, ::dec]
+    rng = np.random.default_rng(SEED0 + 303)
+    P = np.column_stack([rng.uniform(0.5, 5.0, n_sets), rng.uniform(1.0, 10.0, n_sets), 10.0 ** rng.uniform(-4.0, -2.0, n_sets),
+                         rng.uniform(100.0, 1000.0, n_sets), 10.0 ** rng.uniform(-1.0, 1.0, n_sets), 10.0 ** rng.uniform(-0.5, 1.0, n_sets)])
+    out["pars"] = P
+    states = {"piroott": [], "bucciantini": []}
+    for name, f in (("piroott", fig.piroott), ("bucciantini", fig.bucciantini)):
+        trajs, ok = [], []
+        for p in P:
+            a_ = (p[0], p[2], p[3], p[4], p[5])
+            with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+                sol, info = odeint(f, fig.init_conds(p[2], p[1]), tarr, args=a_, rtol=1e-12, atol=1e-12, mxstep=100000, full_output=True)
+            good = info["message"] == "Integration successful." and np.all(np.isfinite(sol))
+            ok.append(good)
+            trajs.append(sol.T[:, ::50] if good else np.full((2, len(tarr[::50])), np.nan))
+            if good:
+                idx = rng.integers(0, len(tarr), 40)
+                for i in idx:
+                    states[name].append((p, tarr[i], sol[i] * (1.0 + 0.02 * rng.standard_normal(2))))
+        out[f"{name}_tight_dec50"] = np.array(trajs)
+        out[f"{name}_ok"] = np.array(ok)
+    for name, f in (("piroott", fig.piroott), ("bucciantini", fig.bucciantini)):
+        st = states[name]
+        pick = rng.choice(len(st), min(n_rhs, len(st)), replace=False)
+        pp = np.array([st[i][0] for i in pick]); tt = np.array([st[i][1] for i in pick]); yy = np.array([st[i][2] for i in pick])
+        dy = np.array([f(yy[i], tt[i], pp[i, 0], pp[i, 2], pp[i, 3], pp[i, 4], pp[i, 5]) for i in range(len(pick))])
+        out[f"rhs_{name}_pars"], out[f"rhs_{name}_t"], out[f"rhs_{name}_y"], out[f"rhs_{name}_dydt"] = pp, tt, yy, dy
+    np.savez_compressed(os.path.join(HERE, "golden_fig3.npz"), **out)
+    print("fig3: sets ok", int(out["piroott_ok"].sum()), int(out["bucciantini_ok"].sum()), "of", n_sets, "; rhs points",
+          len(out["rhs_piroott_t"]), len(out["rhs_bucciantini_t"]), flush=True)
+
+
 def make_corners():
     """All 64 corners of the synth prior box on the Humped dataset, plus the largest rotation parameter the
     reference's own trajectory reaches (so tests can tell 'rode the break-up limit but LSODA survived')."""
@@ -719,7 +780,7 @@ def make_swift():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--flag-scan", type=int, default=1500)
-    ap.add_argument("--only", choices=["all", "lib", "libkw", "corners", "libscan", "longlc", "flagscan2", "libscan2", "rhs", "tight", "swift", "holdout", "holdout2"], default="all", help="regenerate only one file")
+    ap.add_argument("--only", choices=["all", "lib", "libkw", "corners", "libscan", "longlc", "flagscan2", "libscan2", "rhs", "tight", "swift", "holdout", "holdout2", "fig3"], default="all", help="regenerate only one file")
     a = ap.parse_args()
     import scipy, pandas
     if a.only == "all":
@@ -748,6 +809,8 @@ def main():
         make_holdout(n_synth=600, n_lib=400, seed=HOLDOUT2_SEED, out_name="golden_holdout2.npz")
     if a.only in ("all", "swift"):
         make_swift()
+    if a.only in ("all", "fig3"):
+        make_fig3()
     manifest = {
         "generator": "tests/golden/make_golden.py",
         "reference": "sgibson91/magprop mounted at /root/reference (magnetar v%s)" % lib.__version__

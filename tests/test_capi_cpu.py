@@ -50,7 +50,7 @@ def test_python_mirror_follows_the_header_constants():
 
 
 def test_cfg_struct_layout_and_presets():
-    assert ctypes.sizeof(_capi.ModelCfg) == 11 * 8 + 2 * 4 + 2 * 8
+    assert ctypes.sizeof(_capi.ModelCfg) == 11 * 8 + 2 * 4 + 2 * 8 + 2 * 4
     c0 = _capi.cfg_synth()
     assert c0.sweep_tol == 0.0 and c0.stride_tol == 0.0 and c0.max_stride == 0   # 0 = the library defaults (MP_*_DEFAULT)
     s, l = _capi.cfg_synth(), _capi.cfg_lib()

@@ -4,6 +4,8 @@
   (3) size-independent properties at BASELINE.json's full sizes.
 Tolerances are written next to each comparison; DESIGN.md section 5 explains them.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -708,3 +710,66 @@ def test_light_curves_with_real_swift_time_stamps(mpa, gswift, gsynth, name):
     ll = mpa.lnlike(gswift[f"swift_{name}_libS_pars"], data, "S")
     r, t = gswift[f"swift_{name}_libS_lnlike"], gswift[f"swift_{name}_libS_lnlike_tight"]
     assert_vs_reference(ll, r, np.isfinite(r), t, noise_mask(gswift, len(r), f"swift_{name}_libS_lsoda_noise_idx"))
+
+
+# ---------------------------------------------------------------- code/figure_3.py: the alternative torque law
+@pytest.mark.parametrize("model", ["piroott", "bucciantini"])
+def test_figure_3_models(mpa, gsynth, model):
+    """The two spin-down models of the reference's code/figure_3.py: `piroott` (:40-102: the packages'
+    dipole torque; I = 0.8 M R^2, factor 3 in the Alfven radius, n = 10) and `bucciantini` (:105-165: Ndip = -(2/3) mu^2
+    omega^3 / c^3 (Rlc / Rm)^3, `mp_model_cfg.dipole_torque = 1`) against values produced by importing that script
+    (tests/golden/golden_fig3.npz): right-hand sides point by point, the script's own two trajectories, twelve further
+    parameter sets with the break-up verdict.  A handle with the alternative torque serves lnprob batches through the curve
+    kernels and refuses the device-resident sampler."""
+    from magprop_amd import LogProb, _capi, figure_3
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "golden_fig3.npz"))
+    f = getattr(figure_3, model)
+    P, t, y, ref = g[f"rhs_{model}_pars"], g[f"rhs_{model}_t"], g[f"rhs_{model}_y"], g[f"rhs_{model}_dydt"]
+    out = f(y, t, P[:, 0], P[:, 2], P[:, 3], P[:, 4], P[:, 5])
+    scale0 = np.maximum(np.abs(ref[:, 0]), y[:, 0] / (P[:, 3] * 1.0e5 / 1.0e6))
+    assert np.all(np.abs(out[:, 0] - ref[:, 0]) <= 1e-11 * scale0)
+    assert np.all(np.abs(out[:, 1] - ref[:, 1]) <= 2e-11 * np.abs(ref[:, 1]) + 1e-300)
+    one = f(y[0], t[0], P[0, 0], P[0, 2], P[0, 3], P[0, 4], P[0, 5])              # scalar form, as an odeint callable gets it
+    assert one.shape == (2,) and np.array_equal(one, out[0])
+    d = int(g["decim"][0])
+    tarr, M, W = figure_3.trajectory(model, *g["script_pars"])
+    assert np.array_equal(tarr[::d], g["tarr"])
+    for key, rtol in ((f"script_{model}", 5e-6), (f"script_{model}_tight", 5e-7)):     # default LSODA as the script runs it / tight
+        assert np.allclose(M[::d], g[key][0], rtol=rtol, atol=0.0) and np.allclose(W[::d], g[key][1], rtol=rtol, atol=0.0), key
+    for p, traj, ok in zip(g["pars"], g[f"{model}_tight_dec50"], g[f"{model}_ok"]):
+        res = figure_3.trajectory(model, *p)
+        assert (not isinstance(res, str)) == bool(ok), p
+        if ok:
+            assert np.allclose(res[1][::50], traj[0], rtol=5e-7, atol=0.0) and np.allclose(res[2][::50], traj[1], rtol=5e-7, atol=0.0), p
+    if model == "bucciantini":
+        # the two laws differ where it matters (the script's figure): the spin at late times
+        _, _, W0 = figure_3.trajectory("piroott", *g["script_pars"])
+        assert abs(W[-1] / W0[-1] - 1.0) > 1e-2
+        # an lnprob batch on a handle with the alternative torque: curve kernels, finite, different from the default law's
+        x, yy, ye = gsynth["Humped_x"], gsynth["Humped_y"], gsynth["Humped_yerr"]
+        from magprop_amd import engine
+        cfg1 = _capi.cfg_synth(dipole_torque=1)
+        h1 = _capi.Handle(cfg1, engine.grid(None))
+        h0 = _capi.Handle(_capi.cfg_synth(), engine.grid(None))
+        for h in (h0, h1):
+            h.set_dataset(0, x, yy, ye)
+            h.set_prior(gsynth["prior_lower"], gsynth["prior_upper"], LOG_MASK)
+        Pq = np.array(TRUTHS["Humped"]) + 1e-3 * np.random.default_rng(2).standard_normal((40, 6))
+        a, sa = h1.lnprob_batch(Pq, want_status=True)
+        b, sb = h0.lnprob_batch(Pq, want_status=True)
+        assert np.all(sa == 0) and np.all(np.isfinite(a)) and not np.allclose(a, b, rtol=1e-6)
+        with pytest.raises(_capi.MagpropAmdError, match="curve kernels"):
+            _raise_sampler(h1)
+        h0.close()
+        h1.close()
+
+
+def _raise_sampler(h):
+    """mp_sampler_create on a handle with cfg.dipole_torque = 1, through the binding."""
+    from magprop_amd import _capi
+    L = _capi.lib()
+    s = L.mp_sampler_create(h._h, 8, 1, 6, None, 1, 2.0, 0)
+    if not s:
+        raise _capi.MagpropAmdError(_capi.last_error())
+    L.mp_sampler_destroy(s)

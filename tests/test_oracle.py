@@ -271,6 +271,43 @@ def test_c_oracle_rhs_vs_reference(grhs, name):
     assert worst < 1e-11
 
 
+# ---------------------------------------------------------------- code/figure_3.py: the two torque laws
+def _fig3_cfg(model):
+    return co.cfg_lib(inertia_factor=0.8, rm_massflow_factor=3.0, n_ode=10.0, n_lum=10.0, dipole_torque=int(model == "bucciantini"))
+
+
+@pytest.mark.parametrize("model", ["piroott", "bucciantini"])
+def test_figure_3_models_vs_reference(model):
+    """tests/golden/golden_fig3.npz (make_golden.py --only fig3: the script imported once, its functions called): both
+    right-hand sides point by point at 400 states, the Jacobian entry of the alternative torque against a central difference,
+    the script's own two trajectories (default LSODA: 5e-6; rtol = atol = 1e-12: 5e-7) and the tight
+    trajectories of twelve further parameter sets with the break-up verdict where the reference's integrator gives up."""
+    import os
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "golden_fig3.npz"))
+    cfg = _fig3_cfg(model)
+    P, t, y, ref = g[f"rhs_{model}_pars"], g[f"rhs_{model}_t"], g[f"rhs_{model}_y"], g[f"rhs_{model}_dydt"]
+    for i in range(len(P)):
+        out, lam = co.rhs(cfg, P[i], t[i], y[i, 0], y[i, 1])
+        scale0 = max(abs(ref[i, 0]), y[i, 0] / (P[i, 3] * 1.0e5 / 1.0e6))
+        assert abs(out[0] - ref[i, 0]) <= 1e-12 * scale0 and abs(out[1] - ref[i, 1]) <= 1e-11 * abs(ref[i, 1]) + 1e-300, (i, out, ref[i])
+        if i % 20 == 0:
+            h = 1e-6 * y[i, 1]
+            fd = (co.rhs(cfg, P[i], t[i], y[i, 0], y[i, 1] + h)[0][1] - co.rhs(cfg, P[i], t[i], y[i, 0], y[i, 1] - h)[0][1]) / (2 * h)
+            assert abs(lam - fd) <= 2e-4 * abs(fd) + 1e-6 * abs(out[1] / y[i, 1]), (i, lam, fd)
+    tarr = np.logspace(0.0, 6.0, 10001)
+    d = int(g["decim"][0])
+    st, M, W = co.trajectory(cfg, g["script_pars"], tarr)
+    assert st == 0
+    for key, rtol in ((f"script_{model}", 5e-6), (f"script_{model}_tight", 5e-7)):
+        assert np.allclose(M[::d], g[key][0], rtol=rtol, atol=0.0) and np.allclose(W[::d], g[key][1], rtol=rtol, atol=0.0), key
+    for p, traj, ok in zip(g["pars"], g[f"{model}_tight_dec50"], g[f"{model}_ok"]):
+        st, M, W = co.trajectory(cfg, p, tarr)
+        assert (st == 0) == bool(ok), (p, st)
+        if ok:
+            assert np.allclose(M[::50], traj[0], rtol=5e-7, atol=0.0) and np.allclose(W[::50], traj[1], rtol=5e-7, atol=0.0), p
+
+
 # ---------------------------------------------------------------- scipy/LSODA port
 @pytest.mark.parametrize("name", TYPES)
 def test_lsoda_port_matches_reference(gsynth, tarr, name):
