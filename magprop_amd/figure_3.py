@@ -29,8 +29,8 @@ def bucciantini(y, t, B, MdiscI, RdiscI, epsilon, delta, device=-1):
 
 
 def trajectory(model, B, P, MdiscI, RdiscI, epsilon, delta, device=-1):
-    """(tarr, Mdisc, omega) of ``odeint(model, init_conds(MdiscI, P), tarr, args=(B, MdiscI, RdiscI, epsilon, delta))``
-    (code/figure_3.py:194-201) for model "piroott" or "bucciantini"; the string "flag" where the reference's integrator
+    """(tarr, Mdisc, omega) as the script's two integrations return them (code/figure_3.py:194-201: `model` from
+    ``init_conds(MdiscI, P)`` over ``tarr`` with ``args=(B, MdiscI, RdiscI, epsilon, delta)``) for model "piroott" or "bucciantini"; the string "flag" where the reference's integrator
     gives up (break-up limit), as the packages' light-curve functions do."""
     if model not in ("piroott", "bucciantini"):
         raise ValueError("model must be 'piroott' or 'bucciantini'")
