@@ -444,16 +444,60 @@ MP_DEV void image_state(const DevShared &sh, const Walker &w, const TileImage<SP
                         int pos8, int keep, double t_s, int p8, double &Mv, double &Wv) {
     const int sh8 = kind == 0 ? 0 : kind + 2;                        // d8 = 1 << sh8
     const int rel = p8 - pos8, J = rel >> sh8, rem = rel - (J << sh8);
-    Mv = im.M[J];
-    Wv = im.W[J];
+    if constexpr (SPL < 4) {
+        // (the 128-step kernels keep two wavefronts per SIMD, which hide each other's LDS latency, on 256 registers each: the two
+        // dozen values of the batched form below cost them scratch memory.  They read as they go.)
+        Mv = im.M[J];
+        Wv = im.W[J];
+        if (rem != 0) {
+            const int i = (rem >> 3) & 7;
+            const double th = wtab_theta(kind, i);
+            const double t1 = t_s * tt.E[kind - 1][J + 1], h = t1 * sh.sk[kind].one_m_invQ;
+            const double z = h * w.inv_tau;
+            if (z < 1.0 || keep < 3) Mv = hermite_mdisc(th, h, z, im.M[J], im.D[J], im.D2[J], im.M[J + 1], im.D[J + 1], im.D2[J + 1]);
+            else Mv = dense_mdisc_qs(w, im, kind, i, J, keep, fma(th - 1.0, h, t1));
+            Wv = hermite(th, h, im.W[J], im.F[J], im.W[J + 1], im.F[J + 1]);
+        }
+        return;
+    }
+    if (kind < 2) {                                                  // steps of one grid interval or less: every grid point is a node
+        Mv = im.M[J];
+        Wv = im.W[J];
+        return;
+    }
+    // Everything the dense output of a step can need is read from LDS TOGETHER, then used (round 5): read as it was
+    // needed -- node, position of the skipped point, step time, the six Hermite inputs, the four nodes and weights of the
+    // quasi-steady form -- this was a chain of a dozen LDS round trips in a row, ~65 exposed cycles each with one wavefront
+    // per SIMD, twice per tile.  Same arithmetic on the same values: bit-identical.  (Indices of lanes that do not use a
+    // value are clamped into the arrays.)
+    const int J1 = min(J + 1, TileImage<SPL>::kN - 1), i = (rem >> 3) & 7;
+    const int l0 = max(min(J - 1, keep - 3), 0), variant = min(J - l0, 2);
+    const int base = kWtabDense + ((kind - 2) * 7 + max(i - 1, 0)) * 12 + variant * 4;
+    const double M0 = im.M[J], M1 = im.M[J1], D0 = im.D[J], D1 = im.D[J1], E0 = im.D2[J], E1 = im.D2[J1];
+    const double W0 = im.W[J], W1 = im.W[J1], F0 = im.F[J], F1 = im.F[J1];
+    const double th = wtab_theta(kind, i), Et = tt.E[kind - 1][J1];
+    Vd<4> Mq, Dq, wq;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { Mq[k] = im.M[l0 + k]; Dq[k] = im.D[l0 + k]; wq[k] = g_wtab[base + k]; }
+    Mv = M0;
+    Wv = W0;
     if (rem != 0) {
-        const int i = (rem >> 3) & 7;
-        const double th = wtab_theta(kind, i);
-        const double t1 = t_s * tt.E[kind - 1][J + 1], h = t1 * sh.sk[kind].one_m_invQ;
+        const double t1 = t_s * Et, h = t1 * sh.sk[kind].one_m_invQ;
         const double z = h * w.inv_tau;
-        if (z < 1.0 || keep < 3) Mv = hermite_mdisc(th, h, z, im.M[J], im.D[J], im.D2[J], im.M[J + 1], im.D[J + 1], im.D2[J + 1]);
-        else Mv = dense_mdisc_qs(w, im, kind, i, J, keep, fma(th - 1.0, h, t1));
-        Wv = hermite(th, h, im.W[J], im.F[J], im.W[J + 1], im.F[J + 1]);
+        if (z < 1.0 || keep < 3) {
+            Mv = hermite_mdisc(th, h, z, M0, D0, E0, M1, D1, E1);
+        } else {   // (dense_mdisc_qs on the values read above)
+            Vd<4> S;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) S[k] = fma(Mq[k], w.inv_tau, Dq[k]);
+            const Vd<4> iS = rcp_fast(S);
+            double r = 0.0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) r = fma(wq[k], Mq[k] * iS[k], r);
+            const Vd<1> tv{{fma(th - 1.0, h, t1)}};
+            Mv = r * mdot_fb(w, tv)[0];
+        }
+        Wv = hermite(th, h, W0, F0, W1, F1);
     }
 }
 
@@ -653,22 +697,47 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
             // ---------------- step end times (the grid is geometric: t_k = t_s Q^k) and step lengths
             Vd<kSPL> h, S1, dS1, iu1;
             double Sp_team = 0.0, iup_team = 0.0;   // team kernels: the fallback rate and tfb / (t + tfb) at the start of this lane's first own step
+            // (the kind's constants once, and ONE branch on the kind around the four table reads: read step by step, each behind its
+            // own branch and its own scalar load, they were eight memory round trips in a row)
+            const double K_omq = K.one_m_invQ;
             if constexpr (W == 1) {
                 Vd<kSPL> tb;
+                if constexpr (kSPL >= 4) {
+                    if (kind == 0) {
 #pragma unroll
-                for (int s = 0; s < kSPL; ++s) {
-                    tb[s] = t_s * time_factor(sh, tt, kind, min(e0 + s + 1, nc));
-                    h[s] = (e0 + s < nc) ? tb[s] * K.one_m_invQ : 0.0;   // 0 for the padding steps of a short tile
+                        for (int s = 0; s < kSPL; ++s) tb[s] = time_factor(sh, tt, 0, min(e0 + s + 1, nc));
+                    } else {
+#pragma unroll
+                        for (int s = 0; s < kSPL; ++s) tb[s] = tt.E[kind - 1][min(e0 + s + 1, nc)];
+                    }
+#pragma unroll
+                    for (int s = 0; s < kSPL; ++s) {
+                        tb[s] = t_s * tb[s];
+                        h[s] = (e0 + s < nc) ? tb[s] * K_omq : 0.0;   // 0 for the padding steps of a short tile
+                    }
+                } else {   // (two wavefronts per SIMD hide these round trips; this form costs the 128-step kernels no scratch)
+#pragma unroll
+                    for (int s = 0; s < kSPL; ++s) {
+                        tb[s] = t_s * time_factor(sh, tt, kind, min(e0 + s + 1, nc));
+                        h[s] = (e0 + s < nc) ? tb[s] * K.one_m_invQ : 0.0;
+                    }
                 }
                 S1 = mdot_fb_d(w, tb, dS1, iu1);
             } else {
                 // (the start of a lane's first own step is a step end of ANOTHER wavefront: its fallback rate is evaluated here,
                 // next to the own ones -- the same function of the same time, so the same bits -- instead of being exchanged)
                 Vd<kSPL + 1> tb, Sx, dSx, iux;
+                if (kind == 0) {
 #pragma unroll
-                for (int s = 0; s <= kSPL; ++s) tb[s] = t_s * time_factor(sh, tt, kind, min(e0 + s, nc));
+                    for (int s = 0; s <= kSPL; ++s) tb[s] = time_factor(sh, tt, 0, min(e0 + s, nc));
+                } else {
 #pragma unroll
-                for (int s = 0; s < kSPL; ++s) h[s] = (e0 + s < nc) ? tb[s + 1] * K.one_m_invQ : 0.0;
+                    for (int s = 0; s <= kSPL; ++s) tb[s] = tt.E[kind - 1][min(e0 + s, nc)];
+                }
+#pragma unroll
+                for (int s = 0; s <= kSPL; ++s) tb[s] = t_s * tb[s];
+#pragma unroll
+                for (int s = 0; s < kSPL; ++s) h[s] = (e0 + s < nc) ? tb[s + 1] * K_omq : 0.0;
                 Sx = mdot_fb_d(w, tb, dSx, iux);
 #pragma unroll
                 for (int s = 0; s < kSPL; ++s) { S1[s] = Sx[s + 1]; dS1[s] = dSx[s + 1]; iu1[s] = iux[s + 1]; }
