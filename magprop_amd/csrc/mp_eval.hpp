@@ -699,7 +699,7 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
             double Sp_team = 0.0, iup_team = 0.0;   // team kernels: the fallback rate and tfb / (t + tfb) at the start of this lane's first own step
             // (the kind's constants once, and ONE branch on the kind around the four table reads: read step by step, each behind its
             // own branch and its own scalar load, they were eight memory round trips in a row)
-            const double K_omq = K.one_m_invQ;
+            const double K_omq = K.one_m_invQ, K_lnQ = K.lnQ, K_invQ = K.inv_Q;
             if constexpr (W == 1) {
                 Vd<kSPL> tb;
                 if constexpr (kSPL >= 4) {
@@ -878,8 +878,8 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                     // sweeps double the number of correct digits per pass, so this saves most coarse tiles a sweep.
                     const Vd<3> den{{om_s, cw1, cw2}};
                     const Vd<3> rd = rcp_fast(den);
-                    const double tl = t_s * K.lnQ;
-                    const double a0 = tl * cf0 * rd[0], a1 = (tl * K.inv_Q) * cf1 * rd[1], a2 = (tl * K.inv_Q * K.inv_Q) * cf2 * rd[2];
+                    const double tl = t_s * K_lnQ;
+                    const double a0 = tl * cf0 * rd[0], a1 = (tl * K_invQ) * cf1 * rd[1], a2 = (tl * K_invQ * K_invQ) * cf2 * rd[2];
                     const double d1 = a0 - a1, d2 = d1 - (a1 - a2);
                     Vd<kSPL> ex;
 #pragma unroll
@@ -991,10 +991,11 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                         Vd<kSPL> zw;
 #pragma unroll
                         for (int s = 0; s < kSPL; ++s) zw[s] = h[s] * lam[s];
+                        const EamRows2 rows = eam5_rows_begin(wbase);
                         const Phi5<kSPL> pw_ = phi12345(zw);
                         ez = pw_.e;
                         p5 = pw_.p5;
-                        cw = eam5_node_weights(wbase, pw_);
+                        cw = eam5_node_weights_pipelined(wbase, pw_, rows);
                     }
                     __syncthreads();
 #pragma unroll
@@ -1035,10 +1036,18 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                     Vd<kSPL> zw;
 #pragma unroll
                     for (int s = 0; s < kSPL; ++s) zw[s] = h[s] * lam[s];
-                    const Phi5<kSPL> pw_ = phi12345(zw);
-                    ez = pw_.e;
-                    p5 = pw_.p5;
-                    cw = eam5_node_weights(wbase, pw_);
+                    if constexpr (kSPL >= 4) {   // (one wavefront per SIMD: the quadrature table's rows are read ahead of their use)
+                        const EamRows2 rows = eam5_rows_begin(wbase);
+                        const Phi5<kSPL> pw_ = phi12345(zw);
+                        ez = pw_.e;
+                        p5 = pw_.p5;
+                        cw = eam5_node_weights_pipelined(wbase, pw_, rows);
+                    } else {
+                        const Phi5<kSPL> pw_ = phi12345(zw);
+                        ez = pw_.e;
+                        p5 = pw_.p5;
+                        cw = eam5_node_weights(wbase, pw_);
+                    }
                 }
                 MP_PHASE(15)
                 const Vd<kSPL> inc = eam5_increment_nodes(cw, h, n0, n1, n2, n3, n4);
@@ -1670,12 +1679,23 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
 
             MP_PHASE(7)
             // ---------------- carry the end of the kept steps to the next tile
-            t_s = t_s * time_factor(sh, tt, kind, keep);
-            M_s = im.M[keep];
-            om_s = im.W[keep];
-            cf0 = im.F[keep];
-            flags_s = branch_flags(w, im.R[keep], om_s);
-            cS0 = im.C[0]; cdS0 = im.C[1]; ciu0 = im.C[2];
+            if constexpr (kG >= 4) {
+                // (all the reads of the hand-over issued together, the table value among them: one LDS round trip)
+                const double tf_tab = tt.E[max(kind, 1) - 1][keep], Rk = im.R[keep];
+                M_s = im.M[keep];
+                om_s = im.W[keep];
+                cf0 = im.F[keep];
+                cS0 = im.C[0]; cdS0 = im.C[1]; ciu0 = im.C[2];
+                t_s = t_s * (kind == 0 ? time_factor(sh, tt, 0, keep) : tf_tab);
+                flags_s = branch_flags(w, Rk, om_s);
+            } else {
+                t_s = t_s * time_factor(sh, tt, kind, keep);
+                M_s = im.M[keep];
+                om_s = im.W[keep];
+                cf0 = im.F[keep];
+                flags_s = branch_flags(w, im.R[keep], om_s);
+                cS0 = im.C[0]; cdS0 = im.C[1]; ciu0 = im.C[2];
+            }
             rec_valid = true;
             rec_kind = kind;
             rec_sh8 = sh8;

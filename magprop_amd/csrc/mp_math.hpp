@@ -506,6 +506,37 @@ struct EamW5 {
     Vd<N> c0, c1, c2, c3, c4;
 };
 
+// The same with the table rows read two ahead of their use (one-wavefront-per-SIMD kernels: nothing else covers an LDS round
+// trip there).  eam5_rows_begin issues the reads of rows 0 and 1 -- call it BEFORE the phi functions are formed, which
+// take longer than the round trip -- and eam5_node_weights_pipelined reads row k + 2 while it forms the weight of row k.
+struct EamRows2 {
+    d2v a0, b0, e0, a1, b1, e1;
+};
+MP_DEV EamRows2 eam5_rows_begin(int wbase) {
+    EamRows2 r;
+    r.a0 = wtab2(wbase); r.b0 = wtab2(wbase + 2); r.e0 = wtab2(wbase + 4);
+    r.a1 = wtab2(wbase + 6); r.b1 = wtab2(wbase + 8); r.e1 = wtab2(wbase + 10);
+    return r;
+}
+template <int N>
+MP_DEV EamW5<N> eam5_node_weights_pipelined(int wbase, const Phi5<N> &p, const EamRows2 &first) {
+    EamW5<N> w;
+    d2v a[5], b[5], e[5];
+    a[0] = first.a0; b[0] = first.b0; e[0] = first.e0;
+    a[1] = first.a1; b[1] = first.b1; e[1] = first.e1;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        if (k + 2 < 5) { a[k + 2] = wtab2(wbase + 6 * (k + 2)); b[k + 2] = wtab2(wbase + 6 * (k + 2) + 2); e[k + 2] = wtab2(wbase + 6 * (k + 2) + 4); }
+        Vd<N> &c = k == 0 ? w.c0 : k == 1 ? w.c1 : k == 2 ? w.c2 : k == 3 ? w.c3 : w.c4;
+        FORN c[i] = e[k].x * p.p5[i];
+        FORN c[i] = fma(b[k].y, p.p4[i], c[i]);
+        FORN c[i] = fma(b[k].x, p.p3[i], c[i]);
+        FORN c[i] = fma(a[k].y, p.p2[i], c[i]);
+        FORN c[i] = fma(a[k].x, p.p1[i], c[i]);
+    }
+    return w;
+}
+
 template <int N>
 MP_DEV EamW5<N> eam5_node_weights(int wbase, const Phi5<N> &p) {
     EamW5<N> w;
