@@ -523,7 +523,10 @@ def run_passes(c, config, scaling, steps, warmup, curve=False, nwalk=None, grb=N
     if not curve and config != 5 and 2 * n_local <= n_simd:
         variant = "team of four wavefronts per walker (one step per lane each), " + ("one" if 4 * n_local <= n_simd else "two") + " per SIMD"
     else:
-        variant = ("curve kernel, " if curve else "") + ("4 steps per lane, one wavefront per SIMD" if n_local <= n_simd
+        from magprop_amd import _capi
+        # (mode B: by rounds of resident workgroups, magprop_amd/csrc/mp_device.h kernel_spl_curves)
+        spl4 = _capi.curve_steps_per_lane(n_local, n_simd) == 4 if curve else n_local <= n_simd
+        variant = ("curve kernel, " if curve else "") + ("4 steps per lane, one wavefront per SIMD" if spl4
                                                           else "2 steps per lane, two wavefronts per SIMD")
     variant += "; order-5 exponential Adams-Moulton, steps over 1/2/4/8 grid intervals (adaptive)"
     if config == 5:
@@ -914,9 +917,11 @@ def main():
         if world == 1:
             configs = {"3": sub(3, "weak", sampler=True), "4_one_gpu": sub(4, "strong", sampler=True),
                        "5": sub(5, "strong", sampler=True), "curve": sub(2, "weak", curve=True),
-                       # mode B beyond n_simd walkers: the 2-steps-per-lane curve kernel (the one kernel on an ABI path that
-                       # still spills: 64 B of scratch per lane, tools/resource_usage.py)
-                       "curve_4096": sub(2, "weak", curve=True, nwalk=4096)}
+                       # mode B beyond n_simd walkers: four rounds of the 4-steps-per-lane curve kernel at 4 096 walkers (mp_device.h
+                       # kernel_spl_curves), and at 8 192 the 2-steps-per-lane curve kernel (the one kernel on an ABI path that
+                       # still spills: 76 B of scratch per lane, tools/resource_usage.py)
+                       "curve_4096": sub(2, "weak", curve=True, nwalk=4096),
+                       "curve_8192": sub(2, "weak", curve=True, nwalk=8192)}
         else:
             configs = {"4_strong": sub(4, "strong"), "5_strong": sub(5, "strong")}
 

@@ -224,6 +224,17 @@ def cfg_lib(**kw):
     return c
 
 
+def curve_steps_per_lane(n, n_simd):
+    """Steps per lane of the curve kernel (mode B: light curves to HBM) a batch of n walkers runs on: the rule of
+    magprop_amd/csrc/mp_device.h kernel_spl_curves, restated for labels (bench.py) and tests (tests/test_capi_cpu.py holds the
+    two together)."""
+    if n <= n_simd:
+        return 4
+    x2 = n / (7.0 * (n_simd // 4))
+    r2 = 1.62 * ((1.0 if x2 <= 1.0 else 2.0) if x2 <= 2.0 else x2 + 0.2)
+    return 4 if -(-n // n_simd) <= r2 else 2
+
+
 def _dptr(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 

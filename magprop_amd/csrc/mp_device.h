@@ -192,6 +192,21 @@ struct StretchArgs {
 // Steps per lane of the kernel variant used for a batch of n walkers (tiles are 64*spl steps): see launch_lnprob.
 // Up to one wave per SIMD (256 CUs x 4 on MI355X) four steps per lane; beyond, two resident waves win (tools/spl_scan.sh).
 inline int kernel_spl(const DevShared &sh, int n) { return n <= sh.n_simd ? 4 : 2; }
+// The same for the kernels that write light curves to HBM (mode B), whose time is rounds of resident workgroups.  The
+// 2-steps-per-lane build keeps 22.6 KB of LDS per workgroup: 7 workgroups per CU, not 8 -- 1 792 resident walkers on an MI355X,
+// so that 2 048 walkers take TWO rounds (0.49 ms) where the 4-steps-per-lane build, one wavefront per SIMD and no scratch
+// memory, takes two rounds of 1 024 in 0.34 ms.  Measured per round on one box (profiles/r05_ab_curve_spl.log): 0.171 ms
+// (4 steps per lane, sharp rounds: the workgroups of a round end together) and 0.277 ms (2 steps per lane; beyond two rounds
+// the workgroups overlap and the time grows linearly).  The cheaper one by that model: 2 048 walkers 4.16 -> 5.97 M
+// evaluations/s, 3 072 5.45 -> 6.01 M, 4 096 5.66 -> 6.03 M, unchanged elsewhere.
+inline int kernel_spl_curves(const DevShared &sh, int n) {
+    if (n <= sh.n_simd) return 4;
+    const double cap2 = 7.0 * (sh.n_simd / 4);                            // resident workgroups of the 2-steps-per-lane build
+    const double r4 = (double)((n + sh.n_simd - 1) / sh.n_simd);          // rounds of the 4-steps-per-lane build
+    const double x2 = n / cap2;
+    const double r2 = 1.62 * (x2 <= 2.0 ? (x2 <= 1.0 ? 1.0 : 2.0) : x2 + 0.2);   // the other one's, in units of the former's
+    return r4 <= r2 ? 4 : 2;
+}
 // Wavefronts per walker: launches that would leave SIMDs idle (n <= n_simd / 2) put a team of 4 wavefronts on every walker
 // (mp_eval.hpp TeamX; mode A, light curves of up to 64 points); see launch_lnprob.  (force_waves = 2: the two-wavefront
 // team, experiments build only.)

@@ -495,7 +495,8 @@ int launch_lnprob(const DevShared &sh, const LaunchArgs &a, void *stream) {
     //    needs the whole register file of a SIMD);
     //  - beyond: two steps per lane, which keeps two waves resident per SIMD (they fill each other's issue gaps);
     //  - a handle that holds a light curve of more than 64 points runs the LONG builds of the same kernels.
-    const bool wide = (sh.force_spl ? sh.force_spl : kernel_spl(sh, a.n)) == 4;
+    //  - curve outputs (mode B): by rounds of resident workgroups, kernel_spl_curves (mp_device.h);
+    const bool wide = (sh.force_spl ? sh.force_spl : (curves ? kernel_spl_curves(sh, a.n) : kernel_spl(sh, a.n))) == 4;
     const bool lng = sh.has_long != 0;
     hipStream_t st = (hipStream_t)stream;
     //  - launches that would leave SIMDs idle (n <= n_simd / 2): a team of four wavefronts per walker, one step per lane each

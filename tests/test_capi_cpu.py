@@ -49,6 +49,24 @@ def test_python_mirror_follows_the_header_constants():
     assert "6553600.0 *" not in orc                           # (the literal is gone from the oracle's code)
 
 
+def test_curve_kernel_rule_mirror(tmp_path):
+    """_capi.curve_steps_per_lane (labels of bench.py, expectations of the GPU tests) IS kernel_spl_curves of
+    magprop_amd/csrc/mp_device.h: the header's inline function compiled for the host against the Python restatement, every batch
+    size up to 20 000 on two device sizes."""
+    import subprocess
+    src = tmp_path / "rule.cpp"
+    src.write_text('#include <cstdio>\n#include <initializer_list>\n#include "magprop_amd/csrc/mp_device.h"\n'
+                   'int main() { mp::DevShared sh{}; for (int simd : {1024, 416}) { sh.n_simd = simd; '
+                   'for (int n = 1; n <= 20000; ++n) std::printf("%d", mp::kernel_spl_curves(sh, n)); std::printf("\\n"); } }\n')
+    exe = tmp_path / "rule"
+    subprocess.run(["g++", "-std=c++17", "-O1", "-I", ROOT, str(src), "-o", str(exe)], check=True)
+    rows = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    for simd, row in zip((1024, 416), rows):
+        assert row == "".join(str(_capi.curve_steps_per_lane(n, simd)) for n in range(1, 20001)), simd
+    # the measured points of profiles/r05_ab_curve_spl.log (an MI355X: 1 024 SIMDs)
+    assert [_capi.curve_steps_per_lane(n, 1024) for n in (1024, 1536, 2048, 3072, 3584, 4096, 5120, 8192)] == [4, 2, 4, 4, 2, 4, 2, 2]
+
+
 def test_cfg_struct_layout_and_presets():
     assert ctypes.sizeof(_capi.ModelCfg) == 11 * 8 + 2 * 4 + 2 * 8 + 2 * 4
     c0 = _capi.cfg_synth()

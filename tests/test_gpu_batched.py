@@ -32,10 +32,10 @@ def _long_set(rng, tarr, base_lc, n):
 
 
 # ---------------------------------------------------------------- mode B
-@pytest.mark.parametrize("n", [64, 1024, 1300])
+@pytest.mark.parametrize("n", [64, 1024, 1300, 2048])
 def test_mode_b_batched_light_curves(gsynth, gflag, tarr, n):
     """lnprob_batch(P, want_ltot=True): 64 walkers run the 4-steps-per-lane curve kernel like 1 024 do, 1 300 the
-    2-steps-per-lane one.  Physical parameters on a prior-free handle, so that every row can be compared with
+    2-steps-per-lane one, 2 048 two rounds of the 4-steps-per-lane one again (mp_device.h kernel_spl_curves).  Physical parameters on a prior-free handle, so that every row can be compared with
     mp_model_lc of the same walker bit for bit (same variant) — then the same walkers in sampler coordinates with the
     prior: flagged and out-of-prior rows are NaN, the rest agree."""
     import magprop_amd as mpa
@@ -71,7 +71,13 @@ def test_mode_b_batched_light_curves(gsynth, gflag, tarr, n):
     Pphys[:, 2:] = 10.0 ** S[:, 2:]
 
     lnp_b, st_b, lt = hp.lnprob_batch(Pphys, ds_id=ids, want_status=True, want_ltot=True)
-    lnp_a, st_a = hp.lnprob_batch(Pphys, ds_id=ids, want_status=True)
+    if n > hp.n_simd and _capi.curve_steps_per_lane(n, hp.n_simd) == 4:
+        # (mode B runs rounds of the 4-steps-per-lane kernel here, a mode A launch of this size the 2-steps-per-lane one: mode A
+        # in launches of the same variant, for the comparison to the last digits below)
+        parts = [hp.lnprob_batch(Pphys[i:i + 1024], ds_id=ids[i:i + 1024], want_status=True) for i in range(0, n, 1024)]
+        lnp_a, st_a = np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
+    else:
+        lnp_a, st_a = hp.lnprob_batch(Pphys, ds_id=ids, want_status=True)
     assert lt.shape == (n, 10001)
     assert np.array_equal(st_a, st_b) and np.sum(st_b == 1) >= 3
     ok = st_b == 0
@@ -80,7 +86,8 @@ def test_mode_b_batched_light_curves(gsynth, gflag, tarr, n):
     assert np.allclose(lnp_b[ok], lnp_a[ok], rtol=1e-12, atol=1e-12) and np.all(lnp_b[~ok] == -np.inf)
     assert np.all(np.isnan(lt[~ok])) and np.all(np.isfinite(lt[ok])) and np.all(lt[ok] >= 0.0)
     # every row against mp_model_lc of the same walker
-    same_variant = n <= hp.n_simd
+    same_variant = _capi.curve_steps_per_lane(n, hp.n_simd) == 4
+    assert same_variant == (n != 1300) or hp.n_simd != 1024
     worst = 0.0
     for i in range(n):
         st_i, out_i = hp.model_lc(Pphys[i])
