@@ -219,6 +219,19 @@ inline int kernel_waves(const DevShared &sh, int n) {
     return 2 * n <= sh.n_simd ? 4 : 1;
 }
 
+// The same for the kernels of the device-resident sampler, by the size of a WHOLE step of the ensembles (3 x slots of a half:
+// what mp_sampler_run evaluates per launch when that fits) -- for one launch per step and one per half-step alike, so that the
+// two forms run the same arithmetic and their chains stay equal bit for bit; likewise every rank of a walker-sharded run.
+// Ensembles of up to n_simd / 6 walkers in all (170 on an MI355X: what emcee is usually run with; the reference's own example
+// has 24, code/synthetic_datasets/synth_mcmc.py): a step 0.091 -> 0.075 ms.
+inline int stretch_waves(const DevShared &sh, int whole_step_blocks) {
+    if (sh.has_long || sh.force_spl) return 1;
+#ifdef MP_EXPERIMENTS
+    if (sh.force_waves) return sh.force_waves == 4 ? 4 : 1;
+#endif
+    return 2 * whole_step_blocks <= sh.n_simd ? 4 : 1;
+}
+
 // Arguments of the batched right-hand-side evaluation (mp_kernels.hip: rhs_kernel), device pointers.
 struct RhsArgs {
     const double *pars;     // [n][ndim], physical units

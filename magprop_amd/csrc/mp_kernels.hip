@@ -191,13 +191,30 @@ __device__ __forceinline__ int ens_of_slot(const StretchArgs &g, int e_pos) {
     return g.ens_order ? (int)((g.ens_order >> (4 * e_pos)) & 15u) : e_pos;
 }
 
-template <int SPL, bool LONG>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPL >= 4 ? 1 : 2, SPL >= 4 ? 1 : 2))) void stretch_kernel(const DevShared sh, const StretchArgs g) {
-    __shared__ TileImage<SPL> im;
-    __shared__ TimeTable<SPL> tt;
+// (the team's exchange area in LDS, or nothing for the one-wavefront builds)
+template <int G, bool ON>
+struct TeamLds {
+    TeamX<G> x;
+    __device__ TeamX<G> *ptr() { return &x; }
+};
+template <int G>
+struct TeamLds<G, false> {
+    __device__ TeamX<G> *ptr() { return nullptr; }
+};
+
+// W, OCC: small ensembles evaluate every proposal on a team of W = 4 wavefronts (lnprob_team_kernel; OCC = wavefronts resident
+// per SIMD the build is made for), chosen by the size of a WHOLE step of the sampler (stretch_waves, mp_device.h) so that one
+// launch per step and one per half-step run the same arithmetic: the chains stay equal bit for bit.
+template <int SPL, bool LONG, int W = 1, int OCC = 0>
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 1 ? OCC : (SPL >= 4 ? 1 : 2), W > 1 ? OCC : (SPL >= 4 ? 1 : 2))))
+void stretch_kernel(const DevShared sh, const StretchArgs g) {
+    __shared__ TileImage<SPL * W> im;
+    __shared__ TimeTable<SPL * W> tt;
     __shared__ double lds[1];
     __shared__ double park[MP_MAX_NDIM + 3];
-    tables_init<SPL, 64>(sh, tt);
+    __shared__ TeamLds<SPL * W, (W > 1)> tl;
+    TeamX<SPL * W> *const tx = tl.ptr();
+    tables_init<SPL * W, 64 * W>(sh, tt);
     const int gs = g.slot_lo + (int)blockIdx.x;                    // slot of the active half, all ensembles flattened
     const int w_ens = ens_of_slot(g, gs / g.n_half);               // which ensemble (longest light curve first)
     const int slot = gs % g.n_half;                                // which walker of the active half
@@ -223,7 +240,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPL >= 4 ? 1
     // Nothing of the draw stays live across walker_eval (which needs every register): lane 0 parks the proposal, the
     // acceptance threshold and the walker's current value in LDS and reads them back behind the evaluation.
     //   park[0 .. ndim-1] proposal, [ndim] (ndim - 1) ln z, [ndim + 1] ln u, [ndim + 2] lnprob of the walker now
-    const bool lane0 = (threadIdx.x & 63) == 0;
+    const bool lane0 = W > 1 ? threadIdx.x == 0 : (threadIdx.x & 63) == 0;   // (of the team's first wavefront)
     double lnp = 0.0;
     if (g.target == 1) {   // isotropic unit Gaussian: exercises the move itself (tests)
 #pragma unroll
@@ -243,9 +260,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPL >= 4 ? 1
         a.ndim = g.ndim;
         a.physical = 0;
         a.want_chi2 = 1;
-        walker_eval<false, SPL, LONG>(sh, a, k, par, im, tt, lds, lnp, status, sweeps, tiles);
+        if constexpr (W > 1) walker_eval<false, SPL, LONG, false, W, OCC >= 2>(sh, a, k, par, im, tt, lds, lnp, status, sweeps, tiles, tx);
+        else walker_eval<false, SPL, LONG>(sh, a, k, par, im, tt, lds, lnp, status, sweeps, tiles);
     }
-    if (lane0) {   // lane 0 of the evaluating wavefront
+    if (lane0) {   // lane 0 of the evaluating wavefront (team: of its first one)
         const double lnp_old = park[MP_MAX_NDIM + 2];
         const double lnpdiff = sub_rn(add_rn(park[MP_MAX_NDIM], lnp), lnp_old);
         const bool accept = lnpdiff > park[MP_MAX_NDIM + 1];      // false for NaN / -inf proposals
@@ -330,12 +348,15 @@ MP_DEV void stretch_draw(const StretchArgs &g, int half, int k, int n_comp, int 
     logu = log(u01(r2[0], r2[1]));
 }
 
-template <int SPL, bool LONG>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPL >= 4 ? 1 : 2, SPL >= 4 ? 1 : 2))) void stretch_step_kernel(const DevShared sh, const StretchArgs g) {
-    __shared__ TileImage<SPL> im;
-    __shared__ TimeTable<SPL> tt;
+template <int SPL, bool LONG, int W = 1, int OCC = 0>   // (W, OCC: as in stretch_kernel)
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 1 ? OCC : (SPL >= 4 ? 1 : 2), W > 1 ? OCC : (SPL >= 4 ? 1 : 2))))
+void stretch_step_kernel(const DevShared sh, const StretchArgs g) {
+    __shared__ TileImage<SPL * W> im;
+    __shared__ TimeTable<SPL * W> tt;
     __shared__ double lds[1];
-    tables_init<SPL, 64>(sh, tt);
+    __shared__ TeamLds<SPL * W, (W > 1)> tl;
+    TeamX<SPL * W> *const tx = tl.ptr();
+    tables_init<SPL * W, 64 * W>(sh, tt);
     const int n_slots = g.n_half * g.n_ensembles;
     const int blk = g.slot_lo + (int)blockIdx.x;                    // a launch covers blocks [slot_lo, slot_lo + gridDim.x) (sharded: a rank's share)
     const int type = blk / n_slots, gs = blk - type * n_slots;
@@ -385,7 +406,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPL >= 4 ? 1
     // Everything of the outcome row that does not depend on the evaluation is written NOW: nothing of the draw stays live
     // across walker_eval, which needs every register (round 3 held the proposal, the partner and the thresholds in registers
     // there: 180 B of scratch per lane, 16 MB of spill traffic per launch).
-    const bool lane0 = (threadIdx.x & 63) == 0;
+    const bool lane0 = W > 1 ? threadIdx.x == 0 : (threadIdx.x & 63) == 0;   // (of the team's first wavefront)
     if (lane0) {
         double *u = g.spec + (size_t)blockIdx.x * (g.ndim + kSpecExtra);
         for (int i = 0; i < g.ndim; ++i) u[i] = par[i];
@@ -402,7 +423,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPL >= 4 ? 1
         a.ndim = g.ndim;
         a.physical = 0;
         a.want_chi2 = 1;
-        walker_eval<false, SPL, LONG>(sh, a, k, par, im, tt, lds, lnp, status, sweeps, tiles);
+        if constexpr (W > 1) walker_eval<false, SPL, LONG, false, W, OCC >= 2>(sh, a, k, par, im, tt, lds, lnp, status, sweeps, tiles, tx);
+        else walker_eval<false, SPL, LONG>(sh, a, k, par, im, tt, lds, lnp, status, sweeps, tiles);
         if (lane0) {
             double *u = g.spec + (size_t)blockIdx.x * (g.ndim + kSpecExtra);
             u[g.ndim] = lnp;
@@ -553,6 +575,11 @@ int launch_stretch(const DevShared &sh, const StretchArgs &g, int n_blocks, void
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)n_blocks);
     const bool lng = sh.has_long != 0;
+    if (stretch_waves(sh, 3 * g.n_half * g.n_ensembles) == 4) {   // small ensembles: a team of four wavefronts per proposal
+        if (4 * n_blocks <= sh.n_simd) hipLaunchKernelGGL((stretch_kernel<1, false, 4, 1>), grid, dim3(256), 0, st, sh, g);
+        else hipLaunchKernelGGL((stretch_kernel<1, false, 4, 2>), grid, dim3(256), 0, st, sh, g);
+        return (int)hipGetLastError();
+    }
     if ((sh.force_spl ? sh.force_spl : kernel_spl(sh, n_blocks)) == 4) {
         if (lng) hipLaunchKernelGGL((stretch_kernel<4, true>), grid, dim3(64), 0, st, sh, g);
         else hipLaunchKernelGGL((stretch_kernel<4, false>), grid, dim3(64), 0, st, sh, g);
@@ -568,6 +595,11 @@ int launch_stretch_step(const DevShared &sh, const StretchArgs &g, int n_blocks,
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)n_blocks);
     const bool lng = sh.has_long != 0;
+    if (stretch_waves(sh, 3 * g.n_half * g.n_ensembles) == 4) {
+        if (4 * n_blocks <= sh.n_simd) hipLaunchKernelGGL((stretch_step_kernel<1, false, 4, 1>), grid, dim3(256), 0, st, sh, g);
+        else hipLaunchKernelGGL((stretch_step_kernel<1, false, 4, 2>), grid, dim3(256), 0, st, sh, g);
+        return (int)hipGetLastError();
+    }
     if ((sh.force_spl ? sh.force_spl : kernel_spl(sh, n_blocks)) == 4) {
         if (lng) hipLaunchKernelGGL((stretch_step_kernel<4, true>), grid, dim3(64), 0, st, sh, g);
         else hipLaunchKernelGGL((stretch_step_kernel<4, false>), grid, dim3(64), 0, st, sh, g);
