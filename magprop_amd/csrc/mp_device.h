@@ -208,10 +208,9 @@ inline int kernel_spl_curves(const DevShared &sh, int n) {
     return r4 <= r2 ? 4 : 2;
 }
 // Wavefronts per walker: launches that would leave SIMDs idle (n <= n_simd / 2) put a team of 4 wavefronts on every walker
-// (mp_eval.hpp TeamX; mode A, light curves of up to 64 points); see launch_lnprob.  (force_waves = 2: the two-wavefront
-// team, experiments build only.)
+// (mp_eval.hpp TeamX; mode A; handles with light curves of more than 64 points: the LONG builds of the same kernels); see
+// launch_lnprob.  (force_waves = 2: the two-wavefront team, experiments build only.)
 inline int kernel_waves(const DevShared &sh, int n) {
-    if (sh.has_long) return 1;
 #ifdef MP_EXPERIMENTS
     if (sh.force_waves) return sh.force_waves;
 #endif
@@ -225,7 +224,7 @@ inline int kernel_waves(const DevShared &sh, int n) {
 // Ensembles of up to n_simd / 6 walkers in all (170 on an MI355X: what emcee is usually run with; the reference's own example
 // has 24, code/synthetic_datasets/synth_mcmc.py): a step 0.091 -> 0.075 ms.
 inline int stretch_waves(const DevShared &sh, int whole_step_blocks) {
-    if (sh.has_long || sh.force_spl) return 1;
+    if (sh.force_spl) return 1;
 #ifdef MP_EXPERIMENTS
     if (sh.force_waves) return sh.force_waves == 4 ? 4 : 1;
 #endif

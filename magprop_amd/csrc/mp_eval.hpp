@@ -534,7 +534,7 @@ template <bool CURVES, int SPL, bool LONG, bool LOG = false, int W = 1, bool UNI
 MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, double (&par)[MP_MAX_NDIM],
                         TileImage<SPL * W> &im, const TimeTable<SPL * W> &tt, double *Lbuf, double &lnp_out, int &status_out,
                         int &sweeps_out, int &tiles_out, TeamX<SPL * W> *tx = nullptr) {
-    static_assert(W == 1 || (SPL * W == 4 && !CURVES && !LONG), "team kernels: 256-step tiles, mode A, light curves of <= 64 points");
+    static_assert(W == 1 || (SPL * W == 4 && !CURVES), "team kernels: 256-step tiles, mode A");
     constexpr int kSPL = SPL, kG = SPL * W, kTile = 64 * kG, kMaxSweeps = kTile + kMaxSweepsMargin;
     const int lane = threadIdx.x & 63;
     const int wave = W > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;   // which wavefront of the walker's team
@@ -1499,7 +1499,10 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                             const int g_lo = pos8 >> 3, g_hi = end_kept8 >> 3;                 // grid intervals [g_lo, g_hi)
                             const int b_lo = g_lo / kTile64, b_hi = min((g_hi + kTile64 - 1) / kTile64, sh.n_tiles);
                             const int j0 = max(tptr[b_lo], 64), j1 = tptr[b_hi];
-                            for (int jb = j0; jb < j1; jb += 64) {                             // (wave-uniform trip count)
+                            // (team kernels: the chunks of 64 observations are dealt to the team's wavefronts in turn -- the image is
+                            // read-only until the next tile's flag exchange, behind which every wavefront has left this loop; the
+                            // partial sums meet behind the last tile)
+                            for (int jb = j0 + 64 * wave; jb < j1; jb += 64 * W) {             // (wave-uniform trip count)
                                 const int j = jb + lane;
                                 const int jj = dsd.obs_off + min(j, j1 - 1);
                                 const int g = sh.obs_g[jj];
@@ -1725,6 +1728,14 @@ MP_DEV void walker_eval(const DevShared &sh, const LaunchArgs &a, int walker, do
                 const double mod = fma((Lt[1] - Lt[0]) * ob_idt, ob_dx, Lt[0]) / 1.0e50;   // np.interp, then /1e50
                 const double res = (ob_y - mod) / ob_ye;
                 chi = res * res;
+            }
+            if constexpr (W > 1 && LONG) {
+                // the wavefronts' shares of the observations 64.., summed in a fixed order: every wavefront ends with the same bits
+                tx->D4[wave][lane] = chi_long;
+                __syncthreads();
+                chi_long = tx->D4[0][lane];
+#pragma unroll
+                for (int k = 1; k < W; ++k) chi_long += tx->D4[k][lane];
             }
             chi += chi_long;                                         // observations 64.., scored tile by tile above
         }

@@ -82,7 +82,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPL >= 4 ? 1
 // SIMD (each takes what it needs of the register file), so a workgroup is spread over W SIMDs of its CU.
 // OCC = wavefronts resident per SIMD the build is made for: 1 while the launch has a SIMD for every wavefront (n <= n_simd / W),
 // 2 for twice as many walkers (256 registers; the walker's constants in scalar registers).
-template <int SPL, int W, int OCC, bool LOG = false>
+// LONG: built with the path for light curves of more than 64 points (their observations 64.. are scored chunk by chunk, the
+// chunks dealt to the team's wavefronts in turn: a walker on a 1 944-point light curve spends a quarter of its time there).
+template <int SPL, int W, int OCC, bool LOG = false, bool LONG = false>
 __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void lnprob_team_kernel(const DevShared sh, const LaunchArgs a) {
     __shared__ TileImage<SPL * W> im;
     __shared__ TimeTable<SPL * W> tt;
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(OCC, OCC
     LaunchArgs aa = a;
     aa.physical = 0;
     aa.want_chi2 = 1;
-    walker_eval<false, SPL, false, LOG, W, OCC >= 2>(sh, aa, walker, par, im, tt, Lbuf, lnp, status, sweeps, tiles, &tx);
+    walker_eval<false, SPL, LONG, LOG, W, OCC >= 2>(sh, aa, walker, par, im, tt, Lbuf, lnp, status, sweeps, tiles, &tx);
     if (threadIdx.x == 0) {
         a.lnprob[walker] = lnp;
         if (a.status) a.status[walker] = status;
@@ -522,7 +524,7 @@ int launch_lnprob(const DevShared &sh, const LaunchArgs &a, void *stream) {
     const bool lng = sh.has_long != 0;
     hipStream_t st = (hipStream_t)stream;
     //  - launches that would leave SIMDs idle (n <= n_simd / 2): a team of four wavefronts per walker, one step per lane each
-    //    (the same 256-step tiles and policy; mode A on light curves of up to 64 points).  Up to n_simd / 4 walkers every
+    //    (the same 256-step tiles and policy; mode A; LONG builds for handles with longer light curves).  Up to n_simd / 4 walkers every
     //    wavefront has a SIMD of its own; up to n_simd / 2 two share one and fill each other's stalls.  Measured on one box
     //    (profiles/r05_team_*.log): 256 walkers 0.0755 -> 0.0577 ms, 512 walkers 0.0767 -> 0.0699 ms near the truth
     //    (0.197 -> 0.165 ms prior-wide); a team of two (2 steps per lane) at 512 walkers 0.0701 / 0.197 ms.
@@ -530,10 +532,16 @@ int launch_lnprob(const DevShared &sh, const LaunchArgs &a, void *stream) {
     if (team > 1) {
         const bool log = a.tile_log != nullptr || kAlwaysLog;
         if (team == 4 && 4 * a.n <= sh.n_simd) {
-            if (log) hipLaunchKernelGGL((lnprob_team_kernel<1, 4, 1, true>), grid, dim3(256), 0, st, sh, a);
+            if (lng) {
+                if (log) hipLaunchKernelGGL((lnprob_team_kernel<1, 4, 1, true, true>), grid, dim3(256), 0, st, sh, a);
+                else hipLaunchKernelGGL((lnprob_team_kernel<1, 4, 1, false, true>), grid, dim3(256), 0, st, sh, a);
+            } else if (log) hipLaunchKernelGGL((lnprob_team_kernel<1, 4, 1, true>), grid, dim3(256), 0, st, sh, a);
             else hipLaunchKernelGGL((lnprob_team_kernel<1, 4, 1, false>), grid, dim3(256), 0, st, sh, a);
         } else if (team == 4) {
-            if (log) hipLaunchKernelGGL((lnprob_team_kernel<1, 4, 2, true>), grid, dim3(256), 0, st, sh, a);
+            if (lng) {
+                if (log) hipLaunchKernelGGL((lnprob_team_kernel<1, 4, 2, true, true>), grid, dim3(256), 0, st, sh, a);
+                else hipLaunchKernelGGL((lnprob_team_kernel<1, 4, 2, false, true>), grid, dim3(256), 0, st, sh, a);
+            } else if (log) hipLaunchKernelGGL((lnprob_team_kernel<1, 4, 2, true>), grid, dim3(256), 0, st, sh, a);
             else hipLaunchKernelGGL((lnprob_team_kernel<1, 4, 2, false>), grid, dim3(256), 0, st, sh, a);
         } else {
 #ifdef MP_EXPERIMENTS
@@ -576,8 +584,13 @@ int launch_stretch(const DevShared &sh, const StretchArgs &g, int n_blocks, void
     dim3 grid((unsigned)n_blocks);
     const bool lng = sh.has_long != 0;
     if (stretch_waves(sh, 3 * g.n_half * g.n_ensembles) == 4) {   // small ensembles: a team of four wavefronts per proposal
-        if (4 * n_blocks <= sh.n_simd) hipLaunchKernelGGL((stretch_kernel<1, false, 4, 1>), grid, dim3(256), 0, st, sh, g);
-        else hipLaunchKernelGGL((stretch_kernel<1, false, 4, 2>), grid, dim3(256), 0, st, sh, g);
+        if (4 * n_blocks <= sh.n_simd) {
+            if (lng) hipLaunchKernelGGL((stretch_kernel<1, true, 4, 1>), grid, dim3(256), 0, st, sh, g);
+            else hipLaunchKernelGGL((stretch_kernel<1, false, 4, 1>), grid, dim3(256), 0, st, sh, g);
+        } else {
+            if (lng) hipLaunchKernelGGL((stretch_kernel<1, true, 4, 2>), grid, dim3(256), 0, st, sh, g);
+            else hipLaunchKernelGGL((stretch_kernel<1, false, 4, 2>), grid, dim3(256), 0, st, sh, g);
+        }
         return (int)hipGetLastError();
     }
     if ((sh.force_spl ? sh.force_spl : kernel_spl(sh, n_blocks)) == 4) {
@@ -596,8 +609,13 @@ int launch_stretch_step(const DevShared &sh, const StretchArgs &g, int n_blocks,
     dim3 grid((unsigned)n_blocks);
     const bool lng = sh.has_long != 0;
     if (stretch_waves(sh, 3 * g.n_half * g.n_ensembles) == 4) {
-        if (4 * n_blocks <= sh.n_simd) hipLaunchKernelGGL((stretch_step_kernel<1, false, 4, 1>), grid, dim3(256), 0, st, sh, g);
-        else hipLaunchKernelGGL((stretch_step_kernel<1, false, 4, 2>), grid, dim3(256), 0, st, sh, g);
+        if (4 * n_blocks <= sh.n_simd) {
+            if (lng) hipLaunchKernelGGL((stretch_step_kernel<1, true, 4, 1>), grid, dim3(256), 0, st, sh, g);
+            else hipLaunchKernelGGL((stretch_step_kernel<1, false, 4, 1>), grid, dim3(256), 0, st, sh, g);
+        } else {
+            if (lng) hipLaunchKernelGGL((stretch_step_kernel<1, true, 4, 2>), grid, dim3(256), 0, st, sh, g);
+            else hipLaunchKernelGGL((stretch_step_kernel<1, false, 4, 2>), grid, dim3(256), 0, st, sh, g);
+        }
         return (int)hipGetLastError();
     }
     if ((sh.force_spl ? sh.force_spl : kernel_spl(sh, n_blocks)) == 4) {

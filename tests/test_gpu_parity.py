@@ -379,9 +379,10 @@ def test_mixed_datasets_and_lengths(mpa, co, gsynth, tarr, strict):
 @pytest.mark.parametrize("nw", [40, 400, 700, 1700])
 def test_long_light_curves_every_kernel_variant(mpa, co, gsynth, tarr, nw, strict):
     """Real GRB light curves have up to 1 944 points (data/real_data/): observations beyond the 64 register-resident
-    ones are scored from the tile image as their tile is committed (the LONG kernel builds).  40 / 400 / 700 walkers run
-    on the 4-steps-per-lane kernel, 1 700 on the 2-steps-per-lane one; a few walkers are checked against the C oracle,
-    all against each other."""
+    ones are scored from the tile image as their tile is committed (the LONG kernel builds).  40 walkers run on a team of
+    four wavefronts each with a SIMD per wavefront, 400 on teams with two wavefronts per SIMD (the chunks of 64 observations
+    dealt to the team's wavefronts in turn), 700 on the 4-steps-per-lane kernel, 1 700 on the 2-steps-per-lane one; a few
+    walkers are checked against the C oracle, all against each other."""
     from magprop_amd import LogProb
     rng = np.random.default_rng(19)
     base = mpa.model_lum(CANON["Classic"])
