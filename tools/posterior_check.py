@@ -19,7 +19,8 @@ NAMES = ["B", "P", "log MdiscI", "log RdiscI", "log eps", "log delta"]
 
 def main():
     g = np.load(os.path.join(ROOT, "tests", "golden", "golden_synth.npz"))
-    nwalk, nstep, burn = 512, 3000, 1000
+    # (python tools/posterior_check.py [nwalk nstep burn]: 128 walkers and fewer run the sampler's team kernels)
+    nwalk, nstep, burn = (int(v) for v in sys.argv[1:4]) if len(sys.argv) >= 4 else (512, 3000, 1000)
     for grb, truth in TRUTHS.items():
         x, y, yerr = g[grb + "_x"], g[grb + "_y"], g[grb + "_yerr"]
         rng = np.random.default_rng(7)
