@@ -340,7 +340,8 @@ def sampler_leg(c, n_walk, datasets, p0, steps, seed, **kw):
     es.run_mcmc(None, steps, store=False)
     t = time.perf_counter() - t
     n = es.ntotal
-    whole = kw.get("whole_step", True) and 3 * (n // 2) <= 2 * es.handle.n_simd
+    from magprop_amd import _capi
+    whole = kw.get("whole_step", True) and _capi.whole_step_fits(3 * (n // 2), es.handle.n_simd)
     out = {"walkers": n, "ensembles": es.nensembles, "n_obs": [int(len(d[0])) for d in datasets], "steps": steps,
            "walker_steps_per_sec": n * steps / t, "ms_per_step": 1e3 * t / steps,
            "acceptance_fraction": float(es.acceptance_fraction.mean()),
@@ -750,7 +751,8 @@ def main():
             tm = time.perf_counter()
             es.run_mcmc(None, a.mcmc_steps, store=False)
             tm = time.perf_counter() - tm
-            whole = 3 * (n_global // 2) <= 2 * es.handle.n_simd
+            from magprop_amd import _capi
+            whole = _capi.whole_step_fits(3 * (n_global // 2), es.handle.n_simd)
             note = ("emcee-style stretch move; a whole step per launch: the proposals of the first half and both candidate "
                     "proposals of every walker of the second half (3/2 x walkers evaluations, a third of them discarded), then "
                     "the decisions in emcee's order" if whole else

@@ -249,8 +249,8 @@ int mp_sampler_destroy(mp_sampler *s);
 int mp_sampler_set_positions(mp_sampler *s, const double *pos);
 /* n_steps full steps; chain[n_steps][n_total][ndim] and chain_lnprob[n_steps][n_total] (host, both or neither) */
 int mp_sampler_run(mp_sampler *s, int n_steps, double *chain, double *chain_lnprob);
-/* mp_sampler_run evaluates a whole step in one launch while 3/2 x the walkers (all ensembles) fit the device two wavefronts
- * per SIMD: the proposals of the first half and, for every walker of the second half, both proposals it can end up making
+/* mp_sampler_run evaluates a whole step in one launch while 3/2 x the walkers (all ensembles) are at most 19/8 x the SIMDs of
+ * the device (2 432 evaluations on an MI355X: they fit two wavefronts per SIMD, or nearly): the proposals of the first half and, for every walker of the second half, both proposals it can end up making
  * (its partner of the first half moved or not); a small kernel then takes the decisions in emcee's order.  Same chain, bit
  * for bit, as one launch per half-step (enable = 0; what larger ensembles get anyway).  Default: enabled. */
 int mp_sampler_set_whole_step(mp_sampler *s, int enable);

@@ -235,6 +235,13 @@ def curve_steps_per_lane(n, n_simd):
     return 4 if -(-n // n_simd) <= r2 else 2
 
 
+def whole_step_fits(whole_step_blocks, n_simd):
+    """mp_sampler_run evaluates a whole step per launch up to this many evaluations (3/2 x the walkers of all ensembles): the
+    rule of magprop_amd/csrc/mp_device.h stretch_whole_step_fits, restated for labels (tests/test_capi_cpu.py holds the two
+    together)."""
+    return 8 * int(whole_step_blocks) <= 19 * int(n_simd)
+
+
 def _dptr(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 

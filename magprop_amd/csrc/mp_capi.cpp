@@ -1044,9 +1044,10 @@ int mp_sampler_run(mp_sampler *s, int n_steps, double *chain, double *chain_lnpr
     constexpr int kSub = 8;   // steps per batch of splits: the host draws the next batch while the GPU runs this one
     int rc;
     // A whole step per launch (mp_kernels.hip stretch_step_kernel: 3 n/2 evaluations, a third of them speculative) while
-    // those fit the device two waves per SIMD; larger ensembles fill it with one half-step at a time.
+    // that beats two half-step launches (mp_device.h stretch_whole_step_fits); larger ensembles fill the device with one half-step
+    // at a time.
     const int n_slots = (s->n_walkers / 2) * s->n_ensembles;
-    const bool whole = s->whole_step && 3 * (int64_t)n_slots <= 2 * (int64_t)h->sh.n_simd;
+    const bool whole = s->whole_step && mp::stretch_whole_step_fits(h->sh, 3 * (long long)n_slots);
     if (whole && (rc = s->d_spec.ensure((size_t)3 * n_slots * (size_t)(s->ndim + mp::kSpecExtra)))) return rc;
     if (s->ext_stream_work) {   // sharded half-steps on a caller's stream may still be updating the state
         HIP_TRY(hipDeviceSynchronize());

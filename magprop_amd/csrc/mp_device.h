@@ -231,6 +231,13 @@ inline int stretch_waves(const DevShared &sh, int whole_step_blocks) {
     return 2 * whole_step_blocks <= sh.n_simd ? 4 : 1;
 }
 
+// mp_sampler_run evaluates a whole step per launch (3 x slots evaluations, a third of them discarded) while that beats two
+// half-step launches: up to 19/8 x n_simd evaluations (2 432 on an MI355X: ensembles of up to 1 621 walkers).  Two wavefronts per
+// SIMD hold 2 x n_simd of them at once; a little beyond, the second round is still shorter than a second launch (ms per step, whole
+// step / two half-steps: 1 364 walkers 0.140 / 0.191, 1 536 walkers 0.173 / 0.193, 1 700 walkers 0.201 / 0.193, 2 048 walkers
+// 0.216 / 0.195; until round 5 the limit was 2 x n_simd).
+inline bool stretch_whole_step_fits(const DevShared &sh, long long whole_step_blocks) { return 8 * whole_step_blocks <= 19 * (long long)sh.n_simd; }
+
 // Arguments of the batched right-hand-side evaluation (mp_kernels.hip: rhs_kernel), device pointers.
 struct RhsArgs {
     const double *pars;     // [n][ndim], physical units

@@ -57,12 +57,16 @@ def test_curve_kernel_rule_mirror(tmp_path):
     src = tmp_path / "rule.cpp"
     src.write_text('#include <cstdio>\n#include <initializer_list>\n#include "magprop_amd/csrc/mp_device.h"\n'
                    'int main() { mp::DevShared sh{}; for (int simd : {1024, 416}) { sh.n_simd = simd; '
-                   'for (int n = 1; n <= 20000; ++n) std::printf("%d", mp::kernel_spl_curves(sh, n)); std::printf("\\n"); } }\n')
+                   'for (int n = 1; n <= 20000; ++n) std::printf("%d", mp::kernel_spl_curves(sh, n)); std::printf("\\n"); '
+                   'for (int n = 1; n <= 20000; ++n) std::printf("%d", (int)mp::stretch_whole_step_fits(sh, n)); std::printf("\\n"); } }\n')
     exe = tmp_path / "rule"
     subprocess.run(["g++", "-std=c++17", "-O1", "-I", ROOT, str(src), "-o", str(exe)], check=True)
     rows = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
-    for simd, row in zip((1024, 416), rows):
-        assert row == "".join(str(_capi.curve_steps_per_lane(n, simd)) for n in range(1, 20001)), simd
+    for k, simd in enumerate((1024, 416)):
+        assert rows[2 * k] == "".join(str(_capi.curve_steps_per_lane(n, simd)) for n in range(1, 20001)), simd
+        # (likewise the size up to which the sampler evaluates a whole step per launch)
+        assert rows[2 * k + 1] == "".join(str(int(_capi.whole_step_fits(n, simd))) for n in range(1, 20001)), simd
+    assert _capi.whole_step_fits(3 * 810, 1024) and not _capi.whole_step_fits(3 * 811, 1024)
     # the measured points of profiles/r05_ab_curve_spl.log (an MI355X: 1 024 SIMDs)
     assert [_capi.curve_steps_per_lane(n, 1024) for n in (1024, 1536, 2048, 3072, 3584, 4096, 5120, 8192)] == [4, 2, 4, 4, 2, 4, 2, 2]
 

@@ -15,7 +15,7 @@ g = np.load(os.path.join(ROOT, "tests", "golden", "golden_synth.npz"))
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 truth = np.array([1.0, 5.0, -3.0, 2.0, -1.0, 0.0])
 tag = os.path.basename(os.environ.get("MAGPROP_AMD_LIB", "default"))
-for n in (24, 64, 128, 170, 256, 340, 512):
+for n in [int(v) for v in os.environ.get("NS", "24 64 128 170 256 340 512").split()]:
     p0 = truth + 1.0e-4 * np.random.default_rng(5).standard_normal((n, 6))
     row = []
     for w in (True, False):
