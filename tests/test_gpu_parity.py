@@ -713,6 +713,36 @@ def test_light_curves_with_real_swift_time_stamps(mpa, gswift, gsynth, name):
     assert_vs_reference(ll, r, np.isfinite(r), t, noise_mask(gswift, len(r), f"swift_{name}_libS_lsoda_noise_idx"))
 
 
+def test_long_light_curve_prior_wide_through_every_kernel_family(mpa, gswift, gsynth):
+    """2 048 walkers uniform over the prior box on the 1 921-point light curve with the time stamps of GRB 060614, through all
+    four kernel families of a LONG handle (round 5: teams of four wavefronts also serve such handles, the chunks of 64
+    observations dealt to the team's wavefronts): status identical walker by walker (flags and prior among them), the families
+    with 256-step tiles -- both team builds and the 4-steps-per-lane kernel -- to 1e-11 of each other, the 128-step tiles of the
+    2-steps-per-lane kernel within the cross-variant tolerance."""
+    from magprop_amd import LogProb
+    x, y, yerr = gswift["swift_060614_ds"]
+    lp_ = LogProb(x, y, yerr)
+    rng = np.random.default_rng(60614)
+    lo, hi = gsynth["prior_lower"], gsynth["prior_upper"]
+    P = lo + (hi - lo) * rng.random((2048, 6))
+    P[7] = hi + 0.25                                                        # outside the prior box
+    ns = lp_.handle.n_simd
+    big, st_big = lp_.handle.lnprob_batch(P, want_status=True)              # 2 steps per lane
+    assert st_big[7] == 3 and np.sum(st_big == 1) > 0 and np.sum(st_big == 0) > 1500
+    fams = {}
+    for name, size in (("team, a SIMD per wavefront", ns // 4 - 56), ("team, two per SIMD", ns // 2 - 12), ("4 steps per lane", ns - 124)):
+        out, st = lp_.handle.lnprob_batch(P[:size], want_status=True)
+        assert np.array_equal(st, st_big[:size]), name
+        ok = st == 0
+        assert np.all(out[~ok] == -np.inf), name
+        assert np.allclose(out[ok], big[:size][ok], rtol=CROSS_VARIANT_RTOL, atol=1e-9), name
+        fams[name] = out
+    n0 = ns // 4 - 56
+    ok = st_big[:n0] == 0
+    for name, out in fams.items():
+        assert np.allclose(out[:n0][ok], fams["4 steps per lane"][:n0][ok], rtol=1e-11, atol=0.0), name
+
+
 # ---------------------------------------------------------------- code/figure_3.py: the alternative torque law
 @pytest.mark.parametrize("model", ["piroott", "bucciantini"])
 def test_figure_3_models(mpa, gsynth, model):
